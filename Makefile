@@ -1,0 +1,32 @@
+# Builds every native piece in-tree:
+#   ky_amd/lib/libkyhip.so   the product: gfx950 kernels + C ABI (include/kyhip.h)
+#   ky_amd/lib/libkyhost.so  host-side C++ API (ky_amd/host/ky.hpp) behind a small C API for Python
+#   oracle/libkyoracle.so    the CPU checker (test infrastructure only)
+HIPCC    ?= hipcc
+CXX      ?= g++
+ROCM     ?= /opt/rocm
+HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
+LIBDIR   := ky_amd/lib
+
+all: $(LIBDIR)/libkyhip.so $(LIBDIR)/libkyhost.so oracle examples
+
+$(LIBDIR)/libkyhip.so: ky_amd/csrc/kyhip.hip ky_amd/csrc/ky_device.hpp include/kyhip.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ ky_amd/csrc/kyhip.hip
+
+$(LIBDIR)/libkyhost.so: ky_amd/host/ky_capi.cpp ky_amd/host/ky.hpp include/kyhip.h $(LIBDIR)/libkyhip.so
+	$(CXX) -O2 -std=c++17 -fPIC -Wall -shared -o $@ ky_amd/host/ky_capi.cpp -L$(LIBDIR) -lkyhip -Wl,-rpath,'$$ORIGIN'
+
+oracle:
+	$(MAKE) -C oracle
+
+EXAMPLES := $(patsubst examples/%.cpp,examples/bin/%,$(wildcard examples/*.cpp))
+examples: $(EXAMPLES)
+examples/bin/%: examples/%.cpp ky_amd/host/ky.hpp include/kyhip.h $(LIBDIR)/libkyhip.so
+	@mkdir -p examples/bin
+	$(CXX) -O2 -std=c++17 -Wall -o $@ $< -L$(LIBDIR) -lkyhip -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)'
+
+clean:
+	rm -rf $(LIBDIR) examples/bin
+	$(MAKE) -C oracle clean
+.PHONY: all oracle examples clean

@@ -1,0 +1,257 @@
+/*
+ * kyhip.h -- C ABI of the MI355X (gfx950) path-tracing integrator that replaces the body of
+ *            ky's `integrator_t::render()` for `path_tracing_iteration_t`.
+ *
+ * The reference (infancy/ky, one C++ translation unit) has no FFI layer; its seam for this hot
+ * path is the C++ call
+ *
+ *     void integrator_t::render(scene_t* scene, sampler_t* sampler, film_t* film)   ky.cpp:3689
+ *     virtual color_t integrator_t::Li(ray_t, scene_t*, sampler_t*)                 ky.cpp:3792
+ *     std::unique_ptr<integrator_t> create_integrator(enum, depth, direct_sample)   ky.cpp:4621
+ *
+ * This header is what a binding for that seam would declare: plain structs, pointers and sizes,
+ * no C++ / torch types.  Every entry point cites the reference interface it stands in for.
+ * The library (libkyhip.so) owns all device memory it allocates; caller-owned buffers are only
+ * read or accumulated into.  No entry point throws; all return 0 on success or a negative
+ * ky_status, and kyhip_last_error() returns a thread-local message for the last failure.
+ *
+ * All arithmetic on the path is fp32 (ky.cpp:171-172).
+ */
+#ifndef KYHIP_H
+#define KYHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KYHIP_ABI_VERSION 1
+
+/* ------------------------------------------------------------------------------------------
+ * Scene description: a flat restatement of what scene_t holds (ky.cpp:3535-3546) and what the
+ * path reads from it (SURVEY.md 8(b) "Inputs read by the path").
+ * ---------------------------------------------------------------------------------------- */
+
+/* shape_t subclasses, ky.cpp:1100 (disk), 1165 (triangle), 1245 (rectangle), 1326 (sphere) */
+typedef enum ky_shape_kind {
+    KY_SHAPE_DISK      = 0,
+    KY_SHAPE_TRIANGLE  = 1,
+    KY_SHAPE_RECTANGLE = 2,
+    KY_SHAPE_SPHERE    = 3
+} ky_shape_kind;
+
+typedef struct ky_shape {
+    int32_t kind;      /* ky_shape_kind */
+    float   p[4][3];   /* rectangle: p0..p3 (1318-1321); triangle: p0..p2 (1238-1240);
+                          disk: p[0] = position_ (1159); sphere: p[0] = center_ (1516) */
+    float   normal[3]; /* stored normal_ after flip_normal (1174-1176, 1256-1258), disk: normalize(normal) (1105) */
+    float   radius;    /* disk radius_ (1161), sphere radius_ (1517) */
+} ky_shape;
+
+/* material_t subclasses, ky.cpp:2579 (matte), 2596 (mirror), 2613 (glass), 2639 (plastic) */
+typedef enum ky_material_kind {
+    KY_MATERIAL_MATTE   = 0,
+    KY_MATERIAL_MIRROR  = 1,
+    KY_MATERIAL_GLASS   = 2,
+    KY_MATERIAL_PLASTIC = 3
+} ky_material_kind;
+
+typedef struct ky_material {
+    int32_t kind;                 /* ky_material_kind */
+    float   color0[3];            /* matte diffuse_color_ / mirror specular_color_ / glass reflection_color_ / plastic diffuse_color_ */
+    float   color1[3];            /* glass transmission_color_ / plastic specular_color_ */
+    float   eta;                  /* glass eta_ (2634); the outside index is 1 (2630) */
+    float   exponent;             /* plastic exponent_ (2677) */
+    float   diffuse_probability;  /* plastic diffuse_probility_  = lum(Kd)/(lum(Kd)+lum(Ks))   (2653-2657) */
+    float   specular_probability; /* plastic specular_probility_ = lum(Ks)/(lum(Kd)+lum(Ks))   (2658) */
+} ky_material;
+
+/* light_t subclasses, ky.cpp:2810 (point), 2868 (direction), 2923 (area), 2999 (environment) */
+typedef enum ky_light_kind {
+    KY_LIGHT_POINT       = 0,
+    KY_LIGHT_DIRECTION   = 1,
+    KY_LIGHT_AREA        = 2,
+    KY_LIGHT_ENVIRONMENT = 3
+} ky_light_kind;
+
+typedef struct ky_light {
+    int32_t kind;          /* ky_light_kind */
+    int32_t shape;         /* area: index into ky_scene.shapes of the shape it SAMPLES (area_light_t::shape_, 2993).
+                              May differ from the shape of the surface that carries the light (Veach lights 1/2, 3498-3499 vs 3525-3526) */
+    float   color[3];      /* point intensity_ / direction irradiance_ / area radiance_ / environment radiance_ */
+    float   position[3];   /* point: world_position_ (2802) */
+    float   direction[3];  /* direction: normalized world_direction_ (2874) */
+    float   world_radius;  /* direction / environment: world_radius_ set by preprocess (3555-3574) */
+} ky_light;
+
+/* surface_t, ky.cpp:3071-3075 */
+typedef struct ky_surface {
+    int32_t shape;       /* index into shapes */
+    int32_t material;    /* index into materials */
+    int32_t area_light;  /* index into lights, or -1 (nullptr) */
+} ky_surface;
+
+/* camera_t members after its constructor ran, ky.cpp:1900-1905 */
+typedef struct ky_camera {
+    float position[3];
+    float front[3];       /* normalized */
+    float right[3];       /* scaled by tan(fov/2) * aspect (1878) */
+    float up[3];          /* scaled by tan(fov/2)          (1879) */
+    float resolution[2];
+} ky_camera;
+
+typedef struct ky_scene {
+    const ky_shape*    shapes;    int32_t shape_count;
+    const ky_material* materials; int32_t material_count;
+    const ky_light*    lights;    int32_t light_count;     /* light_list_, in order (3541) */
+    const ky_surface*  surfaces;  int32_t surface_count;   /* surface_list_, in order: order decides ties (3177) */
+    int32_t            environment_light;                  /* index into lights of environment_light_ (3542), or -1 */
+    ky_camera          camera;
+} ky_scene;
+
+/* Hard limits of the device path (the scene lives in on-chip memory). */
+#define KYHIP_MAX_SHAPES    64
+#define KYHIP_MAX_SURFACES  64
+#define KYHIP_MAX_MATERIALS 32
+#define KYHIP_MAX_LIGHTS    16
+
+/* ------------------------------------------------------------------------------------------
+ * Render parameters.
+ * ---------------------------------------------------------------------------------------- */
+
+/* integrator_enum_t values that have a device path (ky.cpp:3625-3654). */
+typedef enum ky_integrator_kind {
+    KY_INTEGRATOR_POSITION               = 0,  /* debug_integrator_t, 4112 */
+    KY_INTEGRATOR_NORMAL                 = 1,  /* debug_integrator_t, 4114 */
+    KY_INTEGRATOR_BASECOLOR              = 2,  /* debug_integrator_t, 4116 */
+    KY_INTEGRATOR_DIRECT_LIGHTING        = 6,  /* direct_lighting_t, 4125 */
+    KY_INTEGRATOR_PATH_TRACING_ITERATION = 11  /* path_tracing_iteration_t, 4523 -- the hot path */
+} ky_integrator_kind;
+
+/* direct_sample_enum_t (ky.cpp:3608-3623).  Matched by exact value (3840-3862). */
+typedef enum ky_direct_sample {
+    KY_DIRECT_IDLE      = 0,
+    KY_DIRECT_BSDF      = 4,
+    KY_DIRECT_LIGHT     = 8,
+    KY_DIRECT_BSDF_MIS  = 16,
+    KY_DIRECT_LIGHT_MIS = 32,
+    KY_DIRECT_BOTH_MIS  = 48
+} ky_direct_sample;
+
+/* sampler_t subclasses that can be instantiated (ky.cpp:922, 949). */
+typedef enum ky_sampler_kind {
+    KY_SAMPLER_DEBUG  = 0,  /* debug_sampler_t: every number 0.5, camera sample = pixel centre (933-946) */
+    KY_SAMPLER_RANDOM = 1   /* random_sampler_t semantics (uniform [0,1) fp32) on a counter-based generator
+                               keyed (seed, pixel, sample, dimension); see DESIGN.md "Random numbers" */
+} ky_sampler_kind;
+
+typedef struct ky_render_params {
+    int32_t  integrator;         /* ky_integrator_kind */
+    int32_t  max_path_depth;     /* path_integrator_t::max_path_depth_ (4182) */
+    int32_t  direct_sample;      /* ky_direct_sample, path_integrator_t::direct_sample_enum_ (4183) */
+    int32_t  samples_per_pixel;  /* sampler_t::samples_per_pixel_ (918) */
+    int32_t  sampler;            /* ky_sampler_kind */
+    uint32_t seed;               /* rng_t seed, default 1234 (833) */
+    int32_t  width, height;      /* film->get_resolution() (3692): the pixel loop bounds */
+    /* Image-tile sharding.  The film is cut into tile_w x tile_h tiles numbered
+       row-major; this call renders tiles tile_first, tile_first+tile_step, ...  A single-GPU render
+       uses tile_first = 0, tile_step = 1.  tile_w and tile_h must be multiples of 8. */
+    int32_t  tile_w, tile_h;
+    int32_t  tile_first, tile_step;
+} ky_render_params;
+
+typedef enum ky_status {
+    KY_OK                = 0,
+    KY_ERR_INVALID_VALUE = -1,  /* bad argument, unknown enum (create_integrator returns nullptr, 4638;
+                                   sample_all_light leaves the std::function empty, 3860) */
+    KY_ERR_LIMIT         = -2,  /* scene larger than the KYHIP_MAX_* limits */
+    KY_ERR_DEVICE        = -3,  /* HIP runtime error (message has the hipError string) */
+    KY_ERR_NO_DEVICE     = -4   /* no gfx950 device visible: the product has no CPU fallback */
+} ky_status;
+
+const char* kyhip_last_error(void);
+int         kyhip_abi_version(void);
+int         kyhip_device_count(void);
+
+/* Number of tiles this (first, step) shard owns, and the float count of its compact tile buffer
+   (tiles * tile_w * tile_h * 3).  Pure host arithmetic. */
+int64_t kyhip_shard_tile_count(const ky_render_params* params);
+int64_t kyhip_shard_float_count(const ky_render_params* params);
+
+/*
+ * kyhip_render -- drop-in for integrator_t::render(scene, sampler, film) (ky.cpp:3689-3729).
+ *   film_rgb           caller-owned HOST buffer of film_t::pixels_ layout (AoS RGB fp32, row-major,
+ *                      y down, ky.cpp:1574); the library ADDS clamp01(mean radiance) per pixel,
+ *                      exactly like film_t::add_color (1586-1590, 3726).
+ *   film_row_stride_px row stride in pixels (>= params->width), and film_rgb may point at the
+ *                      first pixel of a sub-film, so a film_grid_t cell can be the target (1817-1822).
+ * Renders the shard named by params (all tiles when tile_first = 0, tile_step = 1) on `device`.
+ * Blocking.
+ */
+int kyhip_render(int device, const ky_scene* scene, const ky_render_params* params,
+                 float* film_rgb, size_t film_row_stride_px);
+
+/*
+ * Device-resident variants used by the multi-GPU path and by bench.py (inputs and outputs stay in
+ * HBM; nothing crosses PCIe inside the timed region).
+ *
+ * kyhip_render_tiles_device: renders this shard's tiles into `d_tiles`, a DEVICE buffer of
+ *   kyhip_shard_float_count() floats laid out [local_tile][ty][tx][rgb]; every pixel is written
+ *   with clamp01(mean radiance) (pixels of edge tiles outside the film are written as 0).
+ *   `stream` is a hipStream_t (0 = default stream).  Asynchronous w.r.t. the host.
+ *   `d_workspace`/`workspace_bytes`: device scratch of at least kyhip_workspace_bytes(); may be
+ *   NULL, in which case the library allocates and caches one per device.
+ *
+ * kyhip_film_add_tiles_device: the de-interleave step after the gather: adds the compact tiles of
+ *   shard (tile_first, tile_step) into a DEVICE film (same layout as kyhip_render's film_rgb).
+ */
+size_t kyhip_workspace_bytes(const ky_render_params* params);
+int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render_params* params,
+                              float* d_tiles, void* d_workspace, size_t workspace_bytes, void* stream);
+int kyhip_film_add_tiles_device(int device, const ky_render_params* params, const float* d_tiles,
+                                float* d_film_rgb, size_t film_row_stride_px, void* stream);
+
+/*
+ * Duration in milliseconds of the integrator kernel (render_kernel) of the most recent
+ * kyhip_render* call on `device`, from hipEvents recorded on the launch stream around that one
+ * kernel.  The stream must have been synchronised.  Negative if no timing is available.
+ */
+float kyhip_kernel_ms(int device);
+
+/* ------------------------------------------------------------------------------------------
+ * Function-level entry points (known-answer tests).  Each runs the DEVICE implementation of one
+ * reference function over n host-side inputs and copies the results back.  Blocking.
+ * ---------------------------------------------------------------------------------------- */
+
+/* shape_t::intersect (1111, 1179, 1261, 1336).  rays: n x {o[3], d[3], tmax}.
+   out: n x {hit(0/1), t, p[3], n[3]}. */
+int kyhip_kat_intersect(int device, const ky_shape* shape, const float* rays7, int n, float* out8);
+
+/* camera_t::generate_ray (1884-1892).  p_film: n x {x, y}.  out: n x {o[3], d[3]}. */
+int kyhip_kat_camera(int device, const ky_camera* camera, const float* p_film2, int n, float* out6);
+
+/* surface_t::intersect + material_t::scattering + bsdf_t::{sample, eval, pdf} (3077, 2587-2671, 2162-2179).
+   in: n x {normal[3], wo[3], u[2], wi_eval[3], lobe_u}.  out: n x {f[3], wi[3], pdf, flags, eval[3], pdf_eval, is_delta}. */
+int kyhip_kat_bsdf(int device, const ky_material* material, const float* in12, int n, float* out13);
+
+/* light_t::sample_Li / pdf_Li (2825, 2891, 2964, 3026).
+   in: n x {p[3], normal[3], u[2], wi[3]}.  out: n x {position[3], wi[3], pdf, Li[3], pdf_Li}. */
+int kyhip_kat_light(int device, const ky_scene* scene, int light, const float* in11, int n, float* out11);
+
+/* scene_t::intersect (3172) and scene_t::occluded (3187-3201).
+   rays7 as above.  out: n x {hit, t, p[3], n[3], surface}.
+   occluded: in n x {p[3], normal[3], target[3]}, out n x {0/1}. */
+int kyhip_kat_scene_intersect(int device, const ky_scene* scene, const float* rays7, int n, float* out9);
+int kyhip_kat_occluded(int device, const ky_scene* scene, const float* in9, int n, float* out1);
+
+/* integrator_t::Li per camera sample (3714-3717): for pixel (x, y) and samples [s0, s0+n) writes the
+   unclamped radiance Li (3 floats per sample) -- the quantity `dL` is built from. */
+int kyhip_kat_li(int device, const ky_scene* scene, const ky_render_params* params,
+                 int x, int y, int s0, int n, float* out3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KYHIP_H */

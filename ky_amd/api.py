@@ -1,0 +1,173 @@
+"""Python plumbing over the C ABI (include/kyhip.h) and the C++ host layer (ky_amd/host/ky.hpp).
+
+Nothing here computes radiance: every function forwards to libkyhip.so (HIP kernels) or to the C++ host
+classes.  numpy is used for host buffers only.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as A
+
+
+class KyError(RuntimeError):
+    pass
+
+
+def _check(rc, lib=None):
+    if rc != A.KY_OK:
+        lib = lib or A.load_kyhip()
+        raise KyError(f"kyhip error {rc}: {lib.kyhip_last_error().decode()}")
+
+
+def _fptr(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class SceneHandle:
+    """A scene built by the C++ host layer (scene_t::create_*_scene) plus its flat C-ABI view."""
+
+    def __init__(self, ptr):
+        if not ptr:
+            raise KyError("scene creation failed: " + A.load_kyhost().kyhost_last_error().decode())
+        self._ptr = C.c_void_p(ptr)
+        self._host = A.load_kyhost()
+        self.flat = self._host.kyhost_scene_flatten(self._ptr)
+        if not self.flat:
+            raise KyError("scene flatten failed: " + self._host.kyhost_last_error().decode())
+
+    def __del__(self):
+        try:
+            if self._ptr:
+                self._host.kyhost_scene_destroy(self._ptr)
+                self._ptr = None
+        except Exception:
+            pass
+
+    @property
+    def c(self):
+        return self.flat.contents
+
+    @property
+    def ptr(self):
+        return self._ptr
+
+
+def cornell_box_scene(flags, width, height):
+    """scene_t::create_cornell_box_scene(flags, {width, height}) -- ky.cpp:3240."""
+    return SceneHandle(A.load_kyhost().kyhost_scene_create_cornell_box(int(flags), float(width), float(height)))
+
+
+def mis_scene(width, height):
+    """scene_t::create_mis_scene({width, height}) -- ky.cpp:3434."""
+    return SceneHandle(A.load_kyhost().kyhost_scene_create_mis(float(width), float(height)))
+
+
+def make_params(width, height, spp, integrator=A.INTEGRATOR_PATH_TRACING_ITERATION, max_path_depth=5,
+                direct_sample=A.DIRECT_BOTH_MIS, sampler=A.SAMPLER_RANDOM, seed=1234, tile_w=32, tile_h=32,
+                tile_first=0, tile_step=1):
+    return A.RenderParams(integrator, max_path_depth, direct_sample, spp, sampler, seed, width, height, tile_w, tile_h,
+                          tile_first, tile_step)
+
+
+def _scene_ptr(scene):
+    return scene.flat if isinstance(scene, SceneHandle) else scene
+
+
+def render(scene, params, film=None, device=0, row_stride_px=None, origin_px=(0, 0)):
+    """kyhip_render: integrator_t::render(scene, sampler, film) on the GPU; returns the (accumulated) host film."""
+    lib = A.load_kyhip()
+    if film is None:
+        film = np.zeros((params.height, params.width, 3), np.float32)
+    stride = film.shape[1] if row_stride_px is None else row_stride_px
+    base = film.ctypes.data + (origin_px[1] * stride + origin_px[0]) * 12
+    _check(lib.kyhip_render(device, _scene_ptr(scene), C.byref(params), C.c_void_p(base), stride))
+    return film
+
+
+def render_host_api(scene, integrator_enum, depth, direct_sample, sampler, spp, width, height, seed=1234,
+                    grid=None, cell=0, film=None, device=0):
+    """Drive the C++ host classes exactly like a reference driver: create_integrator(...)->render(&scene, sampler, &film)."""
+    host = A.load_kyhost()
+    rows, cols = grid if grid else (0, 0)
+    fw, fh = (cols * width, rows * height) if grid else (width, height)
+    if film is None:
+        film = np.zeros((fh, fw, 3), np.float32)
+    rc = host.kyhost_render(scene.ptr, integrator_enum, depth, direct_sample, sampler, spp, seed, width, height, rows, cols,
+                            cell, _fptr(film), device)
+    if rc == -2:
+        return None  # create_integrator returned nullptr (ky.cpp:4638)
+    if rc != 0:
+        raise KyError("kyhost_render failed: " + host.kyhost_last_error().decode())
+    return film
+
+
+def kernel_ms(device=0):
+    return float(A.load_kyhip().kyhip_kernel_ms(device))
+
+
+# ---- function-level entry points (parity tests) -------------------------------------------------
+
+def kat_intersect(shape, rays7, device=0):
+    lib = A.load_kyhip()
+    rays7 = np.ascontiguousarray(rays7, np.float32)
+    out = np.zeros((rays7.shape[0], 8), np.float32)
+    _check(lib.kyhip_kat_intersect(device, C.byref(shape), _fptr(rays7), rays7.shape[0], _fptr(out)))
+    return out
+
+
+def kat_camera(camera, p_film2, device=0):
+    lib = A.load_kyhip()
+    p_film2 = np.ascontiguousarray(p_film2, np.float32)
+    out = np.zeros((p_film2.shape[0], 6), np.float32)
+    _check(lib.kyhip_kat_camera(device, C.byref(camera), _fptr(p_film2), p_film2.shape[0], _fptr(out)))
+    return out
+
+
+def kat_bsdf(material, in12, device=0):
+    lib = A.load_kyhip()
+    in12 = np.ascontiguousarray(in12, np.float32)
+    out = np.zeros((in12.shape[0], 13), np.float32)
+    _check(lib.kyhip_kat_bsdf(device, C.byref(material), _fptr(in12), in12.shape[0], _fptr(out)))
+    return out
+
+
+def kat_light(scene, light, in11, device=0):
+    lib = A.load_kyhip()
+    in11 = np.ascontiguousarray(in11, np.float32)
+    out = np.zeros((in11.shape[0], 11), np.float32)
+    _check(lib.kyhip_kat_light(device, _scene_ptr(scene), light, _fptr(in11), in11.shape[0], _fptr(out)))
+    return out
+
+
+def kat_scene_intersect(scene, rays7, device=0):
+    lib = A.load_kyhip()
+    rays7 = np.ascontiguousarray(rays7, np.float32)
+    out = np.zeros((rays7.shape[0], 9), np.float32)
+    _check(lib.kyhip_kat_scene_intersect(device, _scene_ptr(scene), _fptr(rays7), rays7.shape[0], _fptr(out)))
+    return out
+
+
+def kat_occluded(scene, in9, device=0):
+    lib = A.load_kyhip()
+    in9 = np.ascontiguousarray(in9, np.float32)
+    out = np.zeros((in9.shape[0],), np.float32)
+    _check(lib.kyhip_kat_occluded(device, _scene_ptr(scene), _fptr(in9), in9.shape[0], _fptr(out)))
+    return out
+
+
+def kat_li(scene, params, x, y, s0, n, device=0):
+    lib = A.load_kyhip()
+    out = np.zeros((n, 3), np.float32)
+    _check(lib.kyhip_kat_li(device, _scene_ptr(scene), C.byref(params), x, y, s0, n, _fptr(out)))
+    return out
+
+
+def store_image(filename, rgb, kind="bmp"):
+    """film_t::store_{ppm,bmp,hdr}_impl -- ky.cpp:1646-1782."""
+    host = A.load_kyhost()
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    k = {"ppm": 0, "bmp": 1, "hdr": 2}[kind]
+    if host.kyhost_store_image(filename.encode(), k, rgb.shape[1], rgb.shape[0], _fptr(rgb)) != 0:
+        raise KyError("store_image failed: " + host.kyhost_last_error().decode())

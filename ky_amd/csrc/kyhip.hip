@@ -1,0 +1,656 @@
+/*
+ * kyhip.hip -- kernels and C ABI of libkyhip.so (see include/kyhip.h).
+ *
+ * Kernel structure (DESIGN.md "Kernels"):
+ *   render_kernel     persistent workgroups; each wavefront pulls work items (an 8x8 pixel block x a
+ *                     chunk of samples) from a device counter; one lane owns one pixel and runs a flat
+ *                     state machine over path vertices, regenerating a new camera sample the moment
+ *                     its path ends, so lanes stay busy without any path state in HBM.
+ *   reduce_kernel     sums the per-chunk partial pixel sums in chunk order, clamps, writes the tile buffer.
+ *   film_add_kernel   film_t::add_color (ky.cpp:1586) for a shard's compact tile buffer.
+ *   kat_*             function-level known-answer-test kernels.
+ * gfx950 only; no CPU fallback anywhere in this file.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "ky_device.hpp"
+
+using namespace kyd;
+
+// ------------------------------------------------------------------------------------------------
+// error handling
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_error;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(KY_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// shard geometry (host + device)
+// ------------------------------------------------------------------------------------------------
+struct ShardConst {
+    int tile_w, tile_h, tile_first, tile_step;
+    int tiles_x, tiles_y, n_tiles;     // tiles of the whole film / tiles owned by this shard
+    int blocks_w, blocks_per_tile;     // 8x8 pixel blocks inside a tile
+    int n_blocks;                      // n_tiles * blocks_per_tile
+    int n_chunks, chunk_size;          // sample chunks
+    unsigned n_items;                  // n_blocks * n_chunks
+    int n_pix;                         // n_tiles * tile_w * tile_h
+};
+
+static bool valid_params(const ky_render_params* p) {
+    if (!p) return false;
+    if (p->width <= 0 || p->height <= 0 || p->samples_per_pixel <= 0 || p->max_path_depth < 0) return false;
+    if (p->tile_w <= 0 || p->tile_h <= 0 || (p->tile_w % 8) || (p->tile_h % 8)) return false;
+    if (p->tile_first < 0 || p->tile_step <= 0) return false;
+    switch (p->integrator) {
+    case KY_INTEGRATOR_POSITION: case KY_INTEGRATOR_NORMAL: case KY_INTEGRATOR_BASECOLOR:
+    case KY_INTEGRATOR_DIRECT_LIGHTING: case KY_INTEGRATOR_PATH_TRACING_ITERATION: break;
+    default: return false;   // create_integrator returns nullptr (ky.cpp:4638)
+    }
+    switch (p->direct_sample) {
+    case KY_DIRECT_IDLE: case KY_DIRECT_BSDF: case KY_DIRECT_LIGHT: case KY_DIRECT_BSDF_MIS:
+    case KY_DIRECT_LIGHT_MIS: case KY_DIRECT_BOTH_MIS: break;
+    default: return false;   // empty std::function -> bad_function_call (ky.cpp:3860)
+    }
+    if (p->sampler != KY_SAMPLER_DEBUG && p->sampler != KY_SAMPLER_RANDOM) return false;
+    return true;
+}
+
+static ShardConst make_shard(const ky_render_params* p, int target_items) {
+    ShardConst s{};
+    s.tile_w = p->tile_w; s.tile_h = p->tile_h; s.tile_first = p->tile_first; s.tile_step = p->tile_step;
+    s.tiles_x = (p->width + p->tile_w - 1) / p->tile_w;
+    s.tiles_y = (p->height + p->tile_h - 1) / p->tile_h;
+    const int total = s.tiles_x * s.tiles_y;
+    s.n_tiles = p->tile_first >= total ? 0 : (total - p->tile_first + p->tile_step - 1) / p->tile_step;
+    s.blocks_w = p->tile_w / 8;
+    s.blocks_per_tile = s.blocks_w * (p->tile_h / 8);
+    s.n_blocks = s.n_tiles * s.blocks_per_tile;
+    s.n_pix = s.n_tiles * p->tile_w * p->tile_h;
+    // split the samples of a pixel into chunks until there are enough work items to balance the chip
+    int chunks = 1;
+    if (s.n_blocks > 0 && target_items > 0) chunks = (target_items + s.n_blocks - 1) / s.n_blocks;
+    if (chunks > p->samples_per_pixel) chunks = p->samples_per_pixel;
+    if (chunks < 1) chunks = 1;
+    s.chunk_size = (p->samples_per_pixel + chunks - 1) / chunks;
+    s.n_chunks = (p->samples_per_pixel + s.chunk_size - 1) / s.chunk_size;
+    s.n_items = (unsigned)s.n_blocks * (unsigned)s.n_chunks;
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+template <bool DEBUG_SAMPLER>
+__global__ __launch_bounds__(256) void render_kernel(const DScene* __restrict__ S, RenderConst rc, ShardConst sh,
+                                                     unsigned* __restrict__ counter, float* __restrict__ out) {
+    __shared__ LdsScene Lds;
+    stage_scene(Lds, S);
+
+    const int lane = threadIdx.x & 63;
+    const int lx = lane & 7, ly = lane >> 3;
+
+    for (;;) {
+        unsigned item = 0;
+        if (lane == 0) item = atomicAdd(counter, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= sh.n_items) break;
+
+        const int b = (int)(item / (unsigned)sh.n_chunks), c = (int)(item % (unsigned)sh.n_chunks);
+        const int k = b / sh.blocks_per_tile, inner = b % sh.blocks_per_tile;
+        const int bx = inner % sh.blocks_w, by = inner / sh.blocks_w;
+        const int tile = sh.tile_first + k * sh.tile_step;
+        const int tx = tile % sh.tiles_x, ty = tile / sh.tiles_x;
+        const int x = tx * sh.tile_w + bx * 8 + lx, y = ty * sh.tile_h + by * 8 + ly;
+        const bool in_range = x < rc.width && y < rc.height;
+        const int s_begin = c * sh.chunk_size;
+        const int s_end = min(rc.spp, s_begin + sh.chunk_size);
+
+        PathState ps;
+        bool alive = false;
+        int s = in_range ? s_begin : s_end;
+        f3 Lpix = mk3(0, 0, 0);
+        for (;;) {
+            if (!alive && s < s_end) {  // sampler->next_sample / get_camera_sample / generate_ray, 3712-3715
+                path_begin<DEBUG_SAMPLER>(ps, S, rc, x, y, s);
+                ++s;
+                alive = true;
+            }
+            if (!__any(alive)) break;
+            if (alive) {
+                if (!path_step<DEBUG_SAMPLER>(ps, S, Lds, rc)) {
+                    Lpix = Lpix + ps.Lo * rc.inv_spp;  // L = L + Li * (1. / spp), 3717-3721
+                    alive = false;
+                }
+            }
+        }
+
+        const int pix = (k * sh.tile_h + by * 8 + ly) * sh.tile_w + bx * 8 + lx;
+        float* dst = out + ((size_t)c * sh.n_pix + pix) * 3;
+        if (sh.n_chunks == 1) {  // clamp01(L), 3726
+            dst[0] = fminf(fmaxf(Lpix.x, 0.f), 1.f);
+            dst[1] = fminf(fmaxf(Lpix.y, 0.f), 1.f);
+            dst[2] = fminf(fmaxf(Lpix.z, 0.f), 1.f);
+        } else {
+            dst[0] = Lpix.x; dst[1] = Lpix.y; dst[2] = Lpix.z;
+        }
+    }
+}
+
+__global__ void reduce_kernel(const float* __restrict__ partial, float* __restrict__ tiles, int n_floats, int n_chunks) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_floats) return;
+    float acc = 0.f;
+    for (int c = 0; c < n_chunks; ++c) acc += partial[(size_t)c * n_floats + i];
+    tiles[i] = fminf(fmaxf(acc, 0.f), 1.f);
+}
+
+__global__ void film_add_kernel(const float* __restrict__ tiles, float* __restrict__ film, size_t stride_px, ShardConst sh, int width, int height) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sh.n_pix) return;
+    const int per_tile = sh.tile_w * sh.tile_h;
+    const int k = i / per_tile, r = i % per_tile;
+    const int tile = sh.tile_first + k * sh.tile_step;
+    const int x = (tile % sh.tiles_x) * sh.tile_w + r % sh.tile_w;
+    const int y = (tile / sh.tiles_x) * sh.tile_h + r / sh.tile_w;
+    if (x >= width || y >= height) return;
+    float* px = film + ((size_t)y * stride_px + x) * 3;
+    px[0] += tiles[3 * (size_t)i]; px[1] += tiles[3 * (size_t)i + 1]; px[2] += tiles[3 * (size_t)i + 2];
+}
+
+// ---- KAT kernels ----
+struct KatShape { float p[4][3]; float n[3]; float radius; float radius_sq; int kind; };
+
+__global__ void kat_intersect_kernel(KatShape sh, const float* __restrict__ rays7, int n, float* __restrict__ out8) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays7 + 7 * (size_t)i;
+    const f3 o = ld3(r), d = ld3(r + 3);
+    float t;
+    const bool hit = shape_hit(sh, sh.kind, o, d, r[6], t);
+    DHit H;
+    H.kind = sh.kind;
+    if (sh.kind == KY_SHAPE_SPHERE) { H.n[0] = sh.p[0][0]; H.n[1] = sh.p[0][1]; H.n[2] = sh.p[0][2]; }
+    else { H.n[0] = sh.n[0]; H.n[1] = sh.n[1]; H.n[2] = sh.n[2]; }
+    float* o8 = out8 + 8 * (size_t)i;
+    f3 p = mk3(0, 0, 0), nn = mk3(0, 0, 0);
+    if (hit) { p = o + t * d; nn = hit_normal(H, p, d); }
+    o8[0] = hit ? 1.f : 0.f; o8[1] = hit ? t : 0.f;
+    o8[2] = p.x; o8[3] = p.y; o8[4] = p.z; o8[5] = nn.x; o8[6] = nn.y; o8[7] = nn.z;
+}
+
+__global__ void kat_camera_kernel(const DScene* __restrict__ S, const float* __restrict__ pf, int n, float* __restrict__ out6) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f3 o, d;
+    generate_ray(S, pf[2 * (size_t)i], pf[2 * (size_t)i + 1], o, d);
+    float* q = out6 + 6 * (size_t)i;
+    q[0] = o.x; q[1] = o.y; q[2] = o.z; q[3] = d.x; q[4] = d.y; q[5] = d.z;
+}
+
+__global__ void kat_bsdf_kernel(DMat M, const float* __restrict__ in12, int n, float* __restrict__ out13) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = in12 + 12 * (size_t)i;
+    const f3 normal = ld3(r), wo = ld3(r + 3), wi_eval = ld3(r + 8);
+    const Bsdf B = make_bsdf(M, r[11]);
+    const Frame fr = make_frame(normal);
+    BsdfSample bs = bsdf_sample_local(B, to_local(fr, wo), r[6], r[7]);
+    bs.wi = to_world(fr, bs.wi);
+    f3 ev; float pd;
+    bsdf_eval_pdf(B, to_local(fr, wo), to_local(fr, wi_eval), ev, pd);
+    float* q = out13 + 13 * (size_t)i;
+    q[0] = bs.f.x; q[1] = bs.f.y; q[2] = bs.f.z; q[3] = bs.wi.x; q[4] = bs.wi.y; q[5] = bs.wi.z; q[6] = bs.pdf;
+    q[7] = (float)bs.flags; q[8] = ev.x; q[9] = ev.y; q[10] = ev.z; q[11] = pd; q[12] = bsdf_is_delta(B) ? 1.f : 0.f;
+}
+
+__global__ void kat_light_kernel(const DScene* __restrict__ S, int li, const float* __restrict__ in11, int n, float* __restrict__ out11) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = in11 + 11 * (size_t)i;
+    const f3 p = ld3(r), pn = ld3(r + 3), wi = ld3(r + 8);
+    const LightSample ls = light_sample_Li(S->light[li], p, pn, r[6], r[7]);
+    const float pdf = light_pdf_Li(S->light[li], p, pn, wi);
+    float* q = out11 + 11 * (size_t)i;
+    q[0] = ls.position.x; q[1] = ls.position.y; q[2] = ls.position.z; q[3] = ls.wi.x; q[4] = ls.wi.y; q[5] = ls.wi.z;
+    q[6] = ls.pdf; q[7] = ls.Li.x; q[8] = ls.Li.y; q[9] = ls.Li.z; q[10] = pdf;
+}
+
+__global__ void kat_scene_intersect_kernel(const DScene* __restrict__ S, const float* __restrict__ rays7, int n, float* __restrict__ out9) {
+    __shared__ LdsScene Lds;
+    stage_scene(Lds, S);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays7 + 7 * (size_t)i;
+    const f3 o = ld3(r), d = ld3(r + 3);
+    float t = r[6];
+    const int hs = trace_nearest(S, o, d, t);
+    f3 p = mk3(0, 0, 0), nn = mk3(0, 0, 0);
+    if (hs >= 0) { p = o + t * d; nn = hit_normal(Lds.hit[hs], p, d); }
+    float* q = out9 + 9 * (size_t)i;
+    q[0] = hs >= 0 ? 1.f : 0.f; q[1] = hs >= 0 ? t : 0.f;
+    q[2] = p.x; q[3] = p.y; q[4] = p.z; q[5] = nn.x; q[6] = nn.y; q[7] = nn.z; q[8] = (float)hs;
+}
+
+__global__ void kat_occluded_kernel(const DScene* __restrict__ S, const float* __restrict__ in9, int n, float* __restrict__ out1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = in9 + 9 * (size_t)i;
+    const f3 p = ld3(r), pn = ld3(r + 3), target = ld3(r + 6);
+    const f3 dir = normalize(target - p);
+    const float dist = sqrtf(length_sq(p - target));
+    const f3 o = offset_ray_origin(p, pn, dir);
+    out1[i] = trace_any(S, o, dir, dist - 2e-3f) ? 1.f : 0.f;
+}
+
+template <bool DEBUG_SAMPLER>
+__global__ void kat_li_kernel(const DScene* __restrict__ S, RenderConst rc, int x, int y, int s0, int n, float* __restrict__ out3) {
+    __shared__ LdsScene Lds;
+    stage_scene(Lds, S);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    PathState ps;
+    path_begin<DEBUG_SAMPLER>(ps, S, rc, x, y, s0 + i);
+    while (path_step<DEBUG_SAMPLER>(ps, S, Lds, rc)) {}
+    out3[3 * (size_t)i] = ps.Lo.x; out3[3 * (size_t)i + 1] = ps.Lo.y; out3[3 * (size_t)i + 2] = ps.Lo.z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static void cp3(float* d, const float* s) { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; }
+
+static float host_shape_area(const ky_shape& s) {  // shape_t::area x4 (1141, 1222, 1304, 1401), fp32
+    auto sub = [](const float* a, const float* b, float* r) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; };
+    auto crossmag = [](const float* a, const float* b) {
+        const float cx = a[1] * b[2] - a[2] * b[1], cy = a[2] * b[0] - a[0] * b[2], cz = a[0] * b[1] - a[1] * b[0];
+        return std::sqrt(cx * cx + cy * cy + cz * cz);
+    };
+    const float pi = 3.14159265358979323846f;
+    float u[3], v[3];
+    switch (s.kind) {
+    case KY_SHAPE_DISK: return pi * s.radius * s.radius;
+    case KY_SHAPE_TRIANGLE: sub(s.p[1], s.p[0], u); sub(s.p[2], s.p[0], v); return 0.5f * crossmag(u, v);
+    case KY_SHAPE_RECTANGLE: sub(s.p[0], s.p[1], u); sub(s.p[2], s.p[1], v); return crossmag(u, v);
+    default: return 4 * pi * (s.radius * s.radius);
+    }
+}
+
+static int pack_scene(const ky_scene* in, DScene* out) {
+    if (!in) return fail(KY_ERR_INVALID_VALUE, "scene is NULL");
+    if (in->surface_count < 0 || in->shape_count < 0 || in->material_count < 0 || in->light_count < 0)
+        return fail(KY_ERR_INVALID_VALUE, "negative count in scene");
+    if (in->surface_count > KYHIP_MAX_SURFACES || in->shape_count > KYHIP_MAX_SHAPES || in->material_count > KYHIP_MAX_MATERIALS ||
+        in->light_count > KYHIP_MAX_LIGHTS)
+        return fail(KY_ERR_LIMIT, "scene exceeds device limits (%d surfaces, %d shapes, %d materials, %d lights)", in->surface_count,
+                    in->shape_count, in->material_count, in->light_count);
+    if (in->environment_light < -1 || in->environment_light >= in->light_count) return fail(KY_ERR_INVALID_VALUE, "environment_light out of range");
+    std::memset(out, 0, sizeof *out);
+    out->n_surfaces = in->surface_count; out->n_lights = in->light_count; out->n_materials = in->material_count;
+    out->env_light = in->environment_light;
+    cp3(out->cam_position, in->camera.position); cp3(out->cam_front, in->camera.front); cp3(out->cam_right, in->camera.right);
+    cp3(out->cam_up, in->camera.up);
+    out->cam_w = in->camera.resolution[0]; out->cam_h = in->camera.resolution[1];
+    for (int i = 0; i < in->surface_count; ++i) {
+        const ky_surface& sf = in->surfaces[i];
+        if (sf.shape < 0 || sf.shape >= in->shape_count || sf.material < 0 || sf.material >= in->material_count || sf.area_light < -1 ||
+            sf.area_light >= in->light_count)
+            return fail(KY_ERR_INVALID_VALUE, "surface %d has an index out of range", i);
+        const ky_shape& sh = in->shapes[sf.shape];
+        if (sh.kind < KY_SHAPE_DISK || sh.kind > KY_SHAPE_SPHERE) return fail(KY_ERR_INVALID_VALUE, "shape %d has an unknown kind", sf.shape);
+        if (sf.area_light >= 0 && in->lights[sf.area_light].kind != KY_LIGHT_AREA)
+            return fail(KY_ERR_INVALID_VALUE, "surface %d: area_light must refer to an area light", i);
+        DSurf& d = out->surf[i];
+        std::memcpy(d.p, sh.p, sizeof d.p);
+        cp3(d.n, sh.normal);
+        d.kind = sh.kind; d.radius = sh.radius; d.radius_sq = sh.radius * sh.radius;  // sphere_t::radius_sq_, 1332
+        DHit& h = out->hit[i];
+        cp3(h.n, sh.kind == KY_SHAPE_SPHERE ? sh.p[0] : sh.normal);
+        h.kind = sh.kind; h.material = sf.material; h.area_light = sf.area_light;
+    }
+    for (int i = 0; i < in->material_count; ++i) {
+        const ky_material& m = in->materials[i];
+        if (m.kind < KY_MATERIAL_MATTE || m.kind > KY_MATERIAL_PLASTIC) return fail(KY_ERR_INVALID_VALUE, "material %d has an unknown kind", i);
+        DMat& d = out->mat[i];
+        cp3(d.c0, m.color0); cp3(d.c1, m.color1);
+        d.kind = m.kind; d.eta = m.eta; d.exponent = m.exponent; d.p_diffuse = m.diffuse_probability; d.p_specular = m.specular_probability;
+    }
+    for (int i = 0; i < in->light_count; ++i) {
+        const ky_light& l = in->lights[i];
+        if (l.kind < KY_LIGHT_POINT || l.kind > KY_LIGHT_ENVIRONMENT) return fail(KY_ERR_INVALID_VALUE, "light %d has an unknown kind", i);
+        DLight& d = out->light[i];
+        cp3(d.color, l.color); cp3(d.position, l.position); cp3(d.direction, l.direction);
+        d.kind = l.kind; d.world_radius = l.world_radius; d.shape_kind = -1;
+        if (l.kind == KY_LIGHT_AREA) {
+            if (l.shape < 0 || l.shape >= in->shape_count) return fail(KY_ERR_INVALID_VALUE, "area light %d: shape out of range", i);
+            const ky_shape& sh = in->shapes[l.shape];
+            std::memcpy(d.p, sh.p, sizeof d.p);
+            cp3(d.n, sh.normal);
+            d.shape_kind = sh.kind; d.radius = sh.radius; d.area = host_shape_area(sh);
+        }
+    }
+    return KY_OK;
+}
+
+struct DeviceCtx {
+    bool init = false;
+    int cus = 0;
+    DScene* d_scene = nullptr;
+    DScene* h_scene = nullptr;   // pinned staging
+    unsigned* d_counter = nullptr;
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int blocks_per_cu[2] = {0, 0};
+};
+static std::mutex g_mutex;
+static DeviceCtx g_ctx[16];
+
+static int get_ctx(int device, DeviceCtx** out) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(KY_ERR_NO_DEVICE, "no HIP device visible (libkyhip has no CPU fallback)");
+    if (device < 0 || device >= n || device >= 16) return fail(KY_ERR_INVALID_VALUE, "device %d out of range (%d visible)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    DeviceCtx& c = g_ctx[device];
+    if (!c.init) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(KY_ERR_NO_DEVICE, "device %d is %s; libkyhip is built for gfx950 only", device, prop.gcnArchName);
+        c.cus = prop.multiProcessorCount;
+        HIP_TRY(hipMalloc(&c.d_scene, sizeof(DScene)));
+        HIP_TRY(hipHostMalloc(&c.h_scene, sizeof(DScene)));
+        HIP_TRY(hipMalloc(&c.d_counter, 256));
+        HIP_TRY(hipEventCreate(&c.ev0));
+        HIP_TRY(hipEventCreate(&c.ev1));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[0], render_kernel<false>, 256, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[1], render_kernel<true>, 256, 0));
+        c.init = true;
+    }
+    *out = &c;
+    return KY_OK;
+}
+
+static int upload_scene(DeviceCtx* c, const ky_scene* scene, hipStream_t stream) {
+    // the pinned staging copy must not be overwritten while a previous async copy may still read it
+    HIP_TRY(hipStreamSynchronize(stream));
+    const int rc = pack_scene(scene, c->h_scene);
+    if (rc != KY_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_scene, c->h_scene, sizeof(DScene), hipMemcpyHostToDevice, stream));
+    return KY_OK;
+}
+
+static RenderConst make_rc(const ky_render_params* p) {
+    RenderConst rc{};
+    rc.integrator = p->integrator; rc.max_path_depth = p->max_path_depth; rc.strategy = p->direct_sample; rc.seed = p->seed;
+    rc.width = p->width; rc.height = p->height; rc.spp = p->samples_per_pixel;
+    rc.inv_spp = (float)(1. / p->samples_per_pixel);  // ky.cpp:3717
+    return rc;
+}
+
+static int target_items_for(const DeviceCtx* c) { return c->cus * 8 * 4 * 12; }  // ~12 items per resident wave slot
+
+// shared driver of the KAT entry points
+template <typename F>
+static int kat_run(int device, const void* in, size_t in_bytes, void* out, size_t out_bytes, F launch) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceCtx* c;
+    int rcode = get_ctx(device, &c);
+    if (rcode != KY_OK) return rcode;
+    void *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_in, std::max<size_t>(in_bytes, 16)));
+    HIP_TRY(hipMalloc(&d_out, std::max<size_t>(out_bytes, 16)));
+    HIP_TRY(hipMemcpy(d_in, in, in_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d_out, 0, out_bytes));
+    rcode = launch(c, (const float*)d_in, (float*)d_out);
+    if (rcode == KY_OK) {
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rcode = fail(KY_ERR_DEVICE, "KAT kernel failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rcode;
+}
+
+
+extern "C" {
+
+const char* kyhip_last_error(void) { return g_error.c_str(); }
+int kyhip_abi_version(void) { return KYHIP_ABI_VERSION; }
+int kyhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int64_t kyhip_shard_tile_count(const ky_render_params* p) {
+    if (!valid_params(p)) return fail(KY_ERR_INVALID_VALUE, "invalid render params");
+    return make_shard(p, 0).n_tiles;
+}
+int64_t kyhip_shard_float_count(const ky_render_params* p) {
+    if (!valid_params(p)) return fail(KY_ERR_INVALID_VALUE, "invalid render params");
+    return (int64_t)make_shard(p, 0).n_pix * 3;
+}
+
+// worst case: every sample its own chunk is never needed; bound chunks by the item target of a 256-CU part
+size_t kyhip_workspace_bytes(const ky_render_params* p) {
+    if (!valid_params(p)) return 0;
+    const ShardConst s = make_shard(p, 256 * 8 * 4 * 12);
+    return s.n_chunks > 1 ? (size_t)s.n_chunks * s.n_pix * 3 * sizeof(float) : 0;
+}
+
+int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render_params* p, float* d_tiles, void* d_workspace,
+                              size_t workspace_bytes, void* stream_) {
+    if (!valid_params(p)) return fail(KY_ERR_INVALID_VALUE, "invalid render params (integrator %d, direct_sample %d)", p ? p->integrator : -1, p ? p->direct_sample : -1);
+    if (!d_tiles) return fail(KY_ERR_INVALID_VALUE, "d_tiles is NULL");
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceCtx* c;
+    int rcode = get_ctx(device, &c);
+    if (rcode != KY_OK) return rcode;
+    hipStream_t stream = (hipStream_t)stream_;
+    rcode = upload_scene(c, scene, stream);
+    if (rcode != KY_OK) return rcode;
+
+    const ShardConst sh = make_shard(p, target_items_for(c));
+    if (sh.n_tiles == 0) return KY_OK;
+    const RenderConst rc = make_rc(p);
+    const bool dbg = p->sampler == KY_SAMPLER_DEBUG;
+
+    float* out = d_tiles;
+    if (sh.n_chunks > 1) {
+        const size_t need = (size_t)sh.n_chunks * sh.n_pix * 3 * sizeof(float);
+        if (d_workspace && workspace_bytes >= need) {
+            out = (float*)d_workspace;
+        } else {
+            if (c->ws_bytes < need) {
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (c->ws) HIP_TRY(hipFree(c->ws));
+                c->ws = nullptr; c->ws_bytes = 0;
+                HIP_TRY(hipMalloc(&c->ws, need));
+                c->ws_bytes = need;
+            }
+            out = (float*)c->ws;
+        }
+    }
+
+    HIP_TRY(hipMemsetAsync(c->d_counter, 0, sizeof(unsigned), stream));
+    const int per_cu = c->blocks_per_cu[dbg ? 1 : 0] > 0 ? c->blocks_per_cu[dbg ? 1 : 0] : 1;
+    unsigned grid = (unsigned)(c->cus * per_cu);
+    const unsigned need_blocks = (sh.n_items + 3) / 4;
+    if (grid > need_blocks) grid = need_blocks;
+    if (grid < 1) grid = 1;
+    HIP_TRY(hipEventRecord(c->ev0, stream));
+    if (dbg) hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, out);
+    else hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, stream));
+    if (sh.n_chunks > 1) {
+        const int nf = sh.n_pix * 3;
+        hipLaunchKernelGGL(reduce_kernel, dim3((nf + 255) / 256), dim3(256), 0, stream, out, d_tiles, nf, sh.n_chunks);
+        HIP_TRY(hipGetLastError());
+    }
+    return KY_OK;
+}
+
+// resolves the event pair of the last launch on `device`; the stream must have been synchronised
+float kyhip_kernel_ms(int device) {
+    if (device < 0 || device >= 16 || !g_ctx[device].init) return -1.f;
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, g_ctx[device].ev0, g_ctx[device].ev1) != hipSuccess) return -1.f;
+    return ms;
+}
+
+int kyhip_film_add_tiles_device(int device, const ky_render_params* p, const float* d_tiles, float* d_film, size_t stride_px, void* stream_) {
+    if (!valid_params(p)) return fail(KY_ERR_INVALID_VALUE, "invalid render params");
+    if (!d_tiles || !d_film || stride_px < (size_t)p->width) return fail(KY_ERR_INVALID_VALUE, "bad film arguments");
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceCtx* c;
+    int rcode = get_ctx(device, &c);
+    if (rcode != KY_OK) return rcode;
+    const ShardConst sh = make_shard(p, 0);
+    if (sh.n_pix == 0) return KY_OK;
+    hipLaunchKernelGGL(film_add_kernel, dim3((sh.n_pix + 255) / 256), dim3(256), 0, (hipStream_t)stream_, d_tiles, d_film, stride_px, sh, p->width, p->height);
+    HIP_TRY(hipGetLastError());
+    return KY_OK;
+}
+
+int kyhip_render(int device, const ky_scene* scene, const ky_render_params* p, float* film_rgb, size_t stride_px) {
+    if (!valid_params(p)) return fail(KY_ERR_INVALID_VALUE, "invalid render params (integrator %d, direct_sample %d)", p ? p->integrator : -1, p ? p->direct_sample : -1);
+    if (!film_rgb || stride_px < (size_t)p->width) return fail(KY_ERR_INVALID_VALUE, "bad film arguments");
+    const ShardConst sh = make_shard(p, 0);
+    float *d_tiles = nullptr, *d_film = nullptr;
+    const size_t film_floats = (size_t)p->width * p->height * 3;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        DeviceCtx* c;
+        int rcode = get_ctx(device, &c);
+        if (rcode != KY_OK) return rcode;
+        HIP_TRY(hipMalloc(&d_tiles, std::max<size_t>((size_t)sh.n_pix * 3 * sizeof(float), 16)));
+        HIP_TRY(hipMalloc(&d_film, film_floats * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(d_film, 0, film_floats * sizeof(float), 0));
+    }
+    int rcode = kyhip_render_tiles_device(device, scene, p, d_tiles, nullptr, 0, nullptr);
+    if (rcode == KY_OK) rcode = kyhip_film_add_tiles_device(device, p, d_tiles, d_film, (size_t)p->width, nullptr);
+    std::vector<float> host(film_floats);
+    if (rcode == KY_OK) {
+        hipError_t e = hipMemcpy(host.data(), d_film, film_floats * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rcode = fail(KY_ERR_DEVICE, "hipMemcpy failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_tiles);
+    (void)hipFree(d_film);
+    if (rcode != KY_OK) return rcode;
+    kyhip_kernel_ms(device);
+    for (int y = 0; y < p->height; ++y) {  // film_t::add_color, 1586-1590
+        float* dst = film_rgb + (size_t)y * stride_px * 3;
+        const float* src = host.data() + (size_t)y * p->width * 3;
+        for (int i = 0; i < p->width * 3; ++i) dst[i] += src[i];
+    }
+    return KY_OK;
+}
+
+// ---- KAT entry points ----
+int kyhip_kat_intersect(int device, const ky_shape* shape, const float* rays7, int n, float* out8) {
+    if (!shape || !rays7 || !out8 || n <= 0) return fail(KY_ERR_INVALID_VALUE, "bad KAT arguments");
+    KatShape ks{};
+    std::memcpy(ks.p, shape->p, sizeof ks.p);
+    cp3(ks.n, shape->normal);
+    ks.radius = shape->radius; ks.radius_sq = shape->radius * shape->radius; ks.kind = shape->kind;
+    return kat_run(device, rays7, (size_t)n * 7 * 4, out8, (size_t)n * 8 * 4, [&](DeviceCtx*, const float* d_in, float* d_out) {
+        hipLaunchKernelGGL(kat_intersect_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, ks, d_in, n, d_out);
+        return (int)KY_OK;
+    });
+}
+
+int kyhip_kat_camera(int device, const ky_camera* camera, const float* p_film2, int n, float* out6) {
+    if (!camera || !p_film2 || !out6 || n <= 0) return fail(KY_ERR_INVALID_VALUE, "bad KAT arguments");
+    ky_scene sc{};
+    sc.environment_light = -1;
+    sc.camera = *camera;
+    return kat_run(device, p_film2, (size_t)n * 2 * 4, out6, (size_t)n * 6 * 4, [&](DeviceCtx* c, const float* d_in, float* d_out) {
+        int r = upload_scene(c, &sc, 0);
+        if (r != KY_OK) return r;
+        hipLaunchKernelGGL(kat_camera_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, c->d_scene, d_in, n, d_out);
+        return (int)KY_OK;
+    });
+}
+
+int kyhip_kat_bsdf(int device, const ky_material* m, const float* in12, int n, float* out13) {
+    if (!m || !in12 || !out13 || n <= 0) return fail(KY_ERR_INVALID_VALUE, "bad KAT arguments");
+    DMat d{};
+    cp3(d.c0, m->color0); cp3(d.c1, m->color1);
+    d.kind = m->kind; d.eta = m->eta; d.exponent = m->exponent; d.p_diffuse = m->diffuse_probability; d.p_specular = m->specular_probability;
+    return kat_run(device, in12, (size_t)n * 12 * 4, out13, (size_t)n * 13 * 4, [&](DeviceCtx*, const float* d_in, float* d_out) {
+        hipLaunchKernelGGL(kat_bsdf_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d, d_in, n, d_out);
+        return (int)KY_OK;
+    });
+}
+
+int kyhip_kat_light(int device, const ky_scene* scene, int light, const float* in11, int n, float* out11) {
+    if (!scene || !in11 || !out11 || n <= 0 || light < 0 || light >= scene->light_count) return fail(KY_ERR_INVALID_VALUE, "bad KAT arguments");
+    return kat_run(device, in11, (size_t)n * 11 * 4, out11, (size_t)n * 11 * 4, [&](DeviceCtx* c, const float* d_in, float* d_out) {
+        int r = upload_scene(c, scene, 0);
+        if (r != KY_OK) return r;
+        hipLaunchKernelGGL(kat_light_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, c->d_scene, light, d_in, n, d_out);
+        return (int)KY_OK;
+    });
+}
+
+int kyhip_kat_scene_intersect(int device, const ky_scene* scene, const float* rays7, int n, float* out9) {
+    if (!scene || !rays7 || !out9 || n <= 0) return fail(KY_ERR_INVALID_VALUE, "bad KAT arguments");
+    return kat_run(device, rays7, (size_t)n * 7 * 4, out9, (size_t)n * 9 * 4, [&](DeviceCtx* c, const float* d_in, float* d_out) {
+        int r = upload_scene(c, scene, 0);
+        if (r != KY_OK) return r;
+        hipLaunchKernelGGL(kat_scene_intersect_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, c->d_scene, d_in, n, d_out);
+        return (int)KY_OK;
+    });
+}
+
+int kyhip_kat_occluded(int device, const ky_scene* scene, const float* in9, int n, float* out1) {
+    if (!scene || !in9 || !out1 || n <= 0) return fail(KY_ERR_INVALID_VALUE, "bad KAT arguments");
+    return kat_run(device, in9, (size_t)n * 9 * 4, out1, (size_t)n * 4, [&](DeviceCtx* c, const float* d_in, float* d_out) {
+        int r = upload_scene(c, scene, 0);
+        if (r != KY_OK) return r;
+        hipLaunchKernelGGL(kat_occluded_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, c->d_scene, d_in, n, d_out);
+        return (int)KY_OK;
+    });
+}
+
+int kyhip_kat_li(int device, const ky_scene* scene, const ky_render_params* p, int x, int y, int s0, int n, float* out3) {
+    if (!valid_params(p)) return fail(KY_ERR_INVALID_VALUE, "invalid render params");
+    if (!scene || !out3 || n <= 0 || x < 0 || y < 0 || x >= p->width || y >= p->height) return fail(KY_ERR_INVALID_VALUE, "bad KAT arguments");
+    const RenderConst rc = make_rc(p);
+    const bool dbg = p->sampler == KY_SAMPLER_DEBUG;
+    float dummy = 0.f;
+    return kat_run(device, &dummy, 4, out3, (size_t)n * 3 * 4, [&](DeviceCtx* c, const float*, float* d_out) {
+        int r = upload_scene(c, scene, 0);
+        if (r != KY_OK) return r;
+        if (dbg) hipLaunchKernelGGL(kat_li_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, 0, c->d_scene, rc, x, y, s0, n, d_out);
+        else hipLaunchKernelGGL(kat_li_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, 0, c->d_scene, rc, x, y, s0, n, d_out);
+        return (int)KY_OK;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+"""Multi-GPU rendering: image tiles sharded over the ranks of one node, one gather of film tiles at the end.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).  The path shards
+naturally: tile t of the film goes to rank t mod world (interleaved, for load balance),
+the scene is replicated (< 20 KB), there is NO communication while rendering, and the only collective is
+one gather of the clamped tile buffers to rank 0, which de-interleaves them and ADDS them into the film
+(film_t::add_color semantics, ky.cpp:1586).  Random numbers are keyed by global pixel / sample ids, so the
+image is bit-identical for every world size.
+
+torch is plumbing here: device buffers, streams and the collective.  Radiance is computed by libkyhip.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _abi as A
+from . import api
+
+
+def shard_params(params, rank, world):
+    """This rank's shard of `params`: tiles rank, rank+world, ... (a copy; the input is not modified)."""
+    p = A.RenderParams.from_buffer_copy(params)
+    p.tile_first = rank
+    p.tile_step = world
+    return p
+
+
+def tiles_total(params):
+    tx = (params.width + params.tile_w - 1) // params.tile_w
+    ty = (params.height + params.tile_h - 1) // params.tile_h
+    return tx * ty
+
+
+def shard_tile_count(params, rank, world):
+    total = tiles_total(params)
+    return 0 if rank >= total else (total - rank + world - 1) // world
+
+
+def render_shard(scene, params, rank, world, device_index=0):
+    """Render this rank's tiles on its GPU.  Returns a CUDA tensor [max_tiles_per_rank, tile_h, tile_w, 3]
+    (ranks that own one tile fewer leave the last slot zero) -- equal sizes keep the gather a single call."""
+    lib = A.load_kyhip()
+    p = shard_params(params, rank, world)
+    max_tiles = shard_tile_count(params, 0, world)
+    dev = torch.device("cuda", device_index)
+    tiles = torch.zeros((max_tiles, params.tile_h, params.tile_w, 3), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rc = lib.kyhip_render_tiles_device(device_index, api._scene_ptr(scene), C.byref(p), C.c_void_p(tiles.data_ptr()), None, 0,
+                                       C.c_void_p(stream))
+    api._check(rc, lib)
+    return tiles
+
+
+def gather_tiles(tiles, rank, world, group=None):
+    """The one collective of a frame: gather every rank's tile buffer to rank 0.  Returns [world, ...] on rank 0."""
+    if world == 1:
+        return tiles.unsqueeze(0)
+    import torch.distributed as dist
+    out = [torch.empty_like(tiles) for _ in range(world)] if rank == 0 else None
+    dist.gather(tiles, out, dst=0, group=group)
+    return torch.stack(out, 0) if rank == 0 else None
+
+
+def add_tiles_to_film(film, gathered, params, world, device_index=0):
+    """De-interleave gathered[r, k] (tile r + k*world) and ADD into film [H, W, 3] (rank 0 only).
+
+    CUDA tensors go through kyhip_film_add_tiles_device; CPU tensors (the gloo tests) use index arithmetic.
+    """
+    H, W = params.height, params.width
+    tw, th = params.tile_w, params.tile_h
+    tx = (W + tw - 1) // tw
+    total = tiles_total(params)
+    if film.is_cuda:
+        lib = A.load_kyhip()
+        stream = torch.cuda.current_stream(film.device).cuda_stream
+        for r in range(world):
+            p = shard_params(params, r, world)
+            rc = lib.kyhip_film_add_tiles_device(device_index, C.byref(p), C.c_void_p(gathered[r].data_ptr()),
+                                                 C.c_void_p(film.data_ptr()), film.shape[1], C.c_void_p(stream))
+            api._check(rc, lib)
+        return film
+    for r in range(world):
+        for k in range(shard_tile_count(params, r, world)):
+            t = r + k * world
+            assert t < total
+            x0, y0 = (t % tx) * tw, (t // tx) * th
+            w, h = min(tw, W - x0), min(th, H - y0)
+            film[y0:y0 + h, x0:x0 + w] += gathered[r, k, :h, :w]
+    return film
+
+
+def render_distributed(scene, params, rank, world, device_index=0, film=None, group=None):
+    """integrator_t::render over `world` GPUs.  Returns the film (a CUDA tensor) on rank 0, None elsewhere."""
+    tiles = render_shard(scene, params, rank, world, device_index)
+    gathered = gather_tiles(tiles, rank, world, group)
+    if rank != 0:
+        return None
+    if film is None:
+        film = torch.zeros((params.height, params.width, 3), dtype=torch.float32, device=tiles.device)
+    return add_tiles_to_film(film, gathered, params, world, device_index)

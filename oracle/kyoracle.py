@@ -1,0 +1,126 @@
+"""ctypes binding of oracle/libkyoracle.so (the CPU checker).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Nothing under ky_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from ky_amd import _abi as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+COUNTER_NAMES = ["camera_samples", "traversals", "shadow_rays", "primitive_tests", "nee_vertices", "light_estimates",
+                 "bsdf_path_samples", "path_iterations", "mis_bsdf_rays", "rr_draws", "shadow_occluded"]
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "libkyoracle.so"], stdout=subprocess.DEVNULL)
+
+
+def load():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "libkyoracle.so")
+        if not os.path.exists(path):
+            build()
+        _lib = C.CDLL(path)
+        _lib.kyo_render.restype = C.c_int
+        _lib.kyo_render.argtypes = [A.SP, A.PP, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        _lib.kyo_li.argtypes = [A.SP, A.PP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _lib.kyo_kat_intersect.argtypes = [C.POINTER(A.Shape), C.c_void_p, C.c_int, C.c_void_p]
+        _lib.kyo_kat_camera.argtypes = [C.POINTER(A.Camera), C.c_void_p, C.c_int, C.c_void_p]
+        _lib.kyo_kat_bsdf.argtypes = [C.POINTER(A.Material), C.c_void_p, C.c_int, C.c_void_p]
+        _lib.kyo_kat_light.argtypes = [A.SP, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        _lib.kyo_kat_scene_intersect.argtypes = [A.SP, C.c_void_p, C.c_int, C.c_void_p]
+        _lib.kyo_kat_occluded.argtypes = [A.SP, C.c_void_p, C.c_int, C.c_void_p]
+        _lib.kyo_world_bounding_sphere.argtypes = [A.SP, C.c_void_p]
+        _lib.kyo_max_threads.restype = C.c_int
+    return _lib
+
+
+def _sp(scene):
+    return scene.flat if hasattr(scene, "flat") else scene
+
+
+def _f(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def render(scene, params, film=None, threads=0, counters=False):
+    lib = load()
+    if film is None:
+        film = np.zeros((params.height, params.width, 3), np.float32)
+    cnt = np.zeros(len(COUNTER_NAMES), np.uint64) if counters else None
+    rc = lib.kyo_render(_sp(scene), C.byref(params), _f(film), film.shape[1], threads,
+                        cnt.ctypes.data_as(C.c_void_p) if counters else None)
+    if rc != 0:
+        raise ValueError(f"kyo_render returned {rc}")
+    if counters:
+        return film, dict(zip(COUNTER_NAMES, (int(v) for v in cnt)))
+    return film
+
+
+def li(scene, params, x, y, s0, n):
+    out = np.zeros((n, 3), np.float32)
+    rc = load().kyo_li(_sp(scene), C.byref(params), x, y, s0, n, _f(out))
+    if rc != 0:
+        raise ValueError(f"kyo_li returned {rc}")
+    return out
+
+
+def kat_intersect(shape, rays7):
+    rays7 = np.ascontiguousarray(rays7, np.float32)
+    out = np.zeros((rays7.shape[0], 8), np.float32)
+    load().kyo_kat_intersect(C.byref(shape), _f(rays7), rays7.shape[0], _f(out))
+    return out
+
+
+def kat_camera(camera, p_film2):
+    p_film2 = np.ascontiguousarray(p_film2, np.float32)
+    out = np.zeros((p_film2.shape[0], 6), np.float32)
+    load().kyo_kat_camera(C.byref(camera), _f(p_film2), p_film2.shape[0], _f(out))
+    return out
+
+
+def kat_bsdf(material, in12):
+    in12 = np.ascontiguousarray(in12, np.float32)
+    out = np.zeros((in12.shape[0], 13), np.float32)
+    load().kyo_kat_bsdf(C.byref(material), _f(in12), in12.shape[0], _f(out))
+    return out
+
+
+def kat_light(scene, light, in11):
+    in11 = np.ascontiguousarray(in11, np.float32)
+    out = np.zeros((in11.shape[0], 11), np.float32)
+    load().kyo_kat_light(_sp(scene), light, _f(in11), in11.shape[0], _f(out))
+    return out
+
+
+def kat_scene_intersect(scene, rays7):
+    rays7 = np.ascontiguousarray(rays7, np.float32)
+    out = np.zeros((rays7.shape[0], 9), np.float32)
+    load().kyo_kat_scene_intersect(_sp(scene), _f(rays7), rays7.shape[0], _f(out))
+    return out
+
+
+def kat_occluded(scene, in9):
+    in9 = np.ascontiguousarray(in9, np.float32)
+    out = np.zeros((in9.shape[0],), np.float32)
+    load().kyo_kat_occluded(_sp(scene), _f(in9), in9.shape[0], _f(out))
+    return out
+
+
+def world_bounding_sphere(scene):
+    out = np.zeros(4, np.float32)
+    load().kyo_world_bounding_sphere(_sp(scene), _f(out))
+    return out
+
+
+def max_threads():
+    return int(load().kyo_max_threads())

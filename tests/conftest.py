@@ -1,0 +1,48 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """The in-tree libraries are built by __graft_entry__.build(); build them if a fresh checkout lacks them."""
+    lib = os.path.join(ROOT, "ky_amd", "lib", "libkyhip.so")
+    host = os.path.join(ROOT, "ky_amd", "lib", "libkyhost.so")
+    orc = os.path.join(ROOT, "oracle", "libkyoracle.so")
+    if not (os.path.exists(lib) and os.path.exists(host) and os.path.exists(orc)):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
+@pytest.fixture(scope="session")
+def A():
+    from ky_amd import _abi
+    return _abi
+
+
+@pytest.fixture(scope="session")
+def api():
+    from ky_amd import api as _api
+    return _api
+
+
+@pytest.fixture(scope="session")
+def O():
+    from oracle import kyoracle
+    kyoracle.load()
+    return kyoracle
+
+
+@pytest.fixture(scope="session")
+def rng():
+    return np.random.default_rng(20251001)

@@ -5,7 +5,9 @@
 HIPCC    ?= hipcc
 CXX      ?= g++
 ROCM     ?= /opt/rocm
-HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
+# -no-hip-rt: libkyhip.so does NOT pin a HIP runtime.  A process must hold exactly one runtime: Python callers get the
+# one torch bundles (ky_amd/_abi.py loads it RTLD_GLOBAL first), C++ callers link $(ROCM)/lib/libamdhip64.so themselves.
+HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -no-hip-rt
 LIBDIR   := ky_amd/lib
 
 all: $(LIBDIR)/libkyhip.so $(LIBDIR)/libkyhost.so oracle examples
@@ -24,7 +26,7 @@ EXAMPLES := $(patsubst examples/%.cpp,examples/bin/%,$(wildcard examples/*.cpp))
 examples: $(EXAMPLES)
 examples/bin/%: examples/%.cpp ky_amd/host/ky.hpp include/kyhip.h $(LIBDIR)/libkyhip.so
 	@mkdir -p examples/bin
-	$(CXX) -O2 -std=c++17 -Wall -o $@ $< -L$(LIBDIR) -lkyhip -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)'
+	$(CXX) -O2 -std=c++17 -Wall -o $@ $< -L$(LIBDIR) -lkyhip -L$(ROCM)/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)' -Wl,-rpath,$(ROCM)/lib
 
 clean:
 	rm -rf $(LIBDIR) examples/bin

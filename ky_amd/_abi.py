@@ -114,6 +114,40 @@ def _bind(lib, table):
 
 _kyhip = None
 _kyhost = None
+_hiprt = None
+
+
+def load_hip_runtime():
+    """Put exactly ONE HIP runtime into the process's global symbol scope before libkyhip.so is loaded.
+
+    libkyhip.so is linked with -no-hip-rt.  The PyTorch wheel bundles its own libamdhip64.so (no SONAME), so a
+    library that pinned /opt/rocm/lib/libamdhip64.so.7 would bring a SECOND runtime into the process and torch's
+    streams / device pointers would be foreign to it.  When torch is installed its runtime is the one we share;
+    otherwise (or with KYHIP_HIP_RUNTIME set) the system runtime is used.
+    """
+    global _hiprt
+    if _hiprt is not None:
+        return _hiprt
+    candidates = []
+    if os.environ.get("KYHIP_HIP_RUNTIME"):
+        candidates.append(os.environ["KYHIP_HIP_RUNTIME"])
+    else:
+        try:
+            import torch  # noqa: F401  (loads torch/lib/libamdhip64.so into the process)
+            candidates.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        except Exception:
+            pass
+        candidates += ["/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"]
+    err = None
+    for path in candidates:
+        if os.path.isabs(path) and not os.path.exists(path):
+            continue
+        try:
+            _hiprt = C.CDLL(path, mode=C.RTLD_GLOBAL)
+            return _hiprt
+        except OSError as e:  # try the next candidate
+            err = e
+    raise ImportError(f"no HIP runtime (libamdhip64.so) could be loaded: {err}")
 
 
 def load_kyhip():
@@ -124,6 +158,7 @@ def load_kyhip():
         if not os.path.exists(path):
             raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(ky_amd has no CPU fallback)")
+        load_hip_runtime()
         _kyhip = _bind(C.CDLL(path, mode=C.RTLD_GLOBAL), KYHIP_SYMBOLS)
     return _kyhip
 

@@ -797,6 +797,8 @@ inline ray_t generate_ray(const ky_camera& cam, vec2_t p_film) {
 struct integrator_t {
     const scene_t* scene;
     int kind, max_path_depth, direct_sample;
+    // optional per-vertex trace (kyo_trace_li; the analogue of LOG_VAST, ky.cpp:4578): 24 floats per vertex
+    mutable std::vector<float>* trace = nullptr;
 
     // estimate_direct_lighting_by_bsdf, 3889-3930
     color_t by_bsdf(const isect_t& isect, int li, sampler_t& sampler, counters_t* c) const {
@@ -921,6 +923,12 @@ struct integrator_t {
             }
             if (c) c->bsdf_path_samples++;
             bsdf_sample_t bs = isect.bsdf.sample(isect.wo, sampler.get_float2());
+            if (trace) {
+                const float row[24] = {(float)bounces, (float)isect.surface, (float)isect.bsdf.lobe, isect.position.x, isect.position.y, isect.position.z,
+                                       isect.normal.x, isect.normal.y, isect.normal.z, isect.wo.x, isect.wo.y, isect.wo.z, beta.r, beta.g, beta.b,
+                                       Lo.r, Lo.g, Lo.b, bs.f.r, bs.f.g, bs.f.b, bs.pdf, abs_dot(bs.wi, isect.normal), (float)bs.bsdf_type};
+                trace->insert(trace->end(), row, row + 24);
+            }
             if (bs.f.is_black() || bs.pdf == 0.f) break;
             beta *= bs.f * abs_dot(bs.wi, isect.normal) / bs.pdf;
             is_prev_specular = bs.is_delta_bsdf();
@@ -1049,6 +1057,23 @@ int kyo_li(const ky_scene* cscene, const ky_render_params* p, int x, int y, int 
         out3[3 * i] = L.r; out3[3 * i + 1] = L.g; out3[3 * i + 2] = L.b;
     }
     return KY_OK;
+}
+
+// per-vertex trace of one camera sample (path integrator): rows of 24 floats
+// {bounce, surface, lobe, p[3], n[3], wo[3], beta[3], Lo[3], bs.f[3], bs.pdf, |cos|, flags}; returns the row count
+int kyo_trace_li(const ky_scene* cscene, const ky_render_params* p, int x, int y, int s, float* rows, int max_rows) {
+    scene_t scene(*cscene);
+    integrator_t integrator{&scene, p->integrator, p->max_path_depth, p->direct_sample};
+    std::vector<float> tr;
+    integrator.trace = &tr;
+    sampler_t sampler;
+    sampler.kind = p->sampler;
+    sampler.start_sample(p->seed, (uint32_t)(y * p->width + x), (uint32_t)s);
+    vec2_t cs = sampler.get_camera_sample({(float)x, (float)y});
+    integrator.Li(generate_ray(scene.camera, cs), sampler, nullptr);
+    int n = std::min<int>((int)tr.size() / 24, max_rows);
+    std::memcpy(rows, tr.data(), (size_t)n * 24 * sizeof(float));
+    return n;
 }
 
 int kyo_kat_intersect(const ky_shape* shape, const float* rays7, int n, float* out8) {

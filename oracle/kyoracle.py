@@ -74,6 +74,14 @@ def li(scene, params, x, y, s0, n):
     return out
 
 
+def trace_li(scene, params, x, y, s, max_rows=64):
+    rows = np.zeros((max_rows, 24), np.float32)
+    lib = load()
+    lib.kyo_trace_li.argtypes = [A.SP, A.PP, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    n = lib.kyo_trace_li(_sp(scene), C.byref(params), x, y, s, _f(rows), max_rows)
+    return rows[:n]
+
+
 def kat_intersect(shape, rays7):
     rays7 = np.ascontiguousarray(rays7, np.float32)
     out = np.zeros((rays7.shape[0], 8), np.float32)

@@ -154,7 +154,7 @@ def load_kyhip():
     """Load the product library.  Raises if it has not been built: no fallback."""
     global _kyhip
     if _kyhip is None:
-        path = os.path.join(LIB_DIR, "libkyhip.so")
+        path = os.environ.get("KYHIP_LIB") or os.path.join(LIB_DIR, "libkyhip.so")  # KYHIP_LIB: A/B builds of the same ABI
         if not os.path.exists(path):
             raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(ky_amd has no CPU fallback)")

@@ -2,10 +2,20 @@
  * ky_device.hpp -- gfx950 device code of the path-tracing hot path (one path vertex per call).
  *
  * Written for CDNA4: 64-lane wavefronts, one lane = one pixel.  The primitive list is read with
- * wave-uniform indices (scalar loads into SGPRs, no VGPR or LDS traffic for the traversal); the
+ * wave-uniform indices (scalar loads into SGPRs: no VGPR or LDS traffic for the traversal); the
  * tables that are looked up with a per-lane index AFTER the nearest hit is known (surface ->
  * normal / material / light, materials, light radiance) are staged in LDS once per workgroup.
  * No MFMA: there is no dense contraction on this path.
+ *
+ * Arithmetic is fp32 like the reference, but organised for the VALU rather than transcribed:
+ *   - planar parallelograms (every rectangle_t of the shipped scenes) are tested with a plane hit plus
+ *     two precomputed dual-basis dot products instead of the reference's four edge cross products;
+ *     quads that are not parallelograms, triangles and disks keep the reference's formulation;
+ *   - 1/x, 1/sqrt(x), sqrt(x), sin/cos(2 pi x), exp2 and log2 use the hardware instructions
+ *     (v_rcp/v_rsq/v_sqrt/v_sin/v_cos/v_exp/v_log, about 1 ulp);
+ *   - vectors that are unit by construction are not normalised again.
+ * These change results at the 1e-6 relative level; parity with the CPU oracle is by tolerance
+ * (tests/test_parity_gpu.py), never bit-exact.
  *
  * Every function names the reference function it implements (file = /root/reference/ky.cpp).
  * This file is independent of oracle/ (the CPU checker): nothing is shared between the two.
@@ -21,6 +31,18 @@
 namespace kyd {
 
 // ---------------------------------------------------------------------------------------------
+// scalar helpers: single hardware instructions
+// ---------------------------------------------------------------------------------------------
+KY_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+KY_DEV float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+KY_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+KY_DEV float sin_rev(float x) { return __builtin_amdgcn_sinf(x); }  // sin(2 pi x)
+KY_DEV float cos_rev(float x) { return __builtin_amdgcn_cosf(x); }  // cos(2 pi x)
+KY_DEV float clamp01f(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 1.f); }
+// x^n for x >= 0 (pow(0, n > 0) = 0, pow(x, 0) = 1)
+KY_DEV float pow_nonneg(float x, float n) { return n == 0.f ? 1.f : __builtin_amdgcn_exp2f(n * __builtin_amdgcn_logf(x)); }
+
+// ---------------------------------------------------------------------------------------------
 // vectors (ky.cpp:226-388)
 // ---------------------------------------------------------------------------------------------
 struct f3 {
@@ -33,18 +55,14 @@ KY_DEV f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }
 KY_DEV f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 KY_DEV f3 operator*(float s, f3 a) { return {a.x * s, a.y * s, a.z * s}; }
 KY_DEV f3 operator*(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
-KY_DEV f3 operator/(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
 KY_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 KY_DEV f3 cross(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 KY_DEV float length_sq(f3 a) { return dot(a, a); }
-KY_DEV f3 normalize(f3 a) { return a * (1.0f / sqrtf(dot(a, a))); }  // vec3_t::normalize, 314
+KY_DEV f3 normalize(f3 a) { return a * rsq(dot(a, a)); }  // vec3_t::normalize, 314
 KY_DEV float max3(f3 a) { return fmaxf(a.x, fmaxf(a.y, a.z)); }
 KY_DEV bool is_black(f3 c) { return (c.x <= 0) && (c.y <= 0) && (c.z <= 0); }  // color_t::is_black, 258
 
 constexpr float K_PI = 3.14159265358979323846f;
-constexpr float K_2PI = 2.f * K_PI;
-constexpr float K_PI_OVER2 = K_PI / 2.f;
-constexpr float K_PI_OVER4 = K_PI / 4.f;
 constexpr float K_INV_PI = 0.318309886183790671538f;
 constexpr float K_INV_2PI = K_INV_PI / 2.f;
 constexpr float K_SHAPE_EPS = 1e-3f;   // shape_t::epsilon, 1093
@@ -52,14 +70,35 @@ constexpr float K_RAY_OFFSET = 1e-2f;  // offset_ray_origin, 616
 constexpr float K_INF = __builtin_huge_valf();
 
 // ---------------------------------------------------------------------------------------------
-// device scene layout (HBM, read-only; 16-byte aligned records)
+// device scene layout (HBM, read-only)
 // ---------------------------------------------------------------------------------------------
-struct DSurf {  // traversal record: the shape of one surface_t, read with a wave-uniform index
+enum : int {  // traversal kinds
+    TK_DISK = KY_SHAPE_DISK,
+    TK_TRIANGLE = KY_SHAPE_TRIANGLE,
+    TK_QUAD = KY_SHAPE_RECTANGLE,  // general (non-parallelogram / non-planar) quad: the reference's edge tests
+    TK_SPHERE = KY_SHAPE_SPHERE,
+    TK_PARALLELOGRAM = 4           // planar parallelogram: plane hit + dual-basis coordinates
+};
+
+// 64-byte traversal record, read with a wave-uniform index (scalar loads):
+//   TK_PARALLELOGRAM  f[0..2] = n, f[3] = n.p0, f[4..6] = a*, f[7] = a*.p1 + 0.5, f[8..10] = b*, f[11] = b*.p1 + 0.5
+//                     where a = p0 - p1, b = p2 - p1 and (a*, b*) is the dual basis in the plane, so that for a point
+//                     h of the plane  h.a* - f[7] = u - 0.5,  h.b* - f[11] = v - 0.5  with h = p1 + u a + v b
+//   TK_SPHERE         f[0..2] = centre, f[3] = radius^2
+//   other kinds       full = index of the DShapeFull record
+struct DSurf {
+    float f[12];
+    int32_t kind;
+    int32_t full;
+    int32_t pad[2];
+};
+
+struct DShapeFull {  // the reference's own shape data (ky_shape)
     float p[4][3];
     float n[3];
+    float radius;
     float radius_sq;
     int32_t kind;
-    float radius;
     int32_t pad[2];
 };  // 80 B
 
@@ -76,7 +115,8 @@ struct DMat {  // ky_material, gathered per lane from LDS
     int32_t kind;
     float c1[3];
     float eta;
-    float exponent, p_diffuse, p_specular, pad;
+    float exponent, p_diffuse, p_specular;
+    int32_t exp_flags;  // bit 0: exponent is integral, bit 1: it is odd (sign of pow(negative, n))
 };  // 48 B
 
 struct DLight {  // light_t + the shape an area light samples; wave-uniform index
@@ -85,20 +125,26 @@ struct DLight {  // light_t + the shape an area light samples; wave-uniform inde
     float position[3];
     float world_radius;
     float direction[3];
-    int32_t shape_kind;
-    float p[4][3];  // sampled shape
-    float n[3];
+    int32_t shape_kind;   // ky_shape_kind of the sampled shape
+    float p1[3];          // rectangle: p1, e0 = p0 - p1, e1 = p2 - p1 (1310); triangle: p0, p1, p2; sphere / disk: centre
     float radius;
-    float area, pad[3];
-};  // 128 B
+    float e0[3];
+    float area;
+    float e1[3];
+    float inv_area;
+    float n[3];           // stored normal
+    float pad;
+    DSurf isect;          // traversal record of the sampled shape (pdf_direction re-intersects it, 1057-1061)
+};
 
 struct DScene {
     int32_t n_surfaces, n_lights, n_materials, env_light;
-    float cam_position[3], cam_w;
-    float cam_front[3], cam_h;
+    float cam_position[3], cam_inv_w;
+    float cam_front[3], cam_inv_h;
     float cam_right[3], pad0;
     float cam_up[3], pad1;
     DSurf surf[KYHIP_MAX_SURFACES];
+    DShapeFull full[KYHIP_MAX_SURFACES + KYHIP_MAX_LIGHTS];
     DHit hit[KYHIP_MAX_SURFACES];
     DMat mat[KYHIP_MAX_MATERIALS];
     DLight light[KYHIP_MAX_LIGHTS];
@@ -162,70 +208,79 @@ KY_DEV float sampler_at(const Sampler& s, uint32_t d) {
 // camera_t::generate_ray, ky.cpp:1884-1892
 // ---------------------------------------------------------------------------------------------
 KY_DEV void generate_ray(const DScene* __restrict__ S, float px, float py, f3& o, f3& d) {
-    const float sx = px / S->cam_w - 0.5f;
-    const float sy = 0.5f - py / S->cam_h;
-    f3 dir = ld3(S->cam_front) + ld3(S->cam_right) * sx + ld3(S->cam_up) * sy;
+    const float sx = px * S->cam_inv_w - 0.5f;
+    const float sy = 0.5f - py * S->cam_inv_h;
+    const f3 dir = ld3(S->cam_front) + ld3(S->cam_right) * sx + ld3(S->cam_up) * sy;
     o = ld3(S->cam_position);
     d = normalize(dir);
 }
 
 // offset_ray_origin, ky.cpp:614-620
 KY_DEV f3 offset_ray_origin(f3 position, f3 normal, f3 direction) {
-    f3 offset = normal * K_RAY_OFFSET;
-    if (dot(normal, direction) < 0) offset = -offset;
-    return position + offset;
+    const float s = dot(normal, direction) < 0 ? -K_RAY_OFFSET : K_RAY_OFFSET;
+    return position + normal * s;
 }
 
 // ---------------------------------------------------------------------------------------------
-// shape_t::intersect x4 -- distance only.  Returns true and sets t when eps < t < tmax.
+// shape_t::intersect -- distance only.  Returns true and sets t when eps < t < tmax.
 // ---------------------------------------------------------------------------------------------
 KY_DEV bool is_equal_zero(float x) {  // is_equal(x, 0.f), ky.cpp:212-220
     const float eps = 1.1920929e-07f;
     return fabsf(x) <= eps * fmaxf(1.f, fabsf(x));
 }
 
-template <typename SHAPE>  // SHAPE has p[4][3], n[3], radius, radius_sq, kind
-KY_DEV bool shape_hit(const SHAPE& S, int kind, f3 o, f3 d, float tmax, float& t_out) {
-    if (kind == KY_SHAPE_RECTANGLE) {  // rectangle_t::intersect, 1261-1297
+// the reference's formulations, used for general quads, triangles and disks
+KY_DEV bool full_shape_hit(const DShapeFull& S, f3 o, f3 d, float tmax, float& t_out) {
+    if (S.kind == KY_SHAPE_RECTANGLE) {  // rectangle_t::intersect, 1261-1297
         const f3 oa = ld3(S.p[0]) - o, ob = ld3(S.p[1]) - o, oc = ld3(S.p[2]) - o, od = ld3(S.p[3]) - o;
         const float v0d = dot(cross(oc, ob), d), v1d = dot(cross(ob, oa), d), v2d = dot(cross(oa, od), d), v3d = dot(cross(od, oc), d);
         const bool neg = (v0d < 0.f) && (v1d < 0.f) && (v2d < 0.f) && (v3d < 0.f);
         const bool pos = (v0d >= 0.f) && (v1d >= 0.f) && (v2d >= 0.f) && (v3d >= 0.f);
         const f3 n = ld3(S.n);
-        const float t = dot(n, oa) / dot(n, d);
+        const float t = dot(n, oa) * rcp(dot(n, d));
         t_out = t;
         return (neg || pos) && (t > K_SHAPE_EPS) && (t < tmax);
-    } else if (kind == KY_SHAPE_SPHERE) {  // sphere_t::intersect, 1336-1393
-        const f3 oc = ld3(S.p[0]) - o;
-        const float neg_b = dot(oc, d);
-        const float discr = neg_b * neg_b - dot(oc, oc) + S.radius_sq;
-        bool hit = false;
-        float t = 0.f;
-        if (discr >= 0) {
-            const float sq = sqrtf(discr);
-            const float t0 = neg_b - sq, t1 = neg_b + sq;
-            if (t0 > K_SHAPE_EPS && t0 < tmax) { hit = true; t = t0; }
-            else if (t1 > K_SHAPE_EPS && t1 < tmax) { hit = true; t = t1; }
-        }
-        t_out = t;
-        return hit;
-    } else if (kind == KY_SHAPE_TRIANGLE) {  // triangle_t::intersect, 1179-1215
+    } else if (S.kind == KY_SHAPE_TRIANGLE) {  // triangle_t::intersect, 1179-1215
         const f3 oa = ld3(S.p[0]) - o, ob = ld3(S.p[1]) - o, oc = ld3(S.p[2]) - o;
         const float v0d = dot(cross(oc, ob), d), v1d = dot(cross(ob, oa), d), v2d = dot(cross(oa, oc), d);
         const bool neg = (v0d < 0.f) && (v1d < 0.f) && (v2d < 0.f);
         const bool pos = (v0d >= 0.f) && (v1d >= 0.f) && (v2d >= 0.f);
         const f3 n = ld3(S.n);
-        const float t = dot(n, oa) / dot(n, d);
+        const float t = dot(n, oa) * rcp(dot(n, d));
         t_out = t;
         return (neg || pos) && (t > K_SHAPE_EPS) && (t < tmax);
     } else {  // disk_t::intersect, 1111-1132
         const f3 n = ld3(S.n), c = ld3(S.p[0]);
         const float nd = dot(d, n);
-        const float t = dot(n, c - o) / dot(n, d);
-        const f3 hp = o + t * d;
-        const f3 r = c - hp;
+        const float t = dot(n, c - o) * rcp(nd);
+        const f3 r = c - (o + t * d);
         t_out = t;
-        return !is_equal_zero(nd) && (t > K_SHAPE_EPS) && (t < tmax) && (sqrtf(dot(r, r)) <= S.radius);
+        return !is_equal_zero(nd) && (t > K_SHAPE_EPS) && (t < tmax) && (fsqrt(dot(r, r)) <= S.radius);
+    }
+}
+
+KY_DEV bool surf_hit(const DSurf& S, const DShapeFull* __restrict__ full, f3 o, f3 d, float tmax, float& t_out) {
+    if (S.kind == TK_PARALLELOGRAM) {  // rectangle_t::intersect (1261-1297) for a planar parallelogram
+        const float num = S.f[3] - (S.f[0] * o.x + S.f[1] * o.y + S.f[2] * o.z);   // n.(p0 - o)
+        const float den = S.f[0] * d.x + S.f[1] * d.y + S.f[2] * d.z;
+        const float t = num * rcp(den);
+        const f3 h = o + t * d;
+        const float u = (h.x * S.f[4] + h.y * S.f[5] + h.z * S.f[6]) - S.f[7];     // u - 0.5
+        const float v = (h.x * S.f[8] + h.y * S.f[9] + h.z * S.f[10]) - S.f[11];   // v - 0.5
+        t_out = t;
+        return (fabsf(u) <= 0.5f) && (fabsf(v) <= 0.5f) && (t > K_SHAPE_EPS) && (t < tmax);   // NaN (den = 0) compares false
+    } else if (S.kind == TK_SPHERE) {  // sphere_t::intersect, 1336-1393
+        const f3 oc = mk3(S.f[0], S.f[1], S.f[2]) - o;
+        const float neg_b = dot(oc, d);
+        const float discr = neg_b * neg_b - dot(oc, oc) + S.f[3];
+        const float sq = fsqrt(discr);  // NaN for discr < 0: both comparisons below are then false
+        const float t0 = neg_b - sq, t1 = neg_b + sq;
+        const bool h0 = t0 > K_SHAPE_EPS && t0 < tmax;
+        const bool h1 = t1 > K_SHAPE_EPS && t1 < tmax;
+        t_out = h0 ? t0 : t1;
+        return h0 || h1;
+    } else {
+        return full_shape_hit(full[S.full], o, d, tmax, t_out);
     }
 }
 
@@ -235,7 +290,7 @@ KY_DEV int trace_nearest(const DScene* __restrict__ S, f3 o, f3 d, float& tmax) 
     const int n = S->n_surfaces;
     for (int i = 0; i < n; ++i) {
         float t;
-        if (shape_hit(S->surf[i], S->surf[i].kind, o, d, tmax, t)) {
+        if (surf_hit(S->surf[i], S->full, o, d, tmax, t)) {
             tmax = t;
             best = i;
         }
@@ -249,7 +304,7 @@ KY_DEV bool trace_any(const DScene* __restrict__ S, f3 o, f3 d, float tmax) {
     const int n = S->n_surfaces;
     for (int i = 0; i < n; ++i) {
         float t;
-        occ = occ || shape_hit(S->surf[i], S->surf[i].kind, o, d, tmax, t);
+        occ = occ || surf_hit(S->surf[i], S->full, o, d, tmax, t);
         if (__all(occ)) break;
     }
     return occ;
@@ -264,17 +319,23 @@ KY_DEV f3 hit_normal(const DHit& H, f3 position, f3 d) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// frame_t (ky.cpp:526-578)
+// frame_t (ky.cpp:526-578).  `normal` is unit by construction, so frame_t's own normalize (538) is skipped;
+// cross(n, X) = (0, n.z, -n.y) and cross(n, Y) = (-n.z, 0, n.x) are written out.
 // ---------------------------------------------------------------------------------------------
 struct Frame {
     f3 s, t, n;
 };
-KY_DEV Frame make_frame(f3 normal) {  // frame_t(normal_t), 537-541, 566-571
+KY_DEV Frame make_frame(f3 n) {
     Frame f;
-    f.n = normalize(normal);
-    const f3 a = (fabsf(f.n.x) > 0.99f) ? mk3(0, 1, 0) : mk3(1, 0, 0);
-    f.t = normalize(cross(f.n, a));
-    f.s = normalize(cross(f.t, f.n));
+    f.n = n;
+    if (fabsf(n.x) > 0.99f) {
+        const float k = rsq(n.z * n.z + n.x * n.x);
+        f.t = mk3(-n.z * k, 0.f, n.x * k);
+    } else {
+        const float k = rsq(n.z * n.z + n.y * n.y);
+        f.t = mk3(0.f, n.z * k, -n.y * k);
+    }
+    f.s = cross(f.t, n);  // unit: t is unit and perpendicular to n
     return f;
 }
 KY_DEV f3 to_local(const Frame& f, f3 w) { return {dot(f.s, w), dot(f.t, w), dot(f.n, w)}; }
@@ -288,9 +349,11 @@ enum : int { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_
 
 struct Bsdf {
     int lobe;
-    f3 a, b;       // lambert albedo | mirror R | glass R, T | phong Ks
+    f3 a;          // lambert albedo | mirror R | glass R | phong Ks
+    f3 b;          // glass T
     float eta_t;   // glass (eta_i = 1, 2630)
     float exponent;
+    int exp_flags;
 };
 KY_DEV bool bsdf_is_delta(const Bsdf& B) { return B.lobe == LOBE_MIRROR || B.lobe == LOBE_GLASS; }
 
@@ -301,12 +364,13 @@ KY_DEV Bsdf make_bsdf(const DMat& M, float lobe_random) {
     B.b = ld3(M.c1);
     B.eta_t = M.eta;
     B.exponent = M.exponent;
+    B.exp_flags = M.exp_flags;
     B.lobe = LOBE_LAMBERT;
     if (M.kind == KY_MATERIAL_MIRROR) B.lobe = LOBE_MIRROR;
     else if (M.kind == KY_MATERIAL_GLASS) B.lobe = LOBE_GLASS;
     else if (M.kind == KY_MATERIAL_PLASTIC) {
-        if (lobe_random < M.p_specular) { B.lobe = LOBE_PHONG; B.a = ld3(M.c1) / M.p_specular; }
-        else { B.a = ld3(M.c0) / M.p_diffuse; }
+        if (lobe_random < M.p_specular) { B.lobe = LOBE_PHONG; B.a = ld3(M.c1) * rcp(M.p_specular); }
+        else { B.a = ld3(M.c0) * rcp(M.p_diffuse); }
     }
     return B;
 }
@@ -318,17 +382,22 @@ KY_DEV float fresnel_dielectric(float cos_theta_i, float eta_i, float eta_t) {
         const float tmp = eta_i; eta_i = eta_t; eta_t = tmp;
         cos_theta_i = fabsf(cos_theta_i);
     }
-    const float sin_theta_i = sqrtf(fmaxf(0.f, 1 - cos_theta_i * cos_theta_i));
-    const float sin_theta_t = eta_i / eta_t * sin_theta_i;
+    const float sin_theta_i = fsqrt(fmaxf(0.f, 1 - cos_theta_i * cos_theta_i));
+    const float sin_theta_t = eta_i * rcp(eta_t) * sin_theta_i;
     if (sin_theta_t >= 1) return 1;
-    const float cos_theta_t = sqrtf(fmaxf(0.f, 1 - sin_theta_t * sin_theta_t));
-    const float r_para = ((eta_t * cos_theta_i) - (eta_i * cos_theta_t)) / ((eta_t * cos_theta_i) + (eta_i * cos_theta_t));
-    const float r_perp = ((eta_i * cos_theta_i) - (eta_t * cos_theta_t)) / ((eta_i * cos_theta_i) + (eta_t * cos_theta_t));
-    return (r_para * r_para + r_perp * r_perp) / 2;
+    const float cos_theta_t = fsqrt(fmaxf(0.f, 1 - sin_theta_t * sin_theta_t));
+    const float r_para = ((eta_t * cos_theta_i) - (eta_i * cos_theta_t)) * rcp((eta_t * cos_theta_i) + (eta_i * cos_theta_t));
+    const float r_perp = ((eta_i * cos_theta_i) - (eta_t * cos_theta_t)) * rcp((eta_i * cos_theta_i) + (eta_t * cos_theta_t));
+    return (r_para * r_para + r_perp * r_perp) * 0.5f;
 }
 
-// phong helpers: wr = reflect(wo, (0,0,1)) = (-wo.x, -wo.y, wo.z), 2495 / 2504 / 2517
-KY_DEV float phong_pow(float base, float exponent) { return powf(base, exponent); }
+// std::pow(base, exponent) of the Phong lobe (2499): a negative base is legal for an integral exponent
+KY_DEV float phong_pow(float base, float exponent, int exp_flags) {
+    const float m = pow_nonneg(fabsf(base), exponent);
+    if (base >= 0.f) return m;
+    if (!(exp_flags & 1)) return __builtin_nanf("");   // pow(negative, non-integer)
+    return (exp_flags & 2) ? -m : m;
+}
 
 // bsdf eval_ and pdf_ at one (wo, wi) pair
 KY_DEV void bsdf_eval_pdf(const Bsdf& B, f3 wo, f3 wi, f3& f, float& pdf) {
@@ -337,15 +406,14 @@ KY_DEV void bsdf_eval_pdf(const Bsdf& B, f3 wo, f3 wi, f3& f, float& pdf) {
     const bool same = wo.z * wi.z > 0;  // same_hemisphere, 1921
     if (B.lobe == LOBE_LAMBERT) {       // 2227-2240
         if (same) { f = B.a * K_INV_PI; pdf = fabsf(wi.z) * K_INV_PI; }
-    } else if (B.lobe == LOBE_PHONG) {  // 2489-2508, 2545-2550
-        const float cos_alpha = -wo.x * wi.x - wo.y * wi.y + wo.z * wi.z;
+    } else if (B.lobe == LOBE_PHONG) {  // 2489-2508, 2545-2550; wr = reflect(wo, z) = (-wo.x, -wo.y, wo.z)
+        const float cos_alpha = wo.z * wi.z - wo.x * wi.x - wo.y * wi.y;
         // eval: cos_alpha is not clamped (a negative base with an even integral exponent is positive);
-        // pdf: clamped at 0, no hemisphere test.
-        const float pe = phong_pow(cos_alpha, B.exponent);
-        // pow(max(0, cos_alpha), n): equals pe for a positive base, pow(0, n) otherwise
+        // pdf: clamped at 0, no hemisphere test (quirk 6)
+        const float pe = phong_pow(cos_alpha, B.exponent, B.exp_flags);
         const float p0 = B.exponent == 0.f ? 1.f : (B.exponent > 0.f ? 0.f : K_INF);
         const float pp = cos_alpha > 0.f ? pe : p0;
-        if (same) f = (B.a * (B.exponent + 2.f) * K_INV_2PI) * pe;
+        if (same) f = (B.a * ((B.exponent + 2.f) * K_INV_2PI)) * pe;
         pdf = (B.exponent + 1.f) * pp * K_INV_2PI;
     }
     // mirror / glass: eval 0, pdf 0 (2289-2290, 2352-2353)
@@ -357,6 +425,18 @@ struct BsdfSample {
     int flags;
 };
 
+// concentric_disk_sample, 710-733 (angles in revolutions: theta / 2 pi)
+KY_DEV void concentric_disk(float u0, float u1, float& px, float& py) {
+    const float rx = 2.f * u0 - 1, ry = 2.f * u1 - 1;
+    const bool xmajor = fabsf(rx) > fabsf(ry);
+    const float radius = xmajor ? rx : ry;
+    const float ratio = (xmajor ? ry : rx) * rcp(radius);             // 0/0 = NaN only when rx = ry = 0, handled below
+    const float rev = xmajor ? 0.125f * ratio : 0.25f - 0.125f * ratio;  // (pi/4) q, pi/2 - (pi/4) q
+    const bool origin = (rx == 0 && ry == 0);
+    px = origin ? 0.f : cos_rev(rev) * radius;
+    py = origin ? 0.f : sin_rev(rev) * radius;
+}
+
 // bsdf sample_ x4
 KY_DEV BsdfSample bsdf_sample_local(const Bsdf& B, f3 wo, float u0, float u1) {
     BsdfSample s;
@@ -364,26 +444,17 @@ KY_DEV BsdfSample bsdf_sample_local(const Bsdf& B, f3 wo, float u0, float u1) {
     s.wi = mk3(0, 0, 0);
     s.pdf = 0.f;
     s.flags = 0;
-    if (B.lobe == LOBE_LAMBERT) {  // 2242-2257 + cosine_hemisphere_sample 737-743 + concentric_disk_sample 710-733
-        const float rx = 2.f * u0 - 1, ry = 2.f * u1 - 1;
-        float px = 0.f, py = 0.f;
-        if (!(rx == 0 && ry == 0)) {
-            float radius, theta;
-            if (fabsf(rx) > fabsf(ry)) { radius = rx; theta = K_PI_OVER4 * (ry / rx); }
-            else { radius = ry; theta = K_PI_OVER2 - K_PI_OVER4 * (rx / ry); }
-            float sn, cs;
-            sincosf(theta, &sn, &cs);
-            px = cs * radius;
-            py = sn * radius;
-        }
-        float z = sqrtf(fmaxf(0.f, 1 - px * px - py * py));
-        if (wo.z < 0) z *= -1;
+    if (B.lobe == LOBE_LAMBERT) {  // 2242-2257 + cosine_hemisphere_sample 737-743
+        float px, py;
+        concentric_disk(u0, u1, px, py);
+        float z = fsqrt(fmaxf(0.f, 1 - px * px - py * py));
+        if (wo.z < 0) z = -z;
         s.wi = mk3(px, py, z);
         bsdf_eval_pdf(B, wo, s.wi, s.f, s.pdf);
         s.flags = BSDF_REFLECTION | BSDF_DIFFUSE;
     } else if (B.lobe == LOBE_MIRROR) {  // 2292-2307
         s.wi = mk3(-wo.x, -wo.y, wo.z);
-        s.f = B.a / fabsf(s.wi.z);
+        s.f = B.a * rcp(fabsf(s.wi.z));
         s.pdf = 1;
         s.flags = BSDF_REFLECTION | BSDF_SPECULAR;
     } else if (B.lobe == LOBE_GLASS) {  // 2355-2412
@@ -392,36 +463,33 @@ KY_DEV BsdfSample bsdf_sample_local(const Bsdf& B, f3 wo, float u0, float u1) {
         if (u0 < reflect_percent) {
             s.wi = mk3(-wo.x, -wo.y, wo.z);
             s.pdf = reflect_percent;
-            s.f = (B.a * reflect_percent) / fabsf(s.wi.z);
+            s.f = (B.a * reflect_percent) * rcp(fabsf(s.wi.z));
             s.flags = BSDF_REFLECTION | BSDF_SPECULAR;
         } else {
             const bool into = wo.z > 0;
             const float nz = into ? 1.f : -1.f;
-            const float eta = into ? 1.f / B.eta_t : B.eta_t / 1.f;
+            const float eta = into ? rcp(B.eta_t) : B.eta_t;
             // refract(wo, (0,0,nz), eta), 1931-1957
             const float cos_theta_i = nz * wo.z;
             const float sin_theta_i_sq = fmaxf(0.f, 1 - cos_theta_i * cos_theta_i);
             const float sin_theta_t_sq = eta * eta * sin_theta_i_sq;
             if (!(sin_theta_t_sq >= 1)) {
-                const float cos_theta_t = sqrtf(1 - sin_theta_t_sq);
+                const float cos_theta_t = fsqrt(1 - sin_theta_t_sq);
                 const float k = eta * cos_theta_i - cos_theta_t;
                 s.wi = mk3(eta * -wo.x, eta * -wo.y, eta * -wo.z + k * nz);
                 s.pdf = refract_percent;
-                s.f = (B.b * refract_percent) / fabsf(s.wi.z);
+                s.f = (B.b * refract_percent) * rcp(fabsf(s.wi.z));
                 s.flags = BSDF_TRANSMISSION | BSDF_SPECULAR;
             }
             // else total internal reflection: f = 0, pdf = 0 (2407)
         }
     } else {  // phong, 2510-2529 + 2533-2543
-        const float phi = 2.f * K_PI * u0;
-        const float ct = powf(u1, 1.f / (B.exponent + 1.f));
-        const float st = sqrtf(1.f - ct * ct);
-        float sn, cs;
-        sincosf(phi, &sn, &cs);
-        const f3 local = mk3(cs * st, sn * st, ct);
-        const Frame fr = make_frame(mk3(-wo.x, -wo.y, wo.z));
+        const float ct = pow_nonneg(u1, rcp(B.exponent + 1.f));
+        const float st = fsqrt(1.f - ct * ct);
+        const f3 local = mk3(cos_rev(u0) * st, sin_rev(u0) * st, ct);   // phi = 2 pi u0
+        const Frame fr = make_frame(mk3(-wo.x, -wo.y, wo.z));           // frame_t(wr): wr is unit because wo is
         f3 wi = to_world(fr, local);
-        if (wo.z < 0) wi.z *= -1;
+        if (wo.z < 0) wi.z = -wi.z;
         s.wi = wi;
         bsdf_eval_pdf(B, wo, wi, s.f, s.pdf);
         s.flags = BSDF_REFLECTION | BSDF_GLOSSY;
@@ -447,120 +515,104 @@ struct LightSample {
     float pdf;
 };
 
-KY_DEV float light_shape_area(const DLight& L) { return L.area; }
-
 KY_DEV f3 uniform_sphere_sample(float u0, float u1) {  // 761-769
     const float z = 1 - 2 * u0;
-    const float radius = sqrtf(fmaxf(0.f, 1.f - z * z));
-    const float phi = 2 * K_PI * u1;
-    float sn, cs;
-    sincosf(phi, &sn, &cs);
-    return mk3(radius * cs, radius * sn, z);
+    const float radius = fsqrt(fmaxf(0.f, 1.f - z * z));
+    return mk3(radius * cos_rev(u1), radius * sin_rev(u1), z);
 }
 
-// shape_t::sample_position x4 (1144, 1225, 1307, 1404)
+// shape_t::sample_position x4 (1144, 1225, 1307, 1404); normals are the stored (unit) ones
 KY_DEV void shape_sample_position(const DLight& L, float u0, float u1, f3& position, f3& normal) {
     if (L.shape_kind == KY_SHAPE_RECTANGLE) {
-        const f3 p0 = ld3(L.p[0]), p1 = ld3(L.p[1]), p2 = ld3(L.p[2]);
-        position = p1 + (p0 - p1) * u0 + (p2 - p1) * u1;
-        normal = normalize(ld3(L.n));
+        position = ld3(L.p1) + ld3(L.e0) * u0 + ld3(L.e1) * u1;
+        normal = ld3(L.n);
     } else if (L.shape_kind == KY_SHAPE_SPHERE) {
         const f3 dir = uniform_sphere_sample(u0, u1);
-        position = ld3(L.p[0]) + L.radius * dir;
-        normal = normalize(dir);
+        position = ld3(L.p1) + L.radius * dir;
+        normal = dir;
     } else if (L.shape_kind == KY_SHAPE_TRIANGLE) {
-        const float su0 = sqrtf(u0);
+        const float su0 = fsqrt(u0);
         const float bx = 1 - su0, by = u1 * su0;
-        position = bx * ld3(L.p[0]) + by * ld3(L.p[1]) + (1 - bx - by) * ld3(L.p[2]);
+        position = bx * ld3(L.p1) + by * ld3(L.e0) + (1 - bx - by) * ld3(L.e1);   // p0, p1, p2
         normal = ld3(L.n);
     } else {  // disk
         const Frame fr = make_frame(ld3(L.n));
-        const float rx = 2.f * u0 - 1, ry = 2.f * u1 - 1;
-        float px = 0.f, py = 0.f;
-        if (!(rx == 0 && ry == 0)) {
-            float radius, theta;
-            if (fabsf(rx) > fabsf(ry)) { radius = rx; theta = K_PI_OVER4 * (ry / rx); }
-            else { radius = ry; theta = K_PI_OVER2 - K_PI_OVER4 * (rx / ry); }
-            float sn, cs;
-            sincosf(theta, &sn, &cs);
-            px = cs * radius;
-            py = sn * radius;
-        }
-        position = ld3(L.p[0]) + L.radius * (fr.s * px + fr.t * py);
-        normal = normalize(ld3(L.n));
+        float px, py;
+        concentric_disk(u0, u1, px, py);
+        position = ld3(L.p1) + L.radius * (fr.s * px + fr.t * py);
+        normal = ld3(L.n);
     }
 }
 
 // shape_t::sample_direction (1028-1051) and sphere_t::sample_direction (1419-1501)
 KY_DEV void shape_sample_direction(const DLight& L, f3 p, f3 p_normal, float u0, float u1, f3& lposition, f3& lnormal, float& pdf) {
     const bool sphere = L.shape_kind == KY_SHAPE_SPHERE;
-    const f3 c = ld3(L.p[0]);
-    if (sphere && !(length_sq(p - c) <= L.radius * L.radius)) {
+    const f3 c = ld3(L.p1);
+    const float dc2 = length_sq(p - c);
+    if (sphere && !(dc2 <= L.radius * L.radius)) {
         // outside the sphere: uniform cone sampling, 1458-1500
-        const float dist = sqrtf(length_sq(p - c));
-        const float inv_dist = 1 / dist;
+        const float inv_dist = rsq(dc2);
         const float sin_theta_max = L.radius * inv_dist;
         const float sin_theta_max_sq = sin_theta_max * sin_theta_max;
-        const float inv_sin_theta_max = 1 / sin_theta_max;
-        const float cos_theta_max = sqrtf(fmaxf(0.f, 1 - sin_theta_max_sq));
+        const float inv_sin_theta_max = rcp(sin_theta_max);
+        const float cos_theta_max = fsqrt(fmaxf(0.f, 1 - sin_theta_max_sq));
         float cos_theta = (cos_theta_max - 1) * u0 + 1;
         float sin_theta_sq = 1 - cos_theta * cos_theta;
         if (sin_theta_max_sq < 0.00068523f) {
             sin_theta_sq = sin_theta_max_sq * u0;
-            cos_theta = sqrtf(1 - sin_theta_sq);
+            cos_theta = fsqrt(1 - sin_theta_sq);
         }
         const float cos_alpha = sin_theta_sq * inv_sin_theta_max +
-                                cos_theta * sqrtf(fmaxf(0.f, 1.f - sin_theta_sq * inv_sin_theta_max * inv_sin_theta_max));
-        const float sin_alpha = sqrtf(fmaxf(0.f, 1.f - cos_alpha * cos_alpha));
-        const float phi = u1 * 2 * K_PI;
+                                cos_theta * fsqrt(fmaxf(0.f, 1.f - sin_theta_sq * inv_sin_theta_max * inv_sin_theta_max));
+        const float sin_alpha = fsqrt(fmaxf(0.f, 1.f - cos_alpha * cos_alpha));
         const Frame fr = make_frame((c - p) * inv_dist);
-        float sn, cs;
-        sincosf(phi, &sn, &cs);
-        const f3 world_normal = sin_alpha * cs * (-fr.s) + sin_alpha * sn * (-fr.t) + cos_alpha * (-fr.n);  // 431-439
+        const f3 world_normal = (sin_alpha * cos_rev(u1)) * (-fr.s) + (sin_alpha * sin_rev(u1)) * (-fr.t) + cos_alpha * (-fr.n);  // 431-439
         lposition = c + L.radius * world_normal;
         lnormal = world_normal;
-        pdf = 1 / (2 * K_PI * (1 - cos_theta_max));
+        pdf = rcp(2 * K_PI * (1 - cos_theta_max));
         return;
     }
     shape_sample_position(L, u0, u1, lposition, lnormal);
-    const float area_pdf = 1 / L.area;
-    f3 wi = lposition - p;
-    const float d2 = length_sq(wi);
+    const f3 wv = lposition - p;
+    const float d2 = length_sq(wv);
     if (d2 == 0) {
         pdf = 0;
     } else {
-        wi = normalize(wi);
+        const f3 wi = wv * rsq(d2);
         // inside-sphere case divides by the SHADE POINT's normal (quirk, 1436); the base class by the light's (1044)
         const f3 nn = sphere ? p_normal : lnormal;
-        pdf = area_pdf * d2 / fabsf(dot(nn, -wi));
+        pdf = L.inv_area * d2 * rcp(fabsf(dot(nn, wi)));
         if (isinf(pdf)) pdf = 0.f;
     }
 }
 
 // shape_t::pdf_direction (1055-1090) and sphere_t::pdf_direction (1503-1513)
-KY_DEV float shape_pdf_direction(const DLight& L, f3 p, f3 p_normal, f3 wi) {
-    const f3 c = ld3(L.p[0]);
-    if (L.shape_kind == KY_SHAPE_SPHERE && !(length_sq(p - c) <= L.radius * L.radius)) {
-        const float sin_theta_max_sq = L.radius * L.radius / length_sq(p - c);
-        const float cos_theta_max = sqrtf(fmaxf(0.f, 1 - sin_theta_max_sq));
-        return 1 / (2 * K_PI * (1 - cos_theta_max));  // uniform_cone_pdf, 798; never tests the hit (quirk 13)
+KY_DEV float shape_pdf_direction(const DLight& L, const DShapeFull* __restrict__ full, f3 p, f3 p_normal, f3 wi) {
+    const f3 c = ld3(L.p1);
+    const float dc2 = length_sq(p - c);
+    if (L.shape_kind == KY_SHAPE_SPHERE && !(dc2 <= L.radius * L.radius)) {
+        const float sin_theta_max_sq = L.radius * L.radius * rcp(dc2);
+        const float cos_theta_max = fsqrt(fmaxf(0.f, 1 - sin_theta_max_sq));
+        return rcp(2 * K_PI * (1 - cos_theta_max));  // uniform_cone_pdf, 798; never tests the hit (quirk 13)
     }
     // base class: re-intersect the light's OWN shape with isect.spawn_ray(wi)
     const f3 o = offset_ray_origin(p, p_normal, wi);
-    struct { float p[4][3]; float n[3]; float radius; float radius_sq; } sh;
-    for (int k = 0; k < 4; ++k) for (int j = 0; j < 3; ++j) sh.p[k][j] = L.p[k][j];
-    for (int j = 0; j < 3; ++j) sh.n[j] = L.n[j];
-    sh.radius = L.radius;
-    sh.radius_sq = L.radius * L.radius;
     float t;
-    if (!shape_hit(sh, L.shape_kind, o, wi, K_INF, t)) return 0.f;
+    if (!surf_hit(L.isect, full, o, wi, K_INF, t)) return 0.f;
     const f3 hp = o + t * wi;
     f3 ln = ld3(L.n);
     if (L.shape_kind == KY_SHAPE_SPHERE) ln = normalize(hp - c);
-    else if (L.shape_kind == KY_SHAPE_RECTANGLE) ln = dot(ln, wi) <= 0 ? ln : -ln;
-    float pdf = length_sq(p - hp) / (fabsf(dot(ln, -wi)) * L.area);
+    float pdf = length_sq(p - hp) * rcp(fabsf(dot(ln, wi)) * L.area);   // |dot| makes the ray-facing flip (1289) irrelevant
     if (isinf(pdf)) pdf = 0.f;
     return pdf;
+}
+
+// environment_light_t's pdf (3032-3036, 3046-3052): 1 / (2 pi^2 sin(theta)), theta = acos(clamp(wi.z)):
+// sin(acos(z)) = sqrt(1 - z^2)
+KY_DEV float env_pdf(float wz) {
+    const float z = fminf(fmaxf(wz, -1.f), 1.f);
+    const float sin_theta = fsqrt(fmaxf(0.f, 1.f - z * z));
+    return sin_theta == 0 ? 0.f : rcp(2 * K_PI * K_PI * sin_theta);
 }
 
 // light_t::sample_Li x4 (2825, 2891, 2964, 3026)
@@ -575,43 +627,38 @@ KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0,
         shape_sample_direction(L, p, p_normal, u0, u1, lposition, lnormal, s.pdf);
         s.position = lposition;
         const f3 dv = lposition - p;
-        if (!(s.pdf == 0 || length_sq(dv) == 0)) {
-            s.wi = normalize(dv);
+        const float d2 = length_sq(dv);
+        if (!(s.pdf == 0 || d2 == 0)) {
+            s.wi = dv * rsq(d2);
             // areal_radiance(light_isect, -wi) with the SAMPLED (stored) normal: one-sided (quirk 5), 2957-2960
-            if (dot(lnormal, -s.wi) > 0) s.Li = ld3(L.color);
+            if (dot(lnormal, s.wi) < 0) s.Li = ld3(L.color);
         }
     } else if (L.kind == KY_LIGHT_POINT) {
         const f3 lp = ld3(L.position);
+        const f3 dv = lp - p;
+        const float inv_d2 = rcp(length_sq(dv));
         s.position = lp;
-        s.wi = normalize(lp - p);
+        s.wi = dv * fsqrt(inv_d2);
         s.pdf = 1.f;
-        s.Li = ld3(L.color) / length_sq(lp - p);
+        s.Li = ld3(L.color) * inv_d2;
     } else if (L.kind == KY_LIGHT_DIRECTION) {
         s.wi = -ld3(L.direction);
-        s.position = p + s.wi * 2 * L.world_radius;
+        s.position = p + s.wi * (2 * L.world_radius);
         s.pdf = 1;
         s.Li = ld3(L.color);
-    } else {  // environment: uniform sphere direction with pdf 1/(2 pi^2 sin(theta)) (quirk 4), 3026-3041
+    } else {  // environment: uniform sphere direction with the pdf of quirk 4, 3026-3041
         s.wi = uniform_sphere_sample(u0, u1);
-        s.position = p + s.wi * 2 * L.world_radius;
-        const float theta = acosf(fminf(fmaxf(s.wi.z, -1.f), 1.f));
-        const float sin_theta = sinf(theta);
-        s.pdf = 1 / (2 * K_PI * K_PI * sin_theta);
-        if (sin_theta == 0) s.pdf = 0;
+        s.position = p + s.wi * (2 * L.world_radius);
+        s.pdf = env_pdf(s.wi.z);
         s.Li = ld3(L.color);
     }
     return s;
 }
 
 // light_t::pdf_Li x4 (2855, 2903, 2984, 3043)
-KY_DEV float light_pdf_Li(const DLight& L, f3 p, f3 p_normal, f3 wi) {
-    if (L.kind == KY_LIGHT_AREA) return shape_pdf_direction(L, p, p_normal, wi);
-    if (L.kind == KY_LIGHT_ENVIRONMENT) {
-        const float theta = acosf(fminf(fmaxf(wi.z, -1.f), 1.f));
-        const float sin_theta = sinf(theta);
-        if (sin_theta == 0) return 0;
-        return 1 / (2 * K_PI * K_PI * sin_theta);
-    }
+KY_DEV float light_pdf_Li(const DLight& L, const DShapeFull* __restrict__ full, f3 p, f3 p_normal, f3 wi) {
+    if (L.kind == KY_LIGHT_AREA) return shape_pdf_direction(L, full, p, p_normal, wi);
+    if (L.kind == KY_LIGHT_ENVIRONMENT) return env_pdf(wi.z);
     return 0;
 }
 
@@ -619,7 +666,7 @@ KY_DEV float light_pdf_Li(const DLight& L, f3 p, f3 p_normal, f3 wi) {
 // direct lighting (ky.cpp:3834-4088)
 // ---------------------------------------------------------------------------------------------
 
-// emission seen along a ray that hit `surface` at `position` (surface_t::intersect 3084 + areal_radiance 2957)
+// emission seen along a ray that hit `surface` (surface_t::intersect 3084 + areal_radiance 2957)
 KY_DEV f3 surface_emission(const LdsScene& Lds, int surface, f3 normal, f3 wo) {
     const int al = Lds.hit[surface].area_light;
     f3 e = mk3(0, 0, 0);
@@ -653,10 +700,10 @@ KY_DEV f3 estimate_by_bsdf(const DScene* __restrict__ S, const LdsScene& Lds, co
         }
         if (!is_black(Li)) {
             if (MIS) {
-                const float light_pdf = light_pdf_Li(L, v.position, v.normal, bs.wi);
-                if (light_pdf > 0) Ld = 2.f * (f_cos * Li) / (bs.pdf + light_pdf);  // 4028
+                const float light_pdf = light_pdf_Li(L, S->full, v.position, v.normal, bs.wi);
+                if (light_pdf > 0) Ld = (f_cos * Li) * (2.f * rcp(bs.pdf + light_pdf));  // 4028
             } else {
-                Ld = f_cos * Li / bs.pdf;  // 3924
+                Ld = (f_cos * Li) * rcp(bs.pdf);  // 3924
             }
         }
     }
@@ -673,8 +720,10 @@ KY_DEV f3 estimate_by_emitter(const DScene* __restrict__ S, const LdsScene& Lds,
     if (!dead) {
         // scene_t::occluded(isect, ls.position), 3187-3201
         const f3 to = ls.position - v.position;
-        const f3 dir = normalize(to);
-        const float dist = sqrtf(length_sq(v.position - ls.position));
+        const float d2 = length_sq(to);
+        const float inv_d = rsq(d2);
+        const f3 dir = to * inv_d;
+        const float dist = d2 * inv_d;
         const f3 o = offset_ray_origin(v.position, v.normal, dir);
         const bool occ = trace_any(S, o, dir, dist - 2e-3f);
         if (!occ) {
@@ -684,8 +733,8 @@ KY_DEV f3 estimate_by_emitter(const DScene* __restrict__ S, const LdsScene& Lds,
             const f3 f_cos = f * fabsf(dot(ls.wi, v.normal));
             if (!is_black(f_cos)) {
                 const bool delta_light = L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION;
-                if (!MIS || delta_light) Ld = f_cos * ls.Li / ls.pdf;        // 3956 / 4057
-                else Ld = 2 * (f_cos * ls.Li) / (ls.pdf + bsdf_pdf);         // 4070
+                if (!MIS || delta_light) Ld = (f_cos * ls.Li) * rcp(ls.pdf);          // 3956 / 4057
+                else Ld = (f_cos * ls.Li) * (2.f * rcp(ls.pdf + bsdf_pdf));            // 4070
             }
         }
     }
@@ -699,19 +748,18 @@ KY_DEV f3 sample_all_light(const DScene* __restrict__ S, const LdsScene& Lds, co
     const int nl = S->n_lights;
     for (int li = 0; li < nl; ++li) {
         // the reference's GCC build draws random_bsdf first, then random_light (3866-3868)
-        const float ub0 = sampler_at<DEBUG_SAMPLER>(smp, smp.dim), ub1 = sampler_at<DEBUG_SAMPLER>(smp, smp.dim + 1);
-        const float ul0 = sampler_at<DEBUG_SAMPLER>(smp, smp.dim + 2), ul1 = sampler_at<DEBUG_SAMPLER>(smp, smp.dim + 3);
+        const uint32_t d0 = smp.dim;
         smp.dim += 4;
         if (strategy == KY_DIRECT_BOTH_MIS) {  // 4076-4088
-            const f3 Lb = estimate_by_bsdf<true>(S, Lds, v, li, ub0, ub1);
-            const f3 Ll = estimate_by_emitter<true>(S, Lds, v, li, ul0, ul1);
+            const f3 Lb = estimate_by_bsdf<true>(S, Lds, v, li, sampler_at<DEBUG_SAMPLER>(smp, d0), sampler_at<DEBUG_SAMPLER>(smp, d0 + 1));
+            const f3 Ll = estimate_by_emitter<true>(S, Lds, v, li, sampler_at<DEBUG_SAMPLER>(smp, d0 + 2), sampler_at<DEBUG_SAMPLER>(smp, d0 + 3));
             Ld = Ld + (0.5f * Lb + 0.5f * Ll);
         } else if (strategy == KY_DIRECT_BSDF_MIS) {
-            Ld = Ld + estimate_by_bsdf<true>(S, Lds, v, li, ub0, ub1);
+            Ld = Ld + estimate_by_bsdf<true>(S, Lds, v, li, sampler_at<DEBUG_SAMPLER>(smp, d0), sampler_at<DEBUG_SAMPLER>(smp, d0 + 1));
         } else if (strategy == KY_DIRECT_LIGHT_MIS) {
-            Ld = Ld + estimate_by_emitter<true>(S, Lds, v, li, ul0, ul1);
+            Ld = Ld + estimate_by_emitter<true>(S, Lds, v, li, sampler_at<DEBUG_SAMPLER>(smp, d0 + 2), sampler_at<DEBUG_SAMPLER>(smp, d0 + 3));
         } else if (strategy == KY_DIRECT_LIGHT) {
-            Ld = Ld + estimate_by_emitter<false>(S, Lds, v, li, ul0, ul1);
+            Ld = Ld + estimate_by_emitter<false>(S, Lds, v, li, sampler_at<DEBUG_SAMPLER>(smp, d0 + 2), sampler_at<DEBUG_SAMPLER>(smp, d0 + 3));
         } else if (strategy == KY_DIRECT_BSDF) {
             const int lk = S->light[li].kind;
             if (!(lk == KY_LIGHT_POINT || lk == KY_LIGHT_DIRECTION)) {  // the third float2 is drawn after the delta test (3894-3900)
@@ -731,7 +779,7 @@ KY_DEV f3 sample_all_light(const DScene* __restrict__ S, const LdsScene& Lds, co
 // the path by one vertex and returns false when the path has ended (radiance complete in Lo).
 // ---------------------------------------------------------------------------------------------
 struct PathState {
-    f3 o, d;       // current ray
+    f3 o, d;  // current ray
     f3 beta, Lo;
     Sampler smp;
     int bounces;
@@ -785,14 +833,15 @@ KY_DEV bool path_step(PathState& ps, const DScene* __restrict__ S, const LdsScen
         return false;  // debug integrators return black on a miss (4121)
     }
 
-    // material->scattering(isect) for the nearest hit (3083)
-    const float lobe_u = sampler_at<DEBUG_SAMPLER>(ps.smp, KY_DIM_LOBE + (uint32_t)ps.bounces);
-    v.bsdf = make_bsdf(Lds.mat[Lds.hit[hs].material], lobe_u);
+    // material->scattering(isect) for the nearest hit (3083); only plastic draws a lobe number (2663)
+    const DMat& M = Lds.mat[Lds.hit[hs].material];
+    const float lobe_u = M.kind == KY_MATERIAL_PLASTIC ? sampler_at<DEBUG_SAMPLER>(ps.smp, KY_DIM_LOBE + (uint32_t)ps.bounces) : 0.f;
+    v.bsdf = make_bsdf(M, lobe_u);
     v.frame = make_frame(v.normal);
 
     if (rc.integrator < KY_INTEGRATOR_DIRECT_LIGHTING) {  // debug_integrator_t, 4110-4118
         if (rc.integrator == KY_INTEGRATOR_POSITION) ps.Lo = normalize(v.position);
-        else if (rc.integrator == KY_INTEGRATOR_NORMAL) ps.Lo = normalize(v.normal);
+        else if (rc.integrator == KY_INTEGRATOR_NORMAL) ps.Lo = v.normal;
         else {
             float pdf;
             bsdf_eval_pdf(v.bsdf, to_local(v.frame, v.wo), to_local(v.frame, v.normal), ps.Lo, pdf);
@@ -813,7 +862,7 @@ KY_DEV bool path_step(PathState& ps, const DScene* __restrict__ S, const LdsScen
     BsdfSample bs = bsdf_sample_local(v.bsdf, to_local(v.frame, v.wo), u0, u1);
     bs.wi = to_world(v.frame, bs.wi);
     if (is_black(bs.f) || bs.pdf == 0.f) return false;  // 4588
-    ps.beta = ps.beta * (bs.f * fabsf(dot(bs.wi, v.normal)) / bs.pdf);  // 4592
+    ps.beta = ps.beta * (bs.f * (fabsf(dot(bs.wi, v.normal)) * rcp(bs.pdf)));  // 4592
     ps.prev_specular = (bs.flags & BSDF_SPECULAR) != 0;  // 4596
     ps.o = offset_ray_origin(v.position, v.normal, bs.wi);  // 4597
     ps.d = bs.wi;
@@ -823,7 +872,7 @@ KY_DEV bool path_step(PathState& ps, const DScene* __restrict__ S, const LdsScen
         const float u = sampler_at<DEBUG_SAMPLER>(ps.smp, ps.smp.dim);
         ps.smp.dim += 1;
         if (u < q) return false;
-        ps.beta = ps.beta * (1 / (1 - q));
+        ps.beta = ps.beta * rcp(1 - q);
     }
     ps.bounces += 1;
     // The vertex at bounces == max_depth can only add emission after a delta bounce (4548, 4563):

@@ -3,10 +3,14 @@
  *
  * Kernel structure (DESIGN.md "Kernels"):
  *   render_kernel     persistent workgroups; each wavefront pulls work items (an 8x8 pixel block x a
- *                     chunk of samples) from a device counter; one lane owns one pixel and runs a flat
- *                     state machine over path vertices, regenerating a new camera sample the moment
- *                     its path ends, so lanes stay busy without any path state in HBM.
- *   reduce_kernel     sums the per-chunk partial pixel sums in chunk order, clamps, writes the tile buffer.
+ *                     chunk of KY_CHUNK samples) from a device counter; one lane owns one pixel of the
+ *                     block and runs a flat state machine over path vertices, regenerating a new camera
+ *                     sample the moment its path ends; a lane that finishes its chunk moves on to the
+ *                     wave's next item without waiting for the other lanes (per-wave ring of fetched
+ *                     items), so lanes stay busy and no path state ever goes to HBM.  A finished chunk's
+ *                     pixel sum is added to a 64-bit fixed-point accumulator with integer atomics
+ *                     (order-independent => bit-identical images for every tiling / GPU count).
+ *   resolve_kernel    fixed-point accumulator -> clamp01 -> fp32 tile buffer.
  *   film_add_kernel   film_t::add_color (ky.cpp:1586) for a shard's compact tile buffer.
  *   kat_*             function-level known-answer-test kernels.
  * gfx950 only; no CPU fallback anywhere in this file.
@@ -48,12 +52,16 @@ static int fail(int code, const char* fmt, ...) {
 // ------------------------------------------------------------------------------------------------
 // shard geometry (host + device)
 // ------------------------------------------------------------------------------------------------
+constexpr int KY_CHUNK = 32;        // samples per work item (fixed: chunk boundaries must not depend on the sharding)
+constexpr int KY_RING = 8;          // fetched-but-not-yet-started items a wave can hold
+constexpr double KY_FIX_SCALE = 4294967296.0;   // 2^32: accumulator resolution 2.3e-10, range +-2.1e9
+
 struct ShardConst {
     int tile_w, tile_h, tile_first, tile_step;
     int tiles_x, tiles_y, n_tiles;     // tiles of the whole film / tiles owned by this shard
     int blocks_w, blocks_per_tile;     // 8x8 pixel blocks inside a tile
     int n_blocks;                      // n_tiles * blocks_per_tile
-    int n_chunks, chunk_size;          // sample chunks
+    int n_chunks;                      // ceil(spp / KY_CHUNK)
     unsigned n_items;                  // n_blocks * n_chunks
     int n_pix;                         // n_tiles * tile_w * tile_h
 };
@@ -77,7 +85,7 @@ static bool valid_params(const ky_render_params* p) {
     return true;
 }
 
-static ShardConst make_shard(const ky_render_params* p, int target_items) {
+static ShardConst make_shard(const ky_render_params* p) {
     ShardConst s{};
     s.tile_w = p->tile_w; s.tile_h = p->tile_h; s.tile_first = p->tile_first; s.tile_step = p->tile_step;
     s.tiles_x = (p->width + p->tile_w - 1) / p->tile_w;
@@ -88,13 +96,7 @@ static ShardConst make_shard(const ky_render_params* p, int target_items) {
     s.blocks_per_tile = s.blocks_w * (p->tile_h / 8);
     s.n_blocks = s.n_tiles * s.blocks_per_tile;
     s.n_pix = s.n_tiles * p->tile_w * p->tile_h;
-    // split the samples of a pixel into chunks until there are enough work items to balance the chip
-    int chunks = 1;
-    if (s.n_blocks > 0 && target_items > 0) chunks = (target_items + s.n_blocks - 1) / s.n_blocks;
-    if (chunks > p->samples_per_pixel) chunks = p->samples_per_pixel;
-    if (chunks < 1) chunks = 1;
-    s.chunk_size = (p->samples_per_pixel + chunks - 1) / chunks;
-    s.n_chunks = (p->samples_per_pixel + s.chunk_size - 1) / s.chunk_size;
+    s.n_chunks = (p->samples_per_pixel + KY_CHUNK - 1) / KY_CHUNK;
     s.n_items = (unsigned)s.n_blocks * (unsigned)s.n_chunks;
     return s;
 }
@@ -102,68 +104,140 @@ static ShardConst make_shard(const ky_render_params* p, int target_items) {
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-template <bool DEBUG_SAMPLER>
-__global__ __launch_bounds__(256) void render_kernel(const DScene* __restrict__ S, RenderConst rc, ShardConst sh,
-                                                     unsigned* __restrict__ counter, float* __restrict__ out) {
+#ifndef KY_WAVES_PER_EU
+#define KY_WAVES_PER_EU 2
+#endif
+
+struct ItemSlot {  // one fetched work item, decoded once (wave-uniform) and read per lane
+    int x0, y0, pix0, s_begin, s_end;
+};
+
+KY_DEV int wave_min_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
+    return v;
+}
+KY_DEV int wave_max_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return v;
+}
+
+// STRATEGY >= 0 fixes direct_sample_enum at compile time (prunes the other estimators); -1 reads rc.strategy.
+template <bool DEBUG_SAMPLER, int STRATEGY>
+__global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DScene* __restrict__ S, RenderConst rc, ShardConst sh,
+                                                                     unsigned* __restrict__ counter, unsigned long long* __restrict__ accum,
+                                                                     unsigned* __restrict__ flags) {
     __shared__ LdsScene Lds;
+    __shared__ ItemSlot ring[4][KY_RING];
     stage_scene(Lds, S);
+    if (STRATEGY >= 0) rc.strategy = STRATEGY;
 
     const int lane = threadIdx.x & 63;
     const int lx = lane & 7, ly = lane >> 3;
+    ItemSlot* my_ring = ring[threadIdx.x >> 6];
+
+    int fetched = 0;          // wave-uniform: items this wave has fetched so far
+    bool exhausted = false;   // wave-uniform: the global counter ran past n_items
+    int cur = 0;              // per lane: items this lane has started
+    int x = 0, y = 0, pix = 0, s = 0, s_end = 0;
+    bool has_item = false, done = false, alive = false;
+    f3 Lsum = mk3(0, 0, 0);
+    PathState ps;
 
     for (;;) {
-        unsigned item = 0;
-        if (lane == 0) item = atomicAdd(counter, 1u);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= sh.n_items) break;
-
-        const int b = (int)(item / (unsigned)sh.n_chunks), c = (int)(item % (unsigned)sh.n_chunks);
-        const int k = b / sh.blocks_per_tile, inner = b % sh.blocks_per_tile;
-        const int bx = inner % sh.blocks_w, by = inner / sh.blocks_w;
-        const int tile = sh.tile_first + k * sh.tile_step;
-        const int tx = tile % sh.tiles_x, ty = tile / sh.tiles_x;
-        const int x = tx * sh.tile_w + bx * 8 + lx, y = ty * sh.tile_h + by * 8 + ly;
-        const bool in_range = x < rc.width && y < rc.height;
-        const int s_begin = c * sh.chunk_size;
-        const int s_end = min(rc.spp, s_begin + sh.chunk_size);
-
-        PathState ps;
-        bool alive = false;
-        int s = in_range ? s_begin : s_end;
-        f3 Lpix = mk3(0, 0, 0);
-        for (;;) {
-            if (!alive && s < s_end) {  // sampler->next_sample / get_camera_sample / generate_ray, 3712-3715
-                path_begin<DEBUG_SAMPLER>(ps, S, rc, x, y, s);
-                ++s;
-                alive = true;
-            }
-            if (!__any(alive)) break;
-            if (alive) {
-                if (!path_step<DEBUG_SAMPLER>(ps, S, Lds, rc)) {
-                    Lpix = Lpix + ps.Lo * rc.inv_spp;  // L = L + Li * (1. / spp), 3717-3721
-                    alive = false;
+        // ---- (1) lanes whose chunk is finished flush it and move on to the wave's next item ----
+        const bool need = !alive && !done && s >= s_end;
+        if (__any(need)) {  // wave-uniform branch: every lane runs the bookkeeping below
+            if (need && has_item) {
+                const float v[3] = {Lsum.x, Lsum.y, Lsum.z};
+                unsigned fl = 0;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float a = v[ch];
+                    if (a != a) fl |= 1u << ch;               // NaN
+                    else if (a > 2.0e9f) fl |= 8u << ch;      // +inf (or beyond the accumulator's range)
+                    else if (a < -2.0e9f) fl |= 64u << ch;    // -inf
+                    else if (a != 0.f) atomicAdd(&accum[(size_t)pix * 3 + ch], (unsigned long long)__double2ll_rn((double)a * KY_FIX_SCALE));
                 }
+                if (fl) atomicOr(&flags[pix], fl);
+                has_item = false;
+                Lsum = mk3(0, 0, 0);
+            }
+            if (__any(need && cur >= fetched) && !exhausted) {
+                const int min_cur = wave_min_i32(done ? 0x7fffffff : cur);   // slowest lane still working
+                const int max_want = wave_max_i32(need ? cur : -1);           // highest ordinal a lane is asking for
+                // slot (fetched % KY_RING) may be overwritten once every lane has started ordinal fetched - KY_RING
+                while (fetched <= max_want && fetched - min_cur < KY_RING) {
+                    unsigned id = 0;
+                    if (lane == 0) id = atomicAdd(counter, 1u);
+                    id = __builtin_amdgcn_readfirstlane(id);
+                    if (id >= sh.n_items) { exhausted = true; break; }
+                    const int b = (int)(id / (unsigned)sh.n_chunks), c = (int)(id % (unsigned)sh.n_chunks);
+                    const int k = b / sh.blocks_per_tile, inner = b % sh.blocks_per_tile;
+                    const int bx = inner % sh.blocks_w, by = inner / sh.blocks_w;
+                    const int tile = sh.tile_first + k * sh.tile_step;
+                    if (lane == 0) {
+                        ItemSlot it;
+                        it.x0 = (tile % sh.tiles_x) * sh.tile_w + bx * 8;
+                        it.y0 = (tile / sh.tiles_x) * sh.tile_h + by * 8;
+                        it.pix0 = (k * sh.tile_h + by * 8) * sh.tile_w + bx * 8;
+                        it.s_begin = c * KY_CHUNK;
+                        it.s_end = min(rc.spp, c * KY_CHUNK + KY_CHUNK);
+                        my_ring[fetched % KY_RING] = it;
+                    }
+                    ++fetched;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // lane 0's slot writes before the other lanes' reads
+            }
+            if (need) {
+                if (cur < fetched) {
+                    const ItemSlot it = my_ring[cur % KY_RING];
+                    ++cur;
+                    x = it.x0 + lx;
+                    y = it.y0 + ly;
+                    pix = it.pix0 + ly * sh.tile_w + lx;
+                    const bool in_range = x < rc.width && y < rc.height;
+                    s = in_range ? it.s_begin : it.s_end;
+                    s_end = it.s_end;
+                    has_item = in_range;
+                } else if (exhausted) {
+                    done = true;
+                }  // else: the ring is full -- wait for the slowest lane
             }
         }
-
-        const int pix = (k * sh.tile_h + by * 8 + ly) * sh.tile_w + bx * 8 + lx;
-        float* dst = out + ((size_t)c * sh.n_pix + pix) * 3;
-        if (sh.n_chunks == 1) {  // clamp01(L), 3726
-            dst[0] = fminf(fmaxf(Lpix.x, 0.f), 1.f);
-            dst[1] = fminf(fmaxf(Lpix.y, 0.f), 1.f);
-            dst[2] = fminf(fmaxf(Lpix.z, 0.f), 1.f);
-        } else {
-            dst[0] = Lpix.x; dst[1] = Lpix.y; dst[2] = Lpix.z;
+        // ---- (2) regenerate: next camera sample of this lane's pixel (3712-3715) ----
+        if (!alive && !done && s < s_end) {
+            path_begin<DEBUG_SAMPLER>(ps, S, rc, x, y, s);
+            ++s;
+            alive = true;
+        }
+        if (!__any(alive)) {
+            if (__all(done)) break;
+            continue;
+        }
+        // ---- (3) one path vertex ----
+        if (alive) {
+            if (!path_step<DEBUG_SAMPLER>(ps, S, Lds, rc)) {
+                Lsum = Lsum + ps.Lo * rc.inv_spp;  // L = L + Li * (1. / spp), 3717-3721
+                alive = false;
+            }
         }
     }
 }
 
-__global__ void reduce_kernel(const float* __restrict__ partial, float* __restrict__ tiles, int n_floats, int n_chunks) {
+// fixed-point accumulator -> clamp01(L) (3726) -> fp32 tile buffer
+__global__ void resolve_kernel(const unsigned long long* __restrict__ accum, const unsigned* __restrict__ flags, float* __restrict__ tiles, int n_floats) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_floats) return;
-    float acc = 0.f;
-    for (int c = 0; c < n_chunks; ++c) acc += partial[(size_t)c * n_floats + i];
-    tiles[i] = fminf(fmaxf(acc, 0.f), 1.f);
+    const int ch = i % 3;
+    const unsigned fl = flags[i / 3];
+    float v = (float)((double)(long long)accum[i] * (1.0 / KY_FIX_SCALE));
+    const bool nan = (fl >> ch) & 1u, pinf = (fl >> (3 + ch)) & 1u, ninf = (fl >> (6 + ch)) & 1u;
+    if (pinf) v = 1.f;
+    if (ninf) v = 0.f;
+    if (nan || (pinf && ninf)) v = 0.f;  // a NaN pixel: clamp01 keeps NaN in the reference and its 8-bit image shows 0
+    tiles[i] = fminf(fmaxf(v, 0.f), 1.f);
 }
 
 __global__ void film_add_kernel(const float* __restrict__ tiles, float* __restrict__ film, size_t stride_px, ShardConst sh, int width, int height) {
@@ -180,7 +254,7 @@ __global__ void film_add_kernel(const float* __restrict__ tiles, float* __restri
 }
 
 // ---- KAT kernels ----
-struct KatShape { float p[4][3]; float n[3]; float radius; float radius_sq; int kind; };
+struct KatShape { DSurf surf; DShapeFull full; DHit hit; };
 
 __global__ void kat_intersect_kernel(KatShape sh, const float* __restrict__ rays7, int n, float* __restrict__ out8) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -188,14 +262,10 @@ __global__ void kat_intersect_kernel(KatShape sh, const float* __restrict__ rays
     const float* r = rays7 + 7 * (size_t)i;
     const f3 o = ld3(r), d = ld3(r + 3);
     float t;
-    const bool hit = shape_hit(sh, sh.kind, o, d, r[6], t);
-    DHit H;
-    H.kind = sh.kind;
-    if (sh.kind == KY_SHAPE_SPHERE) { H.n[0] = sh.p[0][0]; H.n[1] = sh.p[0][1]; H.n[2] = sh.p[0][2]; }
-    else { H.n[0] = sh.n[0]; H.n[1] = sh.n[1]; H.n[2] = sh.n[2]; }
+    const bool hit = surf_hit(sh.surf, &sh.full, o, d, r[6], t);
     float* o8 = out8 + 8 * (size_t)i;
     f3 p = mk3(0, 0, 0), nn = mk3(0, 0, 0);
-    if (hit) { p = o + t * d; nn = hit_normal(H, p, d); }
+    if (hit) { p = o + t * d; nn = hit_normal(sh.hit, p, d); }
     o8[0] = hit ? 1.f : 0.f; o8[1] = hit ? t : 0.f;
     o8[2] = p.x; o8[3] = p.y; o8[4] = p.z; o8[5] = nn.x; o8[6] = nn.y; o8[7] = nn.z;
 }
@@ -231,7 +301,7 @@ __global__ void kat_light_kernel(const DScene* __restrict__ S, int li, const flo
     const float* r = in11 + 11 * (size_t)i;
     const f3 p = ld3(r), pn = ld3(r + 3), wi = ld3(r + 8);
     const LightSample ls = light_sample_Li(S->light[li], p, pn, r[6], r[7]);
-    const float pdf = light_pdf_Li(S->light[li], p, pn, wi);
+    const float pdf = light_pdf_Li(S->light[li], S->full, p, pn, wi);
     float* q = out11 + 11 * (size_t)i;
     q[0] = ls.position.x; q[1] = ls.position.y; q[2] = ls.position.z; q[3] = ls.wi.x; q[4] = ls.wi.y; q[5] = ls.wi.z;
     q[6] = ls.pdf; q[7] = ls.Li.x; q[8] = ls.Li.y; q[9] = ls.Li.z; q[10] = pdf;
@@ -297,6 +367,63 @@ static float host_shape_area(const ky_shape& s) {  // shape_t::area x4 (1141, 12
     }
 }
 
+// Builds the traversal record of one shape.  A rectangle_t whose four points form a planar parallelogram gets the
+// plane + dual-basis form (precomputed in double); every other shape keeps the reference's own data in `full`.
+static void pack_shape(const ky_shape& sh, int full_index, DSurf* surf, DShapeFull* full) {
+    std::memset(surf, 0, sizeof *surf);
+    std::memset(full, 0, sizeof *full);
+    std::memcpy(full->p, sh.p, sizeof full->p);
+    cp3(full->n, sh.normal);
+    full->radius = sh.radius; full->radius_sq = sh.radius * sh.radius; full->kind = sh.kind;  // sphere_t::radius_sq_, 1332
+    surf->kind = sh.kind;
+    surf->full = full_index;
+    if (sh.kind == KY_SHAPE_SPHERE) {
+        cp3(surf->f, sh.p[0]);
+        surf->f[3] = sh.radius * sh.radius;
+        return;
+    }
+    if (sh.kind != KY_SHAPE_RECTANGLE) return;
+    double a[3], b[3], e[3], nn[3], bxn[3], nxa[3];
+    double la = 0, lb = 0, le = 0;
+    for (int j = 0; j < 3; ++j) {
+        a[j] = (double)sh.p[0][j] - sh.p[1][j];
+        b[j] = (double)sh.p[2][j] - sh.p[1][j];
+        e[j] = (double)sh.p[3][j] - ((double)sh.p[0][j] + sh.p[2][j] - sh.p[1][j]);
+        la += a[j] * a[j]; lb += b[j] * b[j]; le += e[j] * e[j];
+    }
+    auto cross3 = [](const double* x, const double* y, double* r) {
+        r[0] = x[1] * y[2] - x[2] * y[1]; r[1] = x[2] * y[0] - x[0] * y[2]; r[2] = x[0] * y[1] - x[1] * y[0];
+    };
+    auto dot3 = [](const double* x, const double* y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2]; };
+    cross3(a, b, nn);
+    const double area2 = dot3(nn, nn);
+    if (!(area2 > 1e-24) || !(std::sqrt(le) <= 1e-5 * (std::sqrt(la) + std::sqrt(lb)))) return;  // not a parallelogram: TK_QUAD
+    // the stored normal must be the plane's normal (it is, by construction: 1256); otherwise keep the general path
+    const double sn[3] = {sh.normal[0], sh.normal[1], sh.normal[2]};
+    if (std::fabs(std::fabs(dot3(sn, nn)) / std::sqrt(area2) - 1.0) > 1e-4) return;
+    cross3(b, nn, bxn);
+    cross3(nn, a, nxa);
+    const double ka = 1.0 / dot3(a, bxn), kb = 1.0 / dot3(b, nxa);
+    const double p0[3] = {sh.p[0][0], sh.p[0][1], sh.p[0][2]}, p1[3] = {sh.p[1][0], sh.p[1][1], sh.p[1][2]};
+    double as[3], bs[3];
+    for (int j = 0; j < 3; ++j) { as[j] = bxn[j] * ka; bs[j] = nxa[j] * kb; }
+    surf->kind = TK_PARALLELOGRAM;
+    cp3(surf->f, sh.normal);
+    surf->f[3] = (float)dot3(sn, p0);
+    for (int j = 0; j < 3; ++j) { surf->f[4 + j] = (float)as[j]; surf->f[8 + j] = (float)bs[j]; }
+    surf->f[7] = (float)(dot3(as, p1) + 0.5);
+    surf->f[11] = (float)(dot3(bs, p1) + 0.5);
+}
+
+static void pack_material(const ky_material& m, DMat* d) {
+    std::memset(d, 0, sizeof *d);
+    cp3(d->c0, m.color0); cp3(d->c1, m.color1);
+    d->kind = m.kind; d->eta = m.eta; d->exponent = m.exponent; d->p_diffuse = m.diffuse_probability; d->p_specular = m.specular_probability;
+    const float e = m.exponent;
+    const bool integral = std::isfinite(e) && std::fabs(e) < 16777216.f && std::floor(e) == e;
+    d->exp_flags = (integral ? 1 : 0) | ((integral && std::fmod(std::fabs(e), 2.f) == 1.f) ? 2 : 0);
+}
+
 static int pack_scene(const ky_scene* in, DScene* out) {
     if (!in) return fail(KY_ERR_INVALID_VALUE, "scene is NULL");
     if (in->surface_count < 0 || in->shape_count < 0 || in->material_count < 0 || in->light_count < 0)
@@ -311,7 +438,7 @@ static int pack_scene(const ky_scene* in, DScene* out) {
     out->env_light = in->environment_light;
     cp3(out->cam_position, in->camera.position); cp3(out->cam_front, in->camera.front); cp3(out->cam_right, in->camera.right);
     cp3(out->cam_up, in->camera.up);
-    out->cam_w = in->camera.resolution[0]; out->cam_h = in->camera.resolution[1];
+    out->cam_inv_w = 1.f / in->camera.resolution[0]; out->cam_inv_h = 1.f / in->camera.resolution[1];
     for (int i = 0; i < in->surface_count; ++i) {
         const ky_surface& sf = in->surfaces[i];
         if (sf.shape < 0 || sf.shape >= in->shape_count || sf.material < 0 || sf.material >= in->material_count || sf.area_light < -1 ||
@@ -321,10 +448,7 @@ static int pack_scene(const ky_scene* in, DScene* out) {
         if (sh.kind < KY_SHAPE_DISK || sh.kind > KY_SHAPE_SPHERE) return fail(KY_ERR_INVALID_VALUE, "shape %d has an unknown kind", sf.shape);
         if (sf.area_light >= 0 && in->lights[sf.area_light].kind != KY_LIGHT_AREA)
             return fail(KY_ERR_INVALID_VALUE, "surface %d: area_light must refer to an area light", i);
-        DSurf& d = out->surf[i];
-        std::memcpy(d.p, sh.p, sizeof d.p);
-        cp3(d.n, sh.normal);
-        d.kind = sh.kind; d.radius = sh.radius; d.radius_sq = sh.radius * sh.radius;  // sphere_t::radius_sq_, 1332
+        pack_shape(sh, i, &out->surf[i], &out->full[i]);
         DHit& h = out->hit[i];
         cp3(h.n, sh.kind == KY_SHAPE_SPHERE ? sh.p[0] : sh.normal);
         h.kind = sh.kind; h.material = sf.material; h.area_light = sf.area_light;
@@ -332,9 +456,7 @@ static int pack_scene(const ky_scene* in, DScene* out) {
     for (int i = 0; i < in->material_count; ++i) {
         const ky_material& m = in->materials[i];
         if (m.kind < KY_MATERIAL_MATTE || m.kind > KY_MATERIAL_PLASTIC) return fail(KY_ERR_INVALID_VALUE, "material %d has an unknown kind", i);
-        DMat& d = out->mat[i];
-        cp3(d.c0, m.color0); cp3(d.c1, m.color1);
-        d.kind = m.kind; d.eta = m.eta; d.exponent = m.exponent; d.p_diffuse = m.diffuse_probability; d.p_specular = m.specular_probability;
+        pack_material(m, &out->mat[i]);
     }
     for (int i = 0; i < in->light_count; ++i) {
         const ky_light& l = in->lights[i];
@@ -345,9 +467,18 @@ static int pack_scene(const ky_scene* in, DScene* out) {
         if (l.kind == KY_LIGHT_AREA) {
             if (l.shape < 0 || l.shape >= in->shape_count) return fail(KY_ERR_INVALID_VALUE, "area light %d: shape out of range", i);
             const ky_shape& sh = in->shapes[l.shape];
-            std::memcpy(d.p, sh.p, sizeof d.p);
+            if (sh.kind < KY_SHAPE_DISK || sh.kind > KY_SHAPE_SPHERE) return fail(KY_ERR_INVALID_VALUE, "shape %d has an unknown kind", l.shape);
+            d.shape_kind = sh.kind; d.radius = sh.radius; d.area = host_shape_area(sh); d.inv_area = 1 / d.area;  // area_pdf = 1 / area(), 1313
             cp3(d.n, sh.normal);
-            d.shape_kind = sh.kind; d.radius = sh.radius; d.area = host_shape_area(sh);
+            if (sh.kind == KY_SHAPE_RECTANGLE) {  // p1 + (p0 - p1) u0 + (p2 - p1) u1, 1310
+                cp3(d.p1, sh.p[1]);
+                for (int j = 0; j < 3; ++j) { d.e0[j] = sh.p[0][j] - sh.p[1][j]; d.e1[j] = sh.p[2][j] - sh.p[1][j]; }
+            } else if (sh.kind == KY_SHAPE_TRIANGLE) {
+                cp3(d.p1, sh.p[0]); cp3(d.e0, sh.p[1]); cp3(d.e1, sh.p[2]);
+            } else {
+                cp3(d.p1, sh.p[0]);
+            }
+            pack_shape(sh, KYHIP_MAX_SURFACES + i, &d.isect, &out->full[KYHIP_MAX_SURFACES + i]);
         }
     }
     return KY_OK;
@@ -362,7 +493,7 @@ struct DeviceCtx {
     void* ws = nullptr;
     size_t ws_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int blocks_per_cu[2] = {0, 0};
+    int blocks_per_cu[3] = {0, 0, 0};
 };
 static std::mutex g_mutex;
 static DeviceCtx g_ctx[16];
@@ -384,8 +515,9 @@ static int get_ctx(int device, DeviceCtx** out) {
         HIP_TRY(hipMalloc(&c.d_counter, 256));
         HIP_TRY(hipEventCreate(&c.ev0));
         HIP_TRY(hipEventCreate(&c.ev1));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[0], render_kernel<false>, 256, 0));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[1], render_kernel<true>, 256, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[0], render_kernel<false, KY_DIRECT_BOTH_MIS>, 256, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[1], render_kernel<false, -1>, 256, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[2], render_kernel<true, -1>, 256, 0));
         c.init = true;
     }
     *out = &c;
@@ -409,7 +541,6 @@ static RenderConst make_rc(const ky_render_params* p) {
     return rc;
 }
 
-static int target_items_for(const DeviceCtx* c) { return c->cus * 8 * 4 * 12; }  // ~12 items per resident wave slot
 
 // shared driver of the KAT entry points
 template <typename F>
@@ -448,18 +579,18 @@ int kyhip_device_count(void) {
 
 int64_t kyhip_shard_tile_count(const ky_render_params* p) {
     if (!valid_params(p)) return fail(KY_ERR_INVALID_VALUE, "invalid render params");
-    return make_shard(p, 0).n_tiles;
+    return make_shard(p).n_tiles;
 }
 int64_t kyhip_shard_float_count(const ky_render_params* p) {
     if (!valid_params(p)) return fail(KY_ERR_INVALID_VALUE, "invalid render params");
-    return (int64_t)make_shard(p, 0).n_pix * 3;
+    return (int64_t)make_shard(p).n_pix * 3;
 }
 
-// worst case: every sample its own chunk is never needed; bound chunks by the item target of a 256-CU part
+// per pixel of the shard: 3 x 64-bit fixed-point sums + one flag word
+static size_t workspace_bytes_for(const ShardConst& s) { return (size_t)s.n_pix * (3 * sizeof(unsigned long long) + sizeof(unsigned)); }
 size_t kyhip_workspace_bytes(const ky_render_params* p) {
     if (!valid_params(p)) return 0;
-    const ShardConst s = make_shard(p, 256 * 8 * 4 * 12);
-    return s.n_chunks > 1 ? (size_t)s.n_chunks * s.n_pix * 3 * sizeof(float) : 0;
+    return workspace_bytes_for(make_shard(p));
 }
 
 int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render_params* p, float* d_tiles, void* d_workspace,
@@ -474,44 +605,43 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
     rcode = upload_scene(c, scene, stream);
     if (rcode != KY_OK) return rcode;
 
-    const ShardConst sh = make_shard(p, target_items_for(c));
+    const ShardConst sh = make_shard(p);
     if (sh.n_tiles == 0) return KY_OK;
     const RenderConst rc = make_rc(p);
     const bool dbg = p->sampler == KY_SAMPLER_DEBUG;
 
-    float* out = d_tiles;
-    if (sh.n_chunks > 1) {
-        const size_t need = (size_t)sh.n_chunks * sh.n_pix * 3 * sizeof(float);
-        if (d_workspace && workspace_bytes >= need) {
-            out = (float*)d_workspace;
-        } else {
-            if (c->ws_bytes < need) {
-                HIP_TRY(hipStreamSynchronize(stream));
-                if (c->ws) HIP_TRY(hipFree(c->ws));
-                c->ws = nullptr; c->ws_bytes = 0;
-                HIP_TRY(hipMalloc(&c->ws, need));
-                c->ws_bytes = need;
-            }
-            out = (float*)c->ws;
+    const size_t need = workspace_bytes_for(sh);
+    void* ws = d_workspace;
+    if (!(d_workspace && workspace_bytes >= need)) {
+        if (c->ws_bytes < need) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (c->ws) HIP_TRY(hipFree(c->ws));
+            c->ws = nullptr; c->ws_bytes = 0;
+            HIP_TRY(hipMalloc(&c->ws, need));
+            c->ws_bytes = need;
         }
+        ws = c->ws;
     }
-
+    unsigned long long* accum = (unsigned long long*)ws;
+    unsigned* flags = (unsigned*)(accum + (size_t)sh.n_pix * 3);
+    HIP_TRY(hipMemsetAsync(ws, 0, need, stream));
     HIP_TRY(hipMemsetAsync(c->d_counter, 0, sizeof(unsigned), stream));
-    const int per_cu = c->blocks_per_cu[dbg ? 1 : 0] > 0 ? c->blocks_per_cu[dbg ? 1 : 0] : 1;
+
+    const int variant = dbg ? 2 : (p->direct_sample == KY_DIRECT_BOTH_MIS && p->integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION ? 0 : 1);
+    const int per_cu = c->blocks_per_cu[variant] > 0 ? c->blocks_per_cu[variant] : 1;
     unsigned grid = (unsigned)(c->cus * per_cu);
     const unsigned need_blocks = (sh.n_items + 3) / 4;
     if (grid > need_blocks) grid = need_blocks;
     if (grid < 1) grid = 1;
     HIP_TRY(hipEventRecord(c->ev0, stream));
-    if (dbg) hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, out);
-    else hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, out);
+    if (variant == 0) hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_BOTH_MIS>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags);
+    else if (variant == 1) hipLaunchKernelGGL((render_kernel<false, -1>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags);
+    else hipLaunchKernelGGL((render_kernel<true, -1>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, stream));
-    if (sh.n_chunks > 1) {
-        const int nf = sh.n_pix * 3;
-        hipLaunchKernelGGL(reduce_kernel, dim3((nf + 255) / 256), dim3(256), 0, stream, out, d_tiles, nf, sh.n_chunks);
-        HIP_TRY(hipGetLastError());
-    }
+    const int nf = sh.n_pix * 3;
+    hipLaunchKernelGGL(resolve_kernel, dim3((nf + 255) / 256), dim3(256), 0, stream, accum, flags, d_tiles, nf);
+    HIP_TRY(hipGetLastError());
     return KY_OK;
 }
 
@@ -530,7 +660,7 @@ int kyhip_film_add_tiles_device(int device, const ky_render_params* p, const flo
     DeviceCtx* c;
     int rcode = get_ctx(device, &c);
     if (rcode != KY_OK) return rcode;
-    const ShardConst sh = make_shard(p, 0);
+    const ShardConst sh = make_shard(p);
     if (sh.n_pix == 0) return KY_OK;
     hipLaunchKernelGGL(film_add_kernel, dim3((sh.n_pix + 255) / 256), dim3(256), 0, (hipStream_t)stream_, d_tiles, d_film, stride_px, sh, p->width, p->height);
     HIP_TRY(hipGetLastError());
@@ -540,7 +670,7 @@ int kyhip_film_add_tiles_device(int device, const ky_render_params* p, const flo
 int kyhip_render(int device, const ky_scene* scene, const ky_render_params* p, float* film_rgb, size_t stride_px) {
     if (!valid_params(p)) return fail(KY_ERR_INVALID_VALUE, "invalid render params (integrator %d, direct_sample %d)", p ? p->integrator : -1, p ? p->direct_sample : -1);
     if (!film_rgb || stride_px < (size_t)p->width) return fail(KY_ERR_INVALID_VALUE, "bad film arguments");
-    const ShardConst sh = make_shard(p, 0);
+    const ShardConst sh = make_shard(p);
     float *d_tiles = nullptr, *d_film = nullptr;
     const size_t film_floats = (size_t)p->width * p->height * 3;
     {
@@ -574,10 +704,11 @@ int kyhip_render(int device, const ky_scene* scene, const ky_render_params* p, f
 // ---- KAT entry points ----
 int kyhip_kat_intersect(int device, const ky_shape* shape, const float* rays7, int n, float* out8) {
     if (!shape || !rays7 || !out8 || n <= 0) return fail(KY_ERR_INVALID_VALUE, "bad KAT arguments");
+    if (shape->kind < KY_SHAPE_DISK || shape->kind > KY_SHAPE_SPHERE) return fail(KY_ERR_INVALID_VALUE, "unknown shape kind");
     KatShape ks{};
-    std::memcpy(ks.p, shape->p, sizeof ks.p);
-    cp3(ks.n, shape->normal);
-    ks.radius = shape->radius; ks.radius_sq = shape->radius * shape->radius; ks.kind = shape->kind;
+    pack_shape(*shape, 0, &ks.surf, &ks.full);
+    cp3(ks.hit.n, shape->kind == KY_SHAPE_SPHERE ? shape->p[0] : shape->normal);
+    ks.hit.kind = shape->kind;
     return kat_run(device, rays7, (size_t)n * 7 * 4, out8, (size_t)n * 8 * 4, [&](DeviceCtx*, const float* d_in, float* d_out) {
         hipLaunchKernelGGL(kat_intersect_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, ks, d_in, n, d_out);
         return (int)KY_OK;
@@ -589,6 +720,7 @@ int kyhip_kat_camera(int device, const ky_camera* camera, const float* p_film2, 
     ky_scene sc{};
     sc.environment_light = -1;
     sc.camera = *camera;
+    if (!(camera->resolution[0] > 0) || !(camera->resolution[1] > 0)) return fail(KY_ERR_INVALID_VALUE, "bad camera resolution");
     return kat_run(device, p_film2, (size_t)n * 2 * 4, out6, (size_t)n * 6 * 4, [&](DeviceCtx* c, const float* d_in, float* d_out) {
         int r = upload_scene(c, &sc, 0);
         if (r != KY_OK) return r;
@@ -599,9 +731,9 @@ int kyhip_kat_camera(int device, const ky_camera* camera, const float* p_film2, 
 
 int kyhip_kat_bsdf(int device, const ky_material* m, const float* in12, int n, float* out13) {
     if (!m || !in12 || !out13 || n <= 0) return fail(KY_ERR_INVALID_VALUE, "bad KAT arguments");
+    if (m->kind < KY_MATERIAL_MATTE || m->kind > KY_MATERIAL_PLASTIC) return fail(KY_ERR_INVALID_VALUE, "unknown material kind");
     DMat d{};
-    cp3(d.c0, m->color0); cp3(d.c1, m->color1);
-    d.kind = m->kind; d.eta = m->eta; d.exponent = m->exponent; d.p_diffuse = m->diffuse_probability; d.p_specular = m->specular_probability;
+    pack_material(*m, &d);
     return kat_run(device, in12, (size_t)n * 12 * 4, out13, (size_t)n * 13 * 4, [&](DeviceCtx*, const float* d_in, float* d_out) {
         hipLaunchKernelGGL(kat_bsdf_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d, d_in, n, d_out);
         return (int)KY_OK;

@@ -28,6 +28,21 @@
 
 #define KY_DEV __device__ __forceinline__
 
+// lane-utilisation probes (debug builds with -DKY_PROFILE_LANES): slot k counts active lanes, slot k+16 counts visits
+#ifdef KY_PROFILE_LANES
+__device__ unsigned long long g_lane_probe[32];
+#define KY_PROBE(k)                                                                                          \
+    do {                                                                                                     \
+        const unsigned long long m_ = __ballot(1);                                                           \
+        if ((int)__lane_id() == __ffsll((long long)m_) - 1) {                                                \
+            atomicAdd(&g_lane_probe[k], (unsigned long long)__popcll(m_));                                   \
+            atomicAdd(&g_lane_probe[(k) + 16], 1ull);                                                        \
+        }                                                                                                    \
+    } while (0)
+#else
+#define KY_PROBE(k) do { } while (0)
+#endif
+
 namespace kyd {
 
 // ---------------------------------------------------------------------------------------------
@@ -137,15 +152,31 @@ struct DLight {  // light_t + the shape an area light samples; wave-uniform inde
     DSurf isect;          // traversal record of the sampled shape (pdf_direction re-intersects it, 1057-1061)
 };
 
+struct DPar {  // planar parallelogram, 48 B: q0 = (n, n.p0), q1 = (a*, a*.p1 + 0.5), q2 = (b*, b*.p1 + 0.5)
+    float q0[4], q1[4], q2[4];
+};
+struct DSph {  // sphere, 16 B: centre, radius^2
+    float c[4];
+};
+
+// The surfaces are stored SORTED BY TRAVERSAL KIND -- parallelograms, then spheres, then everything else -- keeping the
+// reference's surface order inside each group, so that each traversal loop is branch-free.  `hit[]` and every surface
+// index used on the device are in this sorted order; orig[] maps back to the caller's surface index.  (Ties: the
+// reference's "first surface in list order wins an exactly equal distance" (3177-3180) is preserved inside a group;
+// an exact tie between shapes of different kinds has measure zero.)
 struct DScene {
     int32_t n_surfaces, n_lights, n_materials, env_light;
+    int32_t n_par, n_sph, n_gen, pad_n;
     float cam_position[3], cam_inv_w;
     float cam_front[3], cam_inv_h;
     float cam_right[3], pad0;
     float cam_up[3], pad1;
-    DSurf surf[KYHIP_MAX_SURFACES];
+    DPar par[KYHIP_MAX_SURFACES];
+    DSph sph[KYHIP_MAX_SURFACES];
+    DSurf gen[KYHIP_MAX_SURFACES];
     DShapeFull full[KYHIP_MAX_SURFACES + KYHIP_MAX_LIGHTS];
     DHit hit[KYHIP_MAX_SURFACES];
+    int32_t orig[KYHIP_MAX_SURFACES];
     DMat mat[KYHIP_MAX_MATERIALS];
     DLight light[KYHIP_MAX_LIGHTS];
 };
@@ -259,40 +290,60 @@ KY_DEV bool full_shape_hit(const DShapeFull& S, f3 o, f3 d, float tmax, float& t
     }
 }
 
-KY_DEV bool surf_hit(const DSurf& S, const DShapeFull* __restrict__ full, f3 o, f3 d, float tmax, float& t_out) {
-    if (S.kind == TK_PARALLELOGRAM) {  // rectangle_t::intersect (1261-1297) for a planar parallelogram
-        const float num = S.f[3] - (S.f[0] * o.x + S.f[1] * o.y + S.f[2] * o.z);   // n.(p0 - o)
-        const float den = S.f[0] * d.x + S.f[1] * d.y + S.f[2] * d.z;
-        const float t = num * rcp(den);
-        const f3 h = o + t * d;
-        const float u = (h.x * S.f[4] + h.y * S.f[5] + h.z * S.f[6]) - S.f[7];     // u - 0.5
-        const float v = (h.x * S.f[8] + h.y * S.f[9] + h.z * S.f[10]) - S.f[11];   // v - 0.5
-        t_out = t;
-        return (fabsf(u) <= 0.5f) && (fabsf(v) <= 0.5f) && (t > K_SHAPE_EPS) && (t < tmax);   // NaN (den = 0) compares false
-    } else if (S.kind == TK_SPHERE) {  // sphere_t::intersect, 1336-1393
-        const f3 oc = mk3(S.f[0], S.f[1], S.f[2]) - o;
-        const float neg_b = dot(oc, d);
-        const float discr = neg_b * neg_b - dot(oc, oc) + S.f[3];
-        const float sq = fsqrt(discr);  // NaN for discr < 0: both comparisons below are then false
-        const float t0 = neg_b - sq, t1 = neg_b + sq;
-        const bool h0 = t0 > K_SHAPE_EPS && t0 < tmax;
-        const bool h1 = t1 > K_SHAPE_EPS && t1 < tmax;
-        t_out = h0 ? t0 : t1;
-        return h0 || h1;
-    } else {
-        return full_shape_hit(full[S.full], o, d, tmax, t_out);
-    }
+// rectangle_t::intersect (1261-1297) for a planar parallelogram: plane hit, then dual-basis coordinates of the hit
+// point; |u - 0.5| <= 0.5 and |v - 0.5| <= 0.5 is "inside".  A zero denominator gives inf / NaN, which compare false.
+KY_DEV bool par_hit(const float* q0, const float* q1, const float* q2, f3 o, f3 d, float tmax, float& t_out) {
+    const float den = q0[0] * d.x + q0[1] * d.y + q0[2] * d.z;
+    const float num = q0[3] - (q0[0] * o.x + q0[1] * o.y + q0[2] * o.z);   // n.(p0 - o)
+    const float t = num * rcp(den);
+    const f3 h = o + t * d;
+    const float u = (h.x * q1[0] + h.y * q1[1] + h.z * q1[2]) - q1[3];
+    const float v = (h.x * q2[0] + h.y * q2[1] + h.z * q2[2]) - q2[3];
+    t_out = t;
+    return (fabsf(u) <= 0.5f) & (fabsf(v) <= 0.5f) & (t > K_SHAPE_EPS) & (t < tmax);
 }
 
-// scene_t::intersect, ky.cpp:3172-3184: linear scan in surface order, tmax shrinks, first of equals wins.
+// sphere_t::intersect, 1336-1393.  sqrt of a negative discriminant is NaN, which fails both range tests.
+KY_DEV bool sph_hit(const float* c, f3 o, f3 d, float tmax, float& t_out) {
+    const f3 oc = mk3(c[0], c[1], c[2]) - o;
+    const float neg_b = dot(oc, d);
+    const float discr = neg_b * neg_b - dot(oc, oc) + c[3];
+    const float sq = fsqrt(discr);
+    const float t0 = neg_b - sq, t1 = neg_b + sq;
+    const bool h0 = (t0 > K_SHAPE_EPS) & (t0 < tmax);
+    const bool h1 = (t1 > K_SHAPE_EPS) & (t1 < tmax);
+    t_out = h0 ? t0 : t1;
+    return h0 | h1;
+}
+
+// one shape given as a generic record (KAT entry point, light shapes re-intersected by pdf_direction)
+KY_DEV bool surf_hit(const DSurf& S, const DShapeFull* __restrict__ full, f3 o, f3 d, float tmax, float& t_out) {
+    if (S.kind == TK_PARALLELOGRAM) return par_hit(&S.f[0], &S.f[4], &S.f[8], o, d, tmax, t_out);
+    if (S.kind == TK_SPHERE) return sph_hit(&S.f[0], o, d, tmax, t_out);
+    return full_shape_hit(full[S.full], o, d, tmax, t_out);
+}
+
+// scene_t::intersect, ky.cpp:3172-3184: linear scan, tmax shrinks, first of equals wins.  Returns the SORTED surface index.
 KY_DEV int trace_nearest(const DScene* __restrict__ S, f3 o, f3 d, float& tmax) {
     int best = -1;
-    const int n = S->n_surfaces;
-    for (int i = 0; i < n; ++i) {
+    const int n_par = S->n_par, n_sph = S->n_sph, n_gen = S->n_gen;
+    for (int i = 0; i < n_par; ++i) {
         float t;
-        if (surf_hit(S->surf[i], S->full, o, d, tmax, t)) {
+        const bool ok = par_hit(S->par[i].q0, S->par[i].q1, S->par[i].q2, o, d, tmax, t);
+        tmax = ok ? t : tmax;
+        best = ok ? i : best;
+    }
+    for (int i = 0; i < n_sph; ++i) {
+        float t;
+        const bool ok = sph_hit(S->sph[i].c, o, d, tmax, t);
+        tmax = ok ? t : tmax;
+        best = ok ? n_par + i : best;
+    }
+    for (int i = 0; i < n_gen; ++i) {
+        float t;
+        if (full_shape_hit(S->full[S->gen[i].full], o, d, tmax, t)) {
             tmax = t;
-            best = i;
+            best = n_par + n_sph + i;
         }
     }
     return best;
@@ -301,12 +352,11 @@ KY_DEV int trace_nearest(const DScene* __restrict__ S, f3 o, f3 d, float& tmax) 
 // scene_t::occluded's traversal (3193-3195): any hit inside (eps, tmax) occludes.
 KY_DEV bool trace_any(const DScene* __restrict__ S, f3 o, f3 d, float tmax) {
     bool occ = false;
-    const int n = S->n_surfaces;
-    for (int i = 0; i < n; ++i) {
-        float t;
-        occ = occ || surf_hit(S->surf[i], S->full, o, d, tmax, t);
-        if (__all(occ)) break;
-    }
+    const int n_par = S->n_par, n_sph = S->n_sph, n_gen = S->n_gen;
+    float t;
+    for (int i = 0; i < n_par; ++i) occ = occ | par_hit(S->par[i].q0, S->par[i].q1, S->par[i].q2, o, d, tmax, t);
+    for (int i = 0; i < n_sph; ++i) occ = occ | sph_hit(S->sph[i].c, o, d, tmax, t);
+    for (int i = 0; i < n_gen; ++i) occ = occ || full_shape_hit(S->full[S->gen[i].full], o, d, tmax, t);
     return occ;
 }
 
@@ -687,6 +737,7 @@ KY_DEV f3 estimate_by_bsdf(const DScene* __restrict__ S, const LdsScene& Lds, co
     if (!dead) {
         const f3 o = offset_ray_origin(v.position, v.normal, bs.wi);  // isect.spawn_ray, 665-668
         float t = K_INF;
+        KY_PROBE(2);
         const int hs = trace_nearest(S, o, bs.wi, t);
         f3 Li = mk3(0, 0, 0);
         if (hs >= 0) {
@@ -715,6 +766,7 @@ template <bool MIS>
 KY_DEV f3 estimate_by_emitter(const DScene* __restrict__ S, const LdsScene& Lds, const Vertex& v, int li, float u0, float u1) {
     const DLight& L = S->light[li];
     f3 Ld = mk3(0, 0, 0);
+    KY_PROBE(3);
     const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1);
     const bool dead = is_black(ls.Li) || (MIS ? (ls.pdf <= 0) : (ls.pdf == 0));
     if (!dead) {
@@ -725,8 +777,10 @@ KY_DEV f3 estimate_by_emitter(const DScene* __restrict__ S, const LdsScene& Lds,
         const f3 dir = to * inv_d;
         const float dist = d2 * inv_d;
         const f3 o = offset_ray_origin(v.position, v.normal, dir);
+        KY_PROBE(4);
         const bool occ = trace_any(S, o, dir, dist - 2e-3f);
         if (!occ) {
+            KY_PROBE(5);
             f3 f;
             float bsdf_pdf;
             bsdf_eval_pdf(v.bsdf, to_local(v.frame, v.wo), to_local(v.frame, ls.wi), f, bsdf_pdf);
@@ -809,6 +863,7 @@ KY_DEV void path_begin(PathState& ps, const DScene* __restrict__ S, const Render
 template <bool DEBUG_SAMPLER>
 KY_DEV bool path_step(PathState& ps, const DScene* __restrict__ S, const LdsScene& Lds, const RenderConst& rc) {
     float t = K_INF;
+    KY_PROBE(0);
     const int hs = trace_nearest(S, ps.o, ps.d, t);  // scene->intersect, 4542
     const bool hit = hs >= 0;
 
@@ -850,7 +905,9 @@ KY_DEV bool path_step(PathState& ps, const DScene* __restrict__ S, const LdsScen
     }
 
     const bool delta = bsdf_is_delta(v.bsdf);
+    KY_PROBE(6);
     if (!delta) {  // 4571-4576
+        KY_PROBE(1);
         const f3 Ld = sample_all_light<DEBUG_SAMPLER>(S, Lds, v, ps.smp, rc.strategy);
         ps.Lo = ps.Lo + ps.beta * Ld;
     }
@@ -859,6 +916,7 @@ KY_DEV bool path_step(PathState& ps, const DScene* __restrict__ S, const LdsScen
     // sample BSDF to get the new path direction, 4586
     const float u0 = sampler_at<DEBUG_SAMPLER>(ps.smp, ps.smp.dim), u1 = sampler_at<DEBUG_SAMPLER>(ps.smp, ps.smp.dim + 1);
     ps.smp.dim += 2;
+    KY_PROBE(7);
     BsdfSample bs = bsdf_sample_local(v.bsdf, to_local(v.frame, v.wo), u0, u1);
     bs.wi = to_world(v.frame, bs.wi);
     if (is_black(bs.f) || bs.pdf == 0.f) return false;  // 4588

@@ -320,7 +320,7 @@ __global__ void kat_scene_intersect_kernel(const DScene* __restrict__ S, const f
     if (hs >= 0) { p = o + t * d; nn = hit_normal(Lds.hit[hs], p, d); }
     float* q = out9 + 9 * (size_t)i;
     q[0] = hs >= 0 ? 1.f : 0.f; q[1] = hs >= 0 ? t : 0.f;
-    q[2] = p.x; q[3] = p.y; q[4] = p.z; q[5] = nn.x; q[6] = nn.y; q[7] = nn.z; q[8] = (float)hs;
+    q[2] = p.x; q[3] = p.y; q[4] = p.z; q[5] = nn.x; q[6] = nn.y; q[7] = nn.z; q[8] = hs >= 0 ? (float)S->orig[hs] : -1.f;
 }
 
 __global__ void kat_occluded_kernel(const DScene* __restrict__ S, const float* __restrict__ in9, int n, float* __restrict__ out1) {
@@ -439,6 +439,9 @@ static int pack_scene(const ky_scene* in, DScene* out) {
     cp3(out->cam_position, in->camera.position); cp3(out->cam_front, in->camera.front); cp3(out->cam_right, in->camera.right);
     cp3(out->cam_up, in->camera.up);
     out->cam_inv_w = 1.f / in->camera.resolution[0]; out->cam_inv_h = 1.f / in->camera.resolution[1];
+    // validate, build the traversal record of every surface, then lay the surfaces out sorted by traversal kind
+    std::vector<DSurf> recs(in->surface_count);
+    std::vector<DShapeFull> fulls(in->surface_count);
     for (int i = 0; i < in->surface_count; ++i) {
         const ky_surface& sf = in->surfaces[i];
         if (sf.shape < 0 || sf.shape >= in->shape_count || sf.material < 0 || sf.material >= in->material_count || sf.area_light < -1 ||
@@ -448,10 +451,32 @@ static int pack_scene(const ky_scene* in, DScene* out) {
         if (sh.kind < KY_SHAPE_DISK || sh.kind > KY_SHAPE_SPHERE) return fail(KY_ERR_INVALID_VALUE, "shape %d has an unknown kind", sf.shape);
         if (sf.area_light >= 0 && in->lights[sf.area_light].kind != KY_LIGHT_AREA)
             return fail(KY_ERR_INVALID_VALUE, "surface %d: area_light must refer to an area light", i);
-        pack_shape(sh, i, &out->surf[i], &out->full[i]);
-        DHit& h = out->hit[i];
-        cp3(h.n, sh.kind == KY_SHAPE_SPHERE ? sh.p[0] : sh.normal);
-        h.kind = sh.kind; h.material = sf.material; h.area_light = sf.area_light;
+        pack_shape(sh, 0, &recs[i], &fulls[i]);
+    }
+    int j = 0;
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int i = 0; i < in->surface_count; ++i) {
+            const int group = recs[i].kind == TK_PARALLELOGRAM ? 0 : (recs[i].kind == TK_SPHERE ? 1 : 2);
+            if (group != pass) continue;
+            const ky_surface& sf = in->surfaces[i];
+            const ky_shape& sh = in->shapes[sf.shape];
+            if (pass == 0) {
+                DPar& d = out->par[out->n_par++];
+                std::memcpy(d.q0, &recs[i].f[0], 16); std::memcpy(d.q1, &recs[i].f[4], 16); std::memcpy(d.q2, &recs[i].f[8], 16);
+            } else if (pass == 1) {
+                std::memcpy(out->sph[out->n_sph++].c, &recs[i].f[0], 16);
+            } else {
+                DSurf& d = out->gen[out->n_gen++];
+                d = recs[i];
+                d.full = j;
+            }
+            out->full[j] = fulls[i];
+            DHit& h = out->hit[j];
+            cp3(h.n, sh.kind == KY_SHAPE_SPHERE ? sh.p[0] : sh.normal);
+            h.kind = sh.kind; h.material = sf.material; h.area_light = sf.area_light;
+            out->orig[j] = i;
+            ++j;
+        }
     }
     for (int i = 0; i < in->material_count; ++i) {
         const ky_material& m = in->materials[i];
@@ -568,6 +593,16 @@ static int kat_run(int device, const void* in, size_t in_bytes, void* out, size_
 
 
 extern "C" {
+
+#ifdef KY_PROFILE_LANES
+// debug builds only: reads and clears the lane-utilisation probes (32 x u64)
+int kyhip_debug_lane_probe(unsigned long long* out32) {
+    unsigned long long zero[32] = {0};
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_lane_probe), sizeof zero) != hipSuccess) return KY_ERR_DEVICE;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_lane_probe), zero, sizeof zero) != hipSuccess) return KY_ERR_DEVICE;
+    return KY_OK;
+}
+#endif
 
 const char* kyhip_last_error(void) { return g_error.c_str(); }
 int kyhip_abi_version(void) { return KYHIP_ABI_VERSION; }

@@ -153,10 +153,10 @@ struct DLight {  // light_t + the shape an area light samples; wave-uniform inde
 };
 
 struct DPar {  // planar parallelogram, 48 B: q0 = (n, n.p0), q1 = (a*, a*.p1 + 0.5), q2 = (b*, b*.p1 + 0.5)
-    float q0[4], q1[4], q2[4];
+    float4 q0, q1, q2;
 };
 struct DSph {  // sphere, 16 B: centre, radius^2
-    float c[4];
+    float4 c;
 };
 
 // The surfaces are stored SORTED BY TRAVERSAL KIND -- parallelograms, then spheres, then everything else -- keeping the
@@ -171,8 +171,8 @@ struct DScene {
     float cam_front[3], cam_inv_h;
     float cam_right[3], pad0;
     float cam_up[3], pad1;
-    DPar par[KYHIP_MAX_SURFACES];
-    DSph sph[KYHIP_MAX_SURFACES];
+    DPar par[KYHIP_MAX_SURFACES + 1];   // one readable record past the end: the traversal prefetches i + 1
+    DSph sph[KYHIP_MAX_SURFACES + 1];
     DSurf gen[KYHIP_MAX_SURFACES];
     DShapeFull full[KYHIP_MAX_SURFACES + KYHIP_MAX_LIGHTS];
     DHit hit[KYHIP_MAX_SURFACES];
@@ -292,22 +292,22 @@ KY_DEV bool full_shape_hit(const DShapeFull& S, f3 o, f3 d, float tmax, float& t
 
 // rectangle_t::intersect (1261-1297) for a planar parallelogram: plane hit, then dual-basis coordinates of the hit
 // point; |u - 0.5| <= 0.5 and |v - 0.5| <= 0.5 is "inside".  A zero denominator gives inf / NaN, which compare false.
-KY_DEV bool par_hit(const float* q0, const float* q1, const float* q2, f3 o, f3 d, float tmax, float& t_out) {
-    const float den = q0[0] * d.x + q0[1] * d.y + q0[2] * d.z;
-    const float num = q0[3] - (q0[0] * o.x + q0[1] * o.y + q0[2] * o.z);   // n.(p0 - o)
+KY_DEV bool par_hit(const float4 q0, const float4 q1, const float4 q2, f3 o, f3 d, float tmax, float& t_out) {
+    const float den = q0.x * d.x + q0.y * d.y + q0.z * d.z;
+    const float num = q0.w - (q0.x * o.x + q0.y * o.y + q0.z * o.z);   // n.(p0 - o)
     const float t = num * rcp(den);
     const f3 h = o + t * d;
-    const float u = (h.x * q1[0] + h.y * q1[1] + h.z * q1[2]) - q1[3];
-    const float v = (h.x * q2[0] + h.y * q2[1] + h.z * q2[2]) - q2[3];
+    const float u = (h.x * q1.x + h.y * q1.y + h.z * q1.z) - q1.w;
+    const float v = (h.x * q2.x + h.y * q2.y + h.z * q2.z) - q2.w;
     t_out = t;
     return (fabsf(u) <= 0.5f) & (fabsf(v) <= 0.5f) & (t > K_SHAPE_EPS) & (t < tmax);
 }
 
 // sphere_t::intersect, 1336-1393.  sqrt of a negative discriminant is NaN, which fails both range tests.
-KY_DEV bool sph_hit(const float* c, f3 o, f3 d, float tmax, float& t_out) {
-    const f3 oc = mk3(c[0], c[1], c[2]) - o;
+KY_DEV bool sph_hit(const float4 c, f3 o, f3 d, float tmax, float& t_out) {
+    const f3 oc = mk3(c.x, c.y, c.z) - o;
     const float neg_b = dot(oc, d);
-    const float discr = neg_b * neg_b - dot(oc, oc) + c[3];
+    const float discr = neg_b * neg_b - dot(oc, oc) + c.w;
     const float sq = fsqrt(discr);
     const float t0 = neg_b - sq, t1 = neg_b + sq;
     const bool h0 = (t0 > K_SHAPE_EPS) & (t0 < tmax);
@@ -318,26 +318,39 @@ KY_DEV bool sph_hit(const float* c, f3 o, f3 d, float tmax, float& t_out) {
 
 // one shape given as a generic record (KAT entry point, light shapes re-intersected by pdf_direction)
 KY_DEV bool surf_hit(const DSurf& S, const DShapeFull* __restrict__ full, f3 o, f3 d, float tmax, float& t_out) {
-    if (S.kind == TK_PARALLELOGRAM) return par_hit(&S.f[0], &S.f[4], &S.f[8], o, d, tmax, t_out);
-    if (S.kind == TK_SPHERE) return sph_hit(&S.f[0], o, d, tmax, t_out);
+    if (S.kind == TK_PARALLELOGRAM)
+        return par_hit(make_float4(S.f[0], S.f[1], S.f[2], S.f[3]), make_float4(S.f[4], S.f[5], S.f[6], S.f[7]), make_float4(S.f[8], S.f[9], S.f[10], S.f[11]), o, d, tmax, t_out);
+    if (S.kind == TK_SPHERE) return sph_hit(make_float4(S.f[0], S.f[1], S.f[2], S.f[3]), o, d, tmax, t_out);
     return full_shape_hit(full[S.full], o, d, tmax, t_out);
 }
 
 // scene_t::intersect, ky.cpp:3172-3184: linear scan, tmax shrinks, first of equals wins.  Returns the SORTED surface index.
+// The record of surface i+1 is fetched (scalar loads) while surface i is being tested, so the scalar-cache latency
+// overlaps the VALU work instead of being exposed once per surface.
 KY_DEV int trace_nearest(const DScene* __restrict__ S, f3 o, f3 d, float& tmax) {
     int best = -1;
     const int n_par = S->n_par, n_sph = S->n_sph, n_gen = S->n_gen;
-    for (int i = 0; i < n_par; ++i) {
-        float t;
-        const bool ok = par_hit(S->par[i].q0, S->par[i].q1, S->par[i].q2, o, d, tmax, t);
-        tmax = ok ? t : tmax;
-        best = ok ? i : best;
+    if (n_par > 0) {
+        float4 q0 = S->par[0].q0, q1 = S->par[0].q1, q2 = S->par[0].q2;
+        for (int i = 0; i < n_par; ++i) {
+            const float4 n0 = S->par[i + 1].q0, n1 = S->par[i + 1].q1, n2 = S->par[i + 1].q2;   // record n_par exists (padding)
+            float t;
+            const bool ok = par_hit(q0, q1, q2, o, d, tmax, t);
+            tmax = ok ? t : tmax;
+            best = ok ? i : best;
+            q0 = n0; q1 = n1; q2 = n2;
+        }
     }
-    for (int i = 0; i < n_sph; ++i) {
-        float t;
-        const bool ok = sph_hit(S->sph[i].c, o, d, tmax, t);
-        tmax = ok ? t : tmax;
-        best = ok ? n_par + i : best;
+    if (n_sph > 0) {
+        float4 c = S->sph[0].c;
+        for (int i = 0; i < n_sph; ++i) {
+            const float4 nc = S->sph[i + 1].c;
+            float t;
+            const bool ok = sph_hit(c, o, d, tmax, t);
+            tmax = ok ? t : tmax;
+            best = ok ? n_par + i : best;
+            c = nc;
+        }
     }
     for (int i = 0; i < n_gen; ++i) {
         float t;
@@ -354,8 +367,22 @@ KY_DEV bool trace_any(const DScene* __restrict__ S, f3 o, f3 d, float tmax) {
     bool occ = false;
     const int n_par = S->n_par, n_sph = S->n_sph, n_gen = S->n_gen;
     float t;
-    for (int i = 0; i < n_par; ++i) occ = occ | par_hit(S->par[i].q0, S->par[i].q1, S->par[i].q2, o, d, tmax, t);
-    for (int i = 0; i < n_sph; ++i) occ = occ | sph_hit(S->sph[i].c, o, d, tmax, t);
+    if (n_par > 0) {
+        float4 q0 = S->par[0].q0, q1 = S->par[0].q1, q2 = S->par[0].q2;
+        for (int i = 0; i < n_par; ++i) {
+            const float4 n0 = S->par[i + 1].q0, n1 = S->par[i + 1].q1, n2 = S->par[i + 1].q2;
+            occ = occ | par_hit(q0, q1, q2, o, d, tmax, t);
+            q0 = n0; q1 = n1; q2 = n2;
+        }
+    }
+    if (n_sph > 0) {
+        float4 c = S->sph[0].c;
+        for (int i = 0; i < n_sph; ++i) {
+            const float4 nc = S->sph[i + 1].c;
+            occ = occ | sph_hit(c, o, d, tmax, t);
+            c = nc;
+        }
+    }
     for (int i = 0; i < n_gen; ++i) occ = occ || full_shape_hit(S->full[S->gen[i].full], o, d, tmax, t);
     return occ;
 }

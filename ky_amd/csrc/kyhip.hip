@@ -462,9 +462,11 @@ static int pack_scene(const ky_scene* in, DScene* out) {
             const ky_shape& sh = in->shapes[sf.shape];
             if (pass == 0) {
                 DPar& d = out->par[out->n_par++];
-                std::memcpy(d.q0, &recs[i].f[0], 16); std::memcpy(d.q1, &recs[i].f[4], 16); std::memcpy(d.q2, &recs[i].f[8], 16);
+                std::memcpy(&d.q0, &recs[i].f[0], 16); std::memcpy(&d.q1, &recs[i].f[4], 16); std::memcpy(&d.q2, &recs[i].f[8], 16);
+                out->par[out->n_par] = d;   // readable padding record for the prefetch of i + 1
             } else if (pass == 1) {
-                std::memcpy(out->sph[out->n_sph++].c, &recs[i].f[0], 16);
+                std::memcpy(&out->sph[out->n_sph++].c, &recs[i].f[0], 16);
+                out->sph[out->n_sph] = out->sph[out->n_sph - 1];
             } else {
                 DSurf& d = out->gen[out->n_gen++];
                 d = recs[i];

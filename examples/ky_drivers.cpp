@@ -1,0 +1,130 @@
+/*
+ * ky_drivers.cpp -- the reference's experiment drivers (ky.cpp:4675-4949) written against ky_amd/host/ky.hpp,
+ * i.e. the same call shape `integrator->render(&scene, sampler.get(), &film); film.next_subfilm();` with the
+ * rendering done by the MI355X library.  Workload definitions only: spp, grids and scene flags are the reference's.
+ *
+ *   ky_drivers single [spp4]     render_single_scene       (4675): 1024x1024 Cornell + environment light
+ *   ky_drivers debug             render_debug              (4715): Veach position / normal / basecolor, 1x3 grid
+ *   ky_drivers direct_sample     render_direct_sample_enum (4779): 4 Cornell lights x 5 strategies, 4x5 grid
+ *   ky_drivers multiple_scene    render_multiple_scene     (4819): 3 strategies x 4 Cornell lights, 3x4 grid
+ *   ky_drivers mis               render_mis_scene          (4878): Veach x 6 strategies, 2x3 grid
+ * An optional last argument multiplies every spp (the reference's values are tiny because its CPU path is slow).
+ */
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <utility>
+#include <vector>
+
+#include "../ky_amd/host/ky.hpp"
+
+using namespace ky;
+
+static int g_spp_scale = 1;
+
+template <typename F>
+static double timing_seconds(F f) {  // wall clock (the reference's clock() counts CPU time on Linux, ky.cpp:156-163)
+    const auto t0 = std::chrono::steady_clock::now();
+    f();
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+static void render_single_scene(int spp4) {
+    const int width = 1024, height = 1024;
+    film_t film(width, height);
+    scene_t scene = scene_t::create_cornell_box_scene(cornell_box_enum_t::both_small_spheres | cornell_box_enum_t::light_environment, film.get_resolution());
+    const int samples_per_pixel = (spp4 > 0 ? spp4 / 4 : 16) * g_spp_scale;
+    std::unique_ptr<sampler_t> sampler = std::make_unique<random_sampler_t>(samples_per_pixel);
+    auto integrator = create_integrator(integrator_enum_t::path_tracing_iteration, 5, direct_sample_enum_t::both_mis);
+    const double seconds = timing_seconds([&] { integrator->render(&scene, sampler.get(), &film); });
+    std::printf("%d spp, %.3f seconds (kernel %.3f ms), %.1f Msamples/s\n", samples_per_pixel, seconds, integrator->last_kernel_ms(),
+                (double)width * height * samples_per_pixel / seconds / 1e6);
+    film.store_image("single");
+}
+
+static void render_debug() {
+    film_grid_t film(1, 3, 512, 308);
+    std::unique_ptr<sampler_t> sampler = std::make_unique<random_sampler_t>(10 * g_spp_scale);
+    scene_t scene = scene_t::create_mis_scene(film.get_resolution());
+    for (auto e : {integrator_enum_t::position, integrator_enum_t::normal, integrator_enum_t::basecolor}) {
+        std::unique_ptr<integrator_t> integrator = std::make_unique<debug_integrator_t>(e);
+        integrator->render(&scene, sampler.get(), &film);
+        film.next_subfilm();
+    }
+    film.store_image("render_debug");
+}
+
+static const std::vector<std::pair<cornell_box_enum_t, int>>& scene_params(bool multiple_scene) {
+    static const std::vector<std::pair<cornell_box_enum_t, int>> a{{cornell_box_enum_t::light_point, 1}, {cornell_box_enum_t::light_direction, 10},
+                                                                   {cornell_box_enum_t::light_area, 1}, {cornell_box_enum_t::light_environment, 10}};
+    static const std::vector<std::pair<cornell_box_enum_t, int>> b{{cornell_box_enum_t::light_point, 10}, {cornell_box_enum_t::light_direction, 40},
+                                                                   {cornell_box_enum_t::light_area, 40}, {cornell_box_enum_t::light_environment, 10}};
+    return multiple_scene ? b : a;
+}
+
+static void render_direct_sample_enum() {
+    const std::vector<direct_sample_enum_t> sample_enums{direct_sample_enum_t::bsdf, direct_sample_enum_t::light, direct_sample_enum_t::bsdf_mis,
+                                                        direct_sample_enum_t::light_mis, direct_sample_enum_t::both_mis};
+    film_grid_t film(4, 5, 256, 256);
+    for (auto [scene_enum, spp] : scene_params(false)) {
+        std::unique_ptr<sampler_t> sampler = std::make_unique<random_sampler_t>(spp * g_spp_scale);
+        scene_t scene = scene_t::create_cornell_box_scene(cornell_box_enum_t::both_small_spheres | scene_enum, film.get_resolution());
+        for (auto sample_enum : sample_enums) {
+            std::unique_ptr<integrator_t> integrator = std::make_unique<path_tracing_iteration_t>(5, sample_enum);
+            integrator->render(&scene, sampler.get(), &film);
+            film.next_subfilm();
+        }
+    }
+    film.store_image("direct_sample");
+}
+
+static void render_multiple_scene() {
+    const std::vector<direct_sample_enum_t> sample_enums{direct_sample_enum_t::bsdf, direct_sample_enum_t::light, direct_sample_enum_t::both_mis};
+    film_grid_t film(3, 4, 256, 256);
+    for (auto sample_enum : sample_enums) {
+        std::unique_ptr<integrator_t> integrator = std::make_unique<path_tracing_iteration_t>(5, sample_enum);
+        for (auto [scene_enum, spp] : scene_params(true)) {
+            std::unique_ptr<sampler_t> sampler = std::make_unique<random_sampler_t>(spp * g_spp_scale);
+            scene_t scene = scene_t::create_cornell_box_scene(cornell_box_enum_t::both_small_spheres | scene_enum, film.get_resolution());
+            integrator->render(&scene, sampler.get(), &film);
+            film.next_subfilm();
+        }
+    }
+    film.store_image("light_mis");
+}
+
+static void render_mis_scene() {
+    film_grid_t film(2, 3, 512, 308);
+    std::unique_ptr<sampler_t> sampler = std::make_unique<random_sampler_t>(10 * g_spp_scale);
+    scene_t scene = scene_t::create_mis_scene(film.get_resolution());
+    for (auto sample_enum : {direct_sample_enum_t::bsdf, direct_sample_enum_t::light, direct_sample_enum_t::idle, direct_sample_enum_t::bsdf_mis,
+                             direct_sample_enum_t::light_mis, direct_sample_enum_t::both_mis}) {
+        std::unique_ptr<integrator_t> integrator = std::make_unique<path_tracing_iteration_t>(5, sample_enum);
+        integrator->render(&scene, sampler.get(), &film);
+        film.next_subfilm();
+    }
+    film.store_image("veach_mis");
+}
+
+int main(int argc, char* argv[]) {
+    const char* which = argc > 1 ? argv[1] : "single";
+    try {
+        if (!std::strcmp(which, "single")) {
+            if (argc > 3) g_spp_scale = std::atoi(argv[3]);
+            render_single_scene(argc > 2 ? std::atoi(argv[2]) : 0);
+        } else {
+            if (argc > 2) g_spp_scale = std::atoi(argv[2]);
+            if (g_spp_scale < 1) g_spp_scale = 1;
+            if (!std::strcmp(which, "debug")) render_debug();
+            else if (!std::strcmp(which, "direct_sample")) render_direct_sample_enum();
+            else if (!std::strcmp(which, "multiple_scene")) render_multiple_scene();
+            else if (!std::strcmp(which, "mis")) render_mis_scene();
+            else { std::fprintf(stderr, "unknown driver '%s'\n", which); return 2; }
+        }
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

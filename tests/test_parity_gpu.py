@@ -312,3 +312,25 @@ def test_full_size_properties(A, api):
     # a different seed gives a different but statistically equal image
     d = api.render(scene, api.make_params(1024, 768, 32, seed=99))
     assert not np.array_equal(a, d) and abs(a.mean() - d.mean()) < 2e-3
+
+
+def test_cpp_driver_matches_the_c_abi_path(A, api, tmp_path):
+    """examples/ky_drivers.cpp `mis` = the reference's render_mis_scene (ky.cpp:4878-4905) written against the C++ host
+    mirror, linked against the system HIP runtime.  Its BMP must equal, byte for byte, the mosaic built through the
+    Python/ctypes path (same kernels, same seeds)."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "bin", "ky_drivers")
+    if not os.path.exists(exe):
+        pytest.skip("examples not built")
+    subprocess.check_call([exe, "mis"], cwd=tmp_path, stdout=subprocess.DEVNULL)
+    got = open(tmp_path / "veach_mis.bmp", "rb").read()
+    scene = api.mis_scene(512, 308)
+    grid = np.zeros((2 * 308, 3 * 512, 3), np.float32)
+    for cell, strat in enumerate((4, 8, 0, 16, 32, 48)):
+        p = api.make_params(512, 308, 10, direct_sample=strat)
+        api.render(scene, p, film=grid, origin_px=((cell % 3) * 512, (cell // 3) * 308))
+    api.store_image(str(tmp_path / "py.bmp"), grid, "bmp")
+    want = open(tmp_path / "py.bmp", "rb").read()
+    assert len(got) == len(want) == 54 + 3 * 512 * 2 * 308 * 3
+    assert got == want

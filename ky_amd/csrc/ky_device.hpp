@@ -208,7 +208,7 @@ KY_DEV void stage_scene(LdsScene& L, const DScene* __restrict__ S) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// random numbers: counter-based, keyed (seed, pixel, sample, dimension) -- DESIGN.md
+// random numbers: one PCG stream per camera sample, keyed (seed, pixel, sample) -- DESIGN.md
 // sampler_t semantics of ky.cpp:877-975
 // ---------------------------------------------------------------------------------------------
 KY_DEV uint32_t mix32(uint32_t x) {
@@ -217,22 +217,22 @@ KY_DEV uint32_t mix32(uint32_t x) {
     x ^= x >> 15;
     return x;
 }
-constexpr uint32_t KY_DIM_LOBE = 0xFFFF0000u;
-
 struct Sampler {
-    uint32_t k0, k1, dim;
+    uint32_t state, inc;
 };
+// the 64-bit key hashed from (seed, pixel, sample) seeds a PCG-RXS-M-XS-32 stream: state = k0, increment = k1 | 1
 KY_DEV void sampler_start(Sampler& s, uint32_t seed, uint32_t pixel_index, uint32_t sample_index) {
     const uint32_t h = mix32(pixel_index ^ mix32(seed));
-    s.k0 = mix32(h + sample_index * 0x9E3779B9u);
-    s.k1 = mix32((h ^ 0x6A09E667u) + sample_index * 0x85EBCA6Bu);
-    s.dim = 0;
+    s.state = mix32(h + sample_index * 0x9E3779B9u);
+    s.inc = mix32((h ^ 0x6A09E667u) + sample_index * 0x85EBCA6Bu) | 1u;
 }
 template <bool DEBUG_SAMPLER>
-KY_DEV float sampler_at(const Sampler& s, uint32_t d) {
+KY_DEV float sampler_next(Sampler& s) {
     if (DEBUG_SAMPLER) return 0.5f;  // debug_sampler_t, 933-941
-    const uint32_t x = mix32(s.k0 ^ mix32(s.k1 + d));
-    return (float)(x >> 8) * (1.0f / 16777216.0f);
+    s.state = s.state * 747796405u + s.inc;
+    uint32_t word = ((s.state >> ((s.state >> 28u) + 4u)) ^ s.state) * 277803737u;
+    word = (word >> 22u) ^ word;
+    return (float)(word >> 8) * (1.0f / 16777216.0f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -828,24 +828,23 @@ KY_DEV f3 sample_all_light(const DScene* __restrict__ S, const LdsScene& Lds, co
     f3 Ld = mk3(0, 0, 0);
     const int nl = S->n_lights;
     for (int li = 0; li < nl; ++li) {
-        // the reference's GCC build draws random_bsdf first, then random_light (3866-3868)
-        const uint32_t d0 = smp.dim;
-        smp.dim += 4;
+        // the reference's GCC build draws random_bsdf first, then random_light (3866-3868), for every light and strategy
+        const float ub0 = sampler_next<DEBUG_SAMPLER>(smp), ub1 = sampler_next<DEBUG_SAMPLER>(smp);
+        const float ul0 = sampler_next<DEBUG_SAMPLER>(smp), ul1 = sampler_next<DEBUG_SAMPLER>(smp);
         if (strategy == KY_DIRECT_BOTH_MIS) {  // 4076-4088
-            const f3 Lb = estimate_by_bsdf<true>(S, Lds, v, li, sampler_at<DEBUG_SAMPLER>(smp, d0), sampler_at<DEBUG_SAMPLER>(smp, d0 + 1));
-            const f3 Ll = estimate_by_emitter<true>(S, Lds, v, li, sampler_at<DEBUG_SAMPLER>(smp, d0 + 2), sampler_at<DEBUG_SAMPLER>(smp, d0 + 3));
+            const f3 Lb = estimate_by_bsdf<true>(S, Lds, v, li, ub0, ub1);
+            const f3 Ll = estimate_by_emitter<true>(S, Lds, v, li, ul0, ul1);
             Ld = Ld + (0.5f * Lb + 0.5f * Ll);
         } else if (strategy == KY_DIRECT_BSDF_MIS) {
-            Ld = Ld + estimate_by_bsdf<true>(S, Lds, v, li, sampler_at<DEBUG_SAMPLER>(smp, d0), sampler_at<DEBUG_SAMPLER>(smp, d0 + 1));
+            Ld = Ld + estimate_by_bsdf<true>(S, Lds, v, li, ub0, ub1);
         } else if (strategy == KY_DIRECT_LIGHT_MIS) {
-            Ld = Ld + estimate_by_emitter<true>(S, Lds, v, li, sampler_at<DEBUG_SAMPLER>(smp, d0 + 2), sampler_at<DEBUG_SAMPLER>(smp, d0 + 3));
+            Ld = Ld + estimate_by_emitter<true>(S, Lds, v, li, ul0, ul1);
         } else if (strategy == KY_DIRECT_LIGHT) {
-            Ld = Ld + estimate_by_emitter<false>(S, Lds, v, li, sampler_at<DEBUG_SAMPLER>(smp, d0 + 2), sampler_at<DEBUG_SAMPLER>(smp, d0 + 3));
+            Ld = Ld + estimate_by_emitter<false>(S, Lds, v, li, ul0, ul1);
         } else if (strategy == KY_DIRECT_BSDF) {
             const int lk = S->light[li].kind;
             if (!(lk == KY_LIGHT_POINT || lk == KY_LIGHT_DIRECTION)) {  // the third float2 is drawn after the delta test (3894-3900)
-                const float u0 = sampler_at<DEBUG_SAMPLER>(smp, smp.dim), u1 = sampler_at<DEBUG_SAMPLER>(smp, smp.dim + 1);
-                smp.dim += 2;
+                const float u0 = sampler_next<DEBUG_SAMPLER>(smp), u1 = sampler_next<DEBUG_SAMPLER>(smp);
                 Ld = Ld + estimate_by_bsdf<false>(S, Lds, v, li, u0, u1);
             }
         }
@@ -878,8 +877,7 @@ template <bool DEBUG_SAMPLER>
 KY_DEV void path_begin(PathState& ps, const DScene* __restrict__ S, const RenderConst& rc, int x, int y, int sample) {
     sampler_start(ps.smp, rc.seed, (uint32_t)(y * rc.width + x), (uint32_t)sample);
     // get_camera_sample, 943-946 / 971-974
-    const float u0 = sampler_at<DEBUG_SAMPLER>(ps.smp, 0), u1 = sampler_at<DEBUG_SAMPLER>(ps.smp, 1);
-    ps.smp.dim = 2;
+    const float u0 = sampler_next<DEBUG_SAMPLER>(ps.smp), u1 = sampler_next<DEBUG_SAMPLER>(ps.smp);
     generate_ray(S, (float)x + u0, (float)y + u1, ps.o, ps.d);
     ps.beta = mk3(1, 1, 1);
     ps.Lo = mk3(0, 0, 0);
@@ -917,7 +915,8 @@ KY_DEV bool path_step(PathState& ps, const DScene* __restrict__ S, const LdsScen
 
     // material->scattering(isect) for the nearest hit (3083); only plastic draws a lobe number (2663)
     const DMat& M = Lds.mat[Lds.hit[hs].material];
-    const float lobe_u = M.kind == KY_MATERIAL_PLASTIC ? sampler_at<DEBUG_SAMPLER>(ps.smp, KY_DIM_LOBE + (uint32_t)ps.bounces) : 0.f;
+    float lobe_u = 0.f;
+    if (M.kind == KY_MATERIAL_PLASTIC) lobe_u = sampler_next<DEBUG_SAMPLER>(ps.smp);
     v.bsdf = make_bsdf(M, lobe_u);
     v.frame = make_frame(v.normal);
 
@@ -941,8 +940,7 @@ KY_DEV bool path_step(PathState& ps, const DScene* __restrict__ S, const LdsScen
     if (rc.integrator == KY_INTEGRATOR_DIRECT_LIGHTING) return false;  // 4153
 
     // sample BSDF to get the new path direction, 4586
-    const float u0 = sampler_at<DEBUG_SAMPLER>(ps.smp, ps.smp.dim), u1 = sampler_at<DEBUG_SAMPLER>(ps.smp, ps.smp.dim + 1);
-    ps.smp.dim += 2;
+    const float u0 = sampler_next<DEBUG_SAMPLER>(ps.smp), u1 = sampler_next<DEBUG_SAMPLER>(ps.smp);
     KY_PROBE(7);
     BsdfSample bs = bsdf_sample_local(v.bsdf, to_local(v.frame, v.wo), u0, u1);
     bs.wi = to_world(v.frame, bs.wi);
@@ -954,8 +952,7 @@ KY_DEV bool path_step(PathState& ps, const DScene* __restrict__ S, const LdsScen
 
     if (ps.bounces > 3) {  // Russian roulette, 4601-4612
         const float q = fmaxf(0.05f, 1 - max3(ps.beta));
-        const float u = sampler_at<DEBUG_SAMPLER>(ps.smp, ps.smp.dim);
-        ps.smp.dim += 1;
+        const float u = sampler_next<DEBUG_SAMPLER>(ps.smp);
         if (u < q) return false;
         ps.beta = ps.beta * rcp(1 - q);
     }

@@ -33,8 +33,9 @@
  *     row (ky.cpp:833, 3701) plus a private, thread-racy generator inside plastic_material_t
  *     (ky.cpp:2663, 2681).  Neither stream is reproducible on a GPU, so this restatement (and the
  *     HIP path) use the counter-based generator documented in DESIGN.md keyed by
- *     (seed, pixel, sample, dimension); the ORDER in which dimensions are consumed is the
- *     reference's (SURVEY.md 8(a) "Random-number consumption order").
+ *     (seed, pixel, sample); the ORDER in which numbers are consumed is the reference's
+ *     (SURVEY.md 8(a) "Random-number consumption order"), with the plastic lobe number drawn from the
+ *     same stream when a path vertex lands on a plastic surface.
  *
  * Build: see oracle/Makefile (g++ -O2 -ffp-contract=off -fopenmp -shared).
  */
@@ -221,32 +222,30 @@ inline uint32_t mix32(uint32_t x) {  // "lowbias32" integer finaliser
     x ^= x >> 15;
     return x;
 }
-constexpr uint32_t KY_DIM_LOBE = 0xFFFF0000u;  // dimension block used for the plastic lobe pick
-
 struct sampler_t {
     int      kind = KY_SAMPLER_RANDOM;
-    uint32_t k0 = 0, k1 = 0, dim = 0;
-    // one camera sample = one key; sampler_t::start_pixel / next_sample (900-908) select it
+    uint32_t state = 0, inc = 1;
+    // one camera sample = one stream; sampler_t::start_pixel / next_sample (900-908) select it.
+    // The 64-bit key (k0, k1) hashed from (seed, pixel, sample) becomes the state and the (odd) increment of a
+    // PCG-RXS-M-XS-32 generator, so two samples share a stream only if both 32-bit halves collide.
     void start_sample(uint32_t seed, uint32_t pixel_index, uint32_t sample_index) {
         uint32_t h = mix32(pixel_index ^ mix32(seed));
-        k0  = mix32(h + sample_index * 0x9E3779B9u);
-        k1  = mix32((h ^ 0x6A09E667u) + sample_index * 0x85EBCA6Bu);
-        dim = 0;
+        state = mix32(h + sample_index * 0x9E3779B9u);
+        inc   = mix32((h ^ 0x6A09E667u) + sample_index * 0x85EBCA6Bu) | 1u;
     }
-    float at(uint32_t d) const {
+    float get_float() {                                                                   // 960
         if (kind == KY_SAMPLER_DEBUG) return 0.5f;                                        // 933-941
-        uint32_t x = mix32(k0 ^ mix32(k1 + d));
-        return (float)(x >> 8) * (1.0f / 16777216.0f);                                    // [0, 1)
+        state = state * 747796405u + inc;
+        uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+        word = (word >> 22u) ^ word;
+        return (float)(word >> 8) * (1.0f / 16777216.0f);                                 // [0, 1)
     }
-    float get_float() { return at(dim++); }                                               // 960
-    vec2_t get_float2() { float a = at(dim); float b = at(dim + 1); dim += 2; return {a, b}; }  // 965, 856-859
+    vec2_t get_float2() { float a = get_float(); float b = get_float(); return {a, b}; }  // 965, 856-859
     // get_camera_sample, 943-946 / 971-974
     vec2_t get_camera_sample(vec2_t p_film) {
         vec2_t u = get_float2();
         return {p_film.x + u.x, p_film.y + u.y};
     }
-    // the draw plastic_material_t::scattering makes from its private generator (2663), one per path vertex
-    float lobe(int bounce) const { return at(KY_DIM_LOBE + (uint32_t)bounce); }
 };
 
 // ============================================================================================
@@ -688,7 +687,9 @@ struct scene_t {
 
     // scene_t::intersect (3172-3184) + surface_t::intersect (3077-3088).
     // with_bsdf=false is used where the reference discards the BSDF (shadow rays, MIS light lookups).
-    bool intersect(const ray_t& ray, isect_t* isect, counters_t* c, float lobe_random = 0.f, bool with_bsdf = true) const {
+    // `sampler` non-null: build the BSDF of the nearest hit; plastic_material_t::scattering then draws its lobe number
+    // (2663) from the path's own stream.  Null where the reference discards the BSDF (shadow rays, MIS light lookups).
+    bool intersect(const ray_t& ray, isect_t* isect, counters_t* c, sampler_t* sampler = nullptr) const {
         bool is_hit = false;
         int surface_num = (int)surfaces.size();
         if (c) { c->traversals++; c->primitive_tests += surface_num; }
@@ -700,7 +701,10 @@ struct scene_t {
         }
         if (is_hit) {
             const ky_surface& s = surfaces[isect->surface];
-            if (with_bsdf) scattering(isect, lobe_random);
+            if (sampler) {
+                const bool plastic = materials[s.material].kind == KY_MATERIAL_PLASTIC;
+                scattering(isect, plastic ? sampler->get_float() : 0.f);
+            }
             isect->emission = s.area_light >= 0 ? areal_radiance(s.area_light, isect->normal, isect->wo) : color_t{};  // 3084
         }
         return is_hit;
@@ -711,7 +715,7 @@ struct scene_t {
         ray_t ray{offset_ray_origin(position, normal, direction), direction, dist - 2e-3f};
         isect_t unused;
         if (c) c->shadow_rays++;
-        bool occ = intersect(ray, &unused, c, 0.f, false);
+        bool occ = intersect(ray, &unused, c);
         if (c && occ) c->shadow_occluded++;
         return occ;
     }
@@ -810,7 +814,7 @@ struct integrator_t {
         ray_t ray = isect.spawn_ray(bs.wi);
         isect_t light_isect;
         if (c) c->mis_bsdf_rays++;
-        bool is_hit_light = scene->intersect(ray, &light_isect, c, 0.f, false);
+        bool is_hit_light = scene->intersect(ray, &light_isect, c);
         color_t Li{};
         if (is_hit_light) {
             if (scene->surfaces[light_isect.surface].area_light == li) Li = light_isect.emission;
@@ -843,7 +847,7 @@ struct integrator_t {
         ray_t ray = isect.spawn_ray(bs.wi);
         isect_t light_isect;
         if (c) c->mis_bsdf_rays++;
-        bool is_hit_light = scene->intersect(ray, &light_isect, c, 0.f, false);
+        bool is_hit_light = scene->intersect(ray, &light_isect, c);
         color_t Li{};
         if (is_hit_light) {
             if (scene->surfaces[light_isect.surface].area_light == li) Li = light_isect.emission;   // 3994
@@ -911,7 +915,7 @@ struct integrator_t {
         for (int bounces = 0;; ++bounces) {
             isect_t isect;
             if (c) c->path_iterations++;
-            bool hit = scene->intersect(ray, &isect, c, sampler.lobe(bounces));
+            bool hit = scene->intersect(ray, &isect, c, &sampler);
             if (bounces == 0 || is_prev_specular) {
                 if (hit) Lo += beta * isect.emission;
                 else Lo += beta * scene->environment_lighting();
@@ -947,7 +951,7 @@ struct integrator_t {
     // debug_integrator_t::Li, 4105-4122
     color_t Li_debug(ray_t ray, sampler_t& sampler, counters_t* c) const {
         isect_t isect;
-        if (scene->intersect(ray, &isect, c, sampler.lobe(0))) {
+        if (scene->intersect(ray, &isect, c, &sampler)) {
             switch (kind) {
             case KY_INTEGRATOR_POSITION: { vec3_t v = isect.position.normalize(); return {v.x, v.y, v.z}; }
             case KY_INTEGRATOR_NORMAL: { vec3_t v = isect.normal.normalize(); return {v.x, v.y, v.z}; }
@@ -960,7 +964,7 @@ struct integrator_t {
     // direct_lighting_t::Li, 4136-4154
     color_t Li_direct(ray_t ray, sampler_t& sampler, counters_t* c) const {
         isect_t isect;
-        bool hit = scene->intersect(ray, &isect, c, sampler.lobe(0));
+        bool hit = scene->intersect(ray, &isect, c, &sampler);
         if (!hit) return scene->environment_lighting();
         color_t Lo = isect.emission;
         if (!isect.bsdf.is_delta()) Lo += sample_all_light(isect, sampler, c);
@@ -1145,7 +1149,7 @@ int kyo_kat_scene_intersect(const ky_scene* cscene, const float* rays7, int n, f
         const float* r = rays7 + 7 * i;
         ray_t ray{vec3_t(r), vec3_t(r + 3), r[6]};
         isect_t isect;
-        bool hit = scene.intersect(ray, &isect, nullptr, 0.f, false);
+        bool hit = scene.intersect(ray, &isect, nullptr);
         float* o = out9 + 9 * i;
         o[0] = hit ? 1.f : 0.f; o[1] = hit ? ray.distance : 0.f;
         o[2] = isect.position.x; o[3] = isect.position.y; o[4] = isect.position.z;

@@ -885,14 +885,15 @@ KY_DEV void path_begin(PathState& ps, const DScene* __restrict__ S, const Render
     ps.prev_specular = false;
 }
 
+// First half of a path vertex: trace the current ray and account for what the hit (or miss) itself contributes.
+// Returns false when the path has ended (radiance complete in ps.Lo); true when `v` holds a vertex to shade.
 template <bool DEBUG_SAMPLER>
-KY_DEV bool path_step(PathState& ps, const DScene* __restrict__ S, const LdsScene& Lds, const RenderConst& rc) {
+KY_DEV bool path_intersect(PathState& ps, Vertex& v, const DScene* __restrict__ S, const LdsScene& Lds, const RenderConst& rc) {
     float t = K_INF;
     KY_PROBE(0);
     const int hs = trace_nearest(S, ps.o, ps.d, t);  // scene->intersect, 4542
     const bool hit = hs >= 0;
 
-    Vertex v;
     f3 emission = mk3(0, 0, 0);
     if (hit) {
         v.position = ps.o + t * ps.d;
@@ -912,9 +913,14 @@ KY_DEV bool path_step(PathState& ps, const DScene* __restrict__ S, const LdsScen
     } else if (!hit) {
         return false;  // debug integrators return black on a miss (4121)
     }
+    return true;
+}
 
+// Second half: material, direct lighting, continuation.  Returns false when the path has ended.
+template <bool DEBUG_SAMPLER>
+KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, const LdsScene& Lds, const RenderConst& rc) {
     // material->scattering(isect) for the nearest hit (3083); only plastic draws a lobe number (2663)
-    const DMat& M = Lds.mat[Lds.hit[hs].material];
+    const DMat& M = Lds.mat[Lds.hit[v.surface].material];
     float lobe_u = 0.f;
     if (M.kind == KY_MATERIAL_PLASTIC) lobe_u = sampler_next<DEBUG_SAMPLER>(ps.smp);
     v.bsdf = make_bsdf(M, lobe_u);
@@ -961,6 +967,13 @@ KY_DEV bool path_step(PathState& ps, const DScene* __restrict__ S, const LdsScen
     // when the previous bounce was not specular that last traversal cannot change Lo, so skip it.
     if (ps.bounces >= rc.max_path_depth && !ps.prev_specular) return false;
     return true;
+}
+
+template <bool DEBUG_SAMPLER>
+KY_DEV bool path_step(PathState& ps, const DScene* __restrict__ S, const LdsScene& Lds, const RenderConst& rc) {
+    Vertex v;
+    if (!path_intersect<DEBUG_SAMPLER>(ps, v, S, Lds, rc)) return false;
+    return path_shade<DEBUG_SAMPLER>(ps, v, S, Lds, rc);
 }
 
 }  // namespace kyd

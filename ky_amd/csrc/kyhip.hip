@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DSce
     __shared__ ItemSlot ring[4][KY_RING];
     stage_scene(Lds, S);
     if (STRATEGY >= 0) rc.strategy = STRATEGY;
+    const int nee_weight = (rc.strategy == KY_DIRECT_IDLE || rc.integrator < KY_INTEGRATOR_DIRECT_LIGHTING) ? 0 : S->n_lights;
 
     const int lane = threadIdx.x & 63;
     const int lx = lane & 7, ly = lane >> 3;
@@ -206,20 +207,42 @@ __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DSce
                 }  // else: the ring is full -- wait for the slowest lane
             }
         }
-        // ---- (2) regenerate: next camera sample of this lane's pixel (3712-3715) ----
-        if (!alive && !done && s < s_end) {
-            path_begin<DEBUG_SAMPLER>(ps, S, rc, x, y, s);
-            ++s;
-            alive = true;
+        // ---- (2) regenerate + trace until enough lanes hold a vertex ----
+        // A lane whose path ends at the traversal itself (a miss, the depth cap) would sit out the whole shading phase,
+        // which costs 2 traversals per light.  When many lanes are in that state, they regenerate and trace once more
+        // before the wave moves on (wave-uniform decision), so the expensive phase runs with fuller lanes.
+        Vertex v;
+        bool have_vertex = false;
+        for (int attempt = 0;; ++attempt) {
+            if (!alive && !done && s < s_end) {  // next camera sample of this lane's pixel, 3712-3715
+                path_begin<DEBUG_SAMPLER>(ps, S, rc, x, y, s);
+                ++s;
+                alive = true;
+            }
+            const bool tracing = alive && !have_vertex;
+            if (!__any(tracing)) break;
+            if (tracing) {
+                if (path_intersect<DEBUG_SAMPLER>(ps, v, S, Lds, rc)) {
+                    have_vertex = true;
+                } else {
+                    Lsum = Lsum + ps.Lo * rc.inv_spp;  // L = L + Li * (1. / spp), 3717-3721
+                    alive = false;
+                }
+            }
+            if (attempt >= 1) break;
+            // lanes that could start another path right now; worth one more traversal if they would otherwise idle
+            // through (2 traversals x lights + shading) that is worth more than the extra traversal
+            const int idle = __popcll(__ballot(!alive && !done && s < s_end));
+            if (idle * (2 * nee_weight + 1) < 40) break;
         }
         if (!__any(alive)) {
             if (__all(done)) break;
-            continue;
+            continue;  // lanes are between items: (1) serves them on the next turn
         }
-        // ---- (3) one path vertex ----
-        if (alive) {
-            if (!path_step<DEBUG_SAMPLER>(ps, S, Lds, rc)) {
-                Lsum = Lsum + ps.Lo * rc.inv_spp;  // L = L + Li * (1. / spp), 3717-3721
+        // ---- (3) shade the vertex: direct lighting, continuation ----
+        if (have_vertex) {
+            if (!path_shade<DEBUG_SAMPLER>(ps, v, S, Lds, rc)) {
+                Lsum = Lsum + ps.Lo * rc.inv_spp;
                 alive = false;
             }
         }

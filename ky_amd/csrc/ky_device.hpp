@@ -148,9 +148,12 @@ struct DLight {  // light_t + the shape an area light samples; wave-uniform inde
     float e1[3];
     float inv_area;
     float n[3];           // stored normal
-    float pad;
+    int32_t n_carriers;   // surfaces whose surface_t::area_light is this light (sorted indices); -1: more than KY_MAX_CARRIERS
+    int32_t carrier[4];
     DSurf isect;          // traversal record of the sampled shape (pdf_direction re-intersects it, 1057-1061)
 };
+constexpr int KY_MAX_CARRIERS = 4;
+constexpr int KY_TRANSPOSE_MAX = 4;   // at most this many occlusion queries per wave are resolved surface-parallel
 
 struct DPar {  // planar parallelogram, 48 B: q0 = (n, n.p0), q1 = (a*, a*.p1 + 0.5), q2 = (b*, b*.p1 + 0.5)
     float4 q0, q1, q2;
@@ -174,6 +177,7 @@ struct DScene {
     DPar par[KYHIP_MAX_SURFACES + 1];   // one readable record past the end: the traversal prefetches i + 1
     DSph sph[KYHIP_MAX_SURFACES + 1];
     DSurf gen[KYHIP_MAX_SURFACES];
+    DSurf all[KYHIP_MAX_SURFACES];      // every surface as a generic record, sorted order (carrier tests, surface-parallel queries)
     DShapeFull full[KYHIP_MAX_SURFACES + KYHIP_MAX_LIGHTS];
     DHit hit[KYHIP_MAX_SURFACES];
     int32_t orig[KYHIP_MAX_SURFACES];
@@ -182,6 +186,7 @@ struct DScene {
 };
 
 struct LdsScene {  // the per-workgroup LDS copy of the tables that are indexed per lane
+    DSurf trav[KYHIP_MAX_SURFACES];   // traversal records, one per LANE in the surface-parallel occlusion query
     DHit hit[KYHIP_MAX_SURFACES];
     DMat mat[KYHIP_MAX_MATERIALS];
     float light_color[KYHIP_MAX_LIGHTS][4];
@@ -195,6 +200,9 @@ KY_DEV void stage_scene(LdsScene& L, const DScene* __restrict__ S) {
     const uint32_t* src_h = reinterpret_cast<const uint32_t*>(S->hit);
     uint32_t* dst_h = reinterpret_cast<uint32_t*>(L.hit);
     for (int i = tid; i < S->n_surfaces * (int)(sizeof(DHit) / 4); i += nt) dst_h[i] = src_h[i];
+    const uint32_t* src_t = reinterpret_cast<const uint32_t*>(S->all);
+    uint32_t* dst_t = reinterpret_cast<uint32_t*>(L.trav);
+    for (int i = tid; i < S->n_surfaces * (int)(sizeof(DSurf) / 4); i += nt) dst_t[i] = src_t[i];
     const uint32_t* src_m = reinterpret_cast<const uint32_t*>(S->mat);
     uint32_t* dst_m = reinterpret_cast<uint32_t*>(L.mat);
     for (int i = tid; i < S->n_materials * (int)(sizeof(DMat) / 4); i += nt) dst_m[i] = src_m[i];
@@ -751,38 +759,90 @@ KY_DEV f3 surface_emission(const LdsScene& Lds, int surface, f3 normal, f3 wo) {
     return e;
 }
 
-// BSDF-sampling half of an estimator: by_bsdf (3889-3930, MIS=false) and by_bsdf_mis (3968-4033, MIS=true)
+// BSDF-sampling half of an estimator: by_bsdf (3889-3930, MIS=false) and by_bsdf_mis (3968-4033, MIS=true).
+//
+// MUST be called in wave-uniform control flow (`active` says whether this lane takes part): the reference asks "is the
+// nearest hit along the sampled direction a surface that carries this light?" (3989-3995) with a full scene traversal
+// per ray, but only the few rays that reach a carrier surface at all need an answer.  So each lane first tests just
+// the carrier surfaces; the rare lanes that hit one then ask "is anything in front of it?", and those few queries
+// are resolved SURFACE-parallel: the query ray is broadcast (v_readlane) and lane j tests surface j (records in LDS),
+// one ballot per query.  With more than KY_TRANSPOSE_MAX queries in the wave, or for scenes the fast path does not
+// cover (general quads / triangles / disks, environment lights, many carriers), the ordinary traversal runs instead.
 template <bool MIS>
-KY_DEV f3 estimate_by_bsdf(const DScene* __restrict__ S, const LdsScene& Lds, const Vertex& v, int li, float u0, float u1) {
+KY_DEV f3 estimate_by_bsdf(const DScene* __restrict__ S, const LdsScene& Lds, const Vertex& v, int li, float u0, float u1, bool active) {
     const DLight& L = S->light[li];
     f3 Ld = mk3(0, 0, 0);
-    if (L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION) return Ld;  // light.is_delta(), 3894 / 3977
-    BsdfSample bs = bsdf_sample_local(v.bsdf, to_local(v.frame, v.wo), u0, u1);
-    bs.wi = to_world(v.frame, bs.wi);  // 2176
-    const f3 f_cos = bs.f * fabsf(dot(bs.wi, v.normal));
-    const bool dead = is_black(f_cos) || (MIS ? (bs.pdf <= 0) : (bs.pdf == 0));
-    if (!dead) {
-        const f3 o = offset_ray_origin(v.position, v.normal, bs.wi);  // isect.spawn_ray, 665-668
+    if (L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION) return Ld;  // light.is_delta(), 3894 / 3977 (wave-uniform)
+    BsdfSample bs;
+    f3 f_cos = mk3(0, 0, 0), o = mk3(0, 0, 0), Li = mk3(0, 0, 0);
+    bs.wi = mk3(0, 0, 1);
+    bs.pdf = 0.f;
+    bool live = false;
+    if (active) {
+        bs = bsdf_sample_local(v.bsdf, to_local(v.frame, v.wo), u0, u1);
+        bs.wi = to_world(v.frame, bs.wi);  // 2176
+        f_cos = bs.f * fabsf(dot(bs.wi, v.normal));
+        live = !(is_black(f_cos) || (MIS ? (bs.pdf <= 0) : (bs.pdf == 0)));
+        o = offset_ray_origin(v.position, v.normal, bs.wi);  // isect.spawn_ray, 665-668
+    }
+    const bool fast = L.kind == KY_LIGHT_AREA && L.n_carriers >= 0 && S->n_gen == 0;  // wave-uniform
+    if (fast) {
+        // (a) nearest carrier surface along the ray, and what it emits towards the ray (3084, 2957-2960)
+        float t_l = K_INF;
+        int c = -1;
+        for (int k = 0; k < L.n_carriers; ++k) {
+            float t;
+            const bool ok = live & surf_hit(S->all[L.carrier[k]], S->full, o, bs.wi, t_l, t);
+            t_l = ok ? t : t_l;
+            c = ok ? L.carrier[k] : c;
+        }
+        bool pending = c >= 0;
+        if (pending) {
+            const f3 hp = o + t_l * bs.wi;
+            Li = surface_emission(Lds, c, hit_normal(Lds.hit[c], hp, bs.wi), -bs.wi);
+            pending = !is_black(Li);
+        }
+        // (b) is any surface in front of the carrier?  (the carrier itself reproduces t_l exactly, and t < t_l is strict)
+        unsigned long long queries = __ballot(pending);
+        bool blocked = false;
+        if (__popcll(queries) > KY_TRANSPOSE_MAX) {
+            KY_PROBE(2);
+            if (pending) blocked = trace_any(S, o, bs.wi, t_l);
+        } else {
+            const int lane = (int)__lane_id();
+            const DSurf& mine = Lds.trav[lane < S->n_surfaces ? lane : 0];
+            while (queries) {
+                const int src = __ffsll((long long)queries) - 1;
+                queries &= queries - 1;
+                const f3 qo = mk3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
+                const f3 qd = mk3(__shfl(bs.wi.x, src), __shfl(bs.wi.y, src), __shfl(bs.wi.z, src));
+                const float qt = __shfl(t_l, src);
+                float t;
+                const bool ok = (lane < S->n_surfaces) && surf_hit(mine, S->full, qo, qd, qt, t);
+                const bool any = __any(ok);
+                if (lane == src) blocked = any;
+            }
+        }
+        if (blocked) Li = mk3(0, 0, 0);
+    } else if (live) {
         float t = K_INF;
         KY_PROBE(2);
         const int hs = trace_nearest(S, o, bs.wi, t);
-        f3 Li = mk3(0, 0, 0);
         if (hs >= 0) {
             if (Lds.hit[hs].area_light == li) {  // 3912 / 3994
                 const f3 hp = o + t * bs.wi;
-                const f3 hn = hit_normal(Lds.hit[hs], hp, bs.wi);
-                Li = surface_emission(Lds, hs, hn, -bs.wi);
+                Li = surface_emission(Lds, hs, hit_normal(Lds.hit[hs], hp, bs.wi), -bs.wi);
             }
         } else if (L.kind == KY_LIGHT_ENVIRONMENT) {
             Li = ld3(L.color);  // light.environmental_radiance(ray), 3918 / 4000
         }
-        if (!is_black(Li)) {
-            if (MIS) {
-                const float light_pdf = light_pdf_Li(L, S->full, v.position, v.normal, bs.wi);
-                if (light_pdf > 0) Ld = (f_cos * Li) * (2.f * rcp(bs.pdf + light_pdf));  // 4028
-            } else {
-                Ld = (f_cos * Li) * rcp(bs.pdf);  // 3924
-            }
+    }
+    if (live && !is_black(Li)) {
+        if (MIS) {
+            const float light_pdf = light_pdf_Li(L, S->full, v.position, v.normal, bs.wi);
+            if (light_pdf > 0) Ld = (f_cos * Li) * (2.f * rcp(bs.pdf + light_pdf));  // 4028
+        } else {
+            Ld = (f_cos * Li) * rcp(bs.pdf);  // 3924
         }
     }
     return Ld;
@@ -822,30 +882,36 @@ KY_DEV f3 estimate_by_emitter(const DScene* __restrict__ S, const LdsScene& Lds,
     return Ld;
 }
 
-// sample_all_light, 3834-3872.  Consumes 4 dimensions per light (+2 for the plain bsdf strategy, 3900).
+// sample_all_light, 3834-3872.  Wave-uniform call; `active` lanes draw 4 numbers per light (+2 for the plain bsdf
+// strategy, 3900) and accumulate the estimators.
 template <bool DEBUG_SAMPLER>
-KY_DEV f3 sample_all_light(const DScene* __restrict__ S, const LdsScene& Lds, const Vertex& v, Sampler& smp, int strategy) {
+KY_DEV f3 sample_all_light(const DScene* __restrict__ S, const LdsScene& Lds, const Vertex& v, Sampler& smp, int strategy, bool active) {
     f3 Ld = mk3(0, 0, 0);
     const int nl = S->n_lights;
     for (int li = 0; li < nl; ++li) {
         // the reference's GCC build draws random_bsdf first, then random_light (3866-3868), for every light and strategy
-        const float ub0 = sampler_next<DEBUG_SAMPLER>(smp), ub1 = sampler_next<DEBUG_SAMPLER>(smp);
-        const float ul0 = sampler_next<DEBUG_SAMPLER>(smp), ul1 = sampler_next<DEBUG_SAMPLER>(smp);
+        float ub0 = 0.f, ub1 = 0.f, ul0 = 0.f, ul1 = 0.f;
+        if (active) {
+            ub0 = sampler_next<DEBUG_SAMPLER>(smp); ub1 = sampler_next<DEBUG_SAMPLER>(smp);
+            ul0 = sampler_next<DEBUG_SAMPLER>(smp); ul1 = sampler_next<DEBUG_SAMPLER>(smp);
+        }
         if (strategy == KY_DIRECT_BOTH_MIS) {  // 4076-4088
-            const f3 Lb = estimate_by_bsdf<true>(S, Lds, v, li, ub0, ub1);
-            const f3 Ll = estimate_by_emitter<true>(S, Lds, v, li, ul0, ul1);
+            const f3 Lb = estimate_by_bsdf<true>(S, Lds, v, li, ub0, ub1, active);
+            f3 Ll = mk3(0, 0, 0);
+            if (active) Ll = estimate_by_emitter<true>(S, Lds, v, li, ul0, ul1);
             Ld = Ld + (0.5f * Lb + 0.5f * Ll);
         } else if (strategy == KY_DIRECT_BSDF_MIS) {
-            Ld = Ld + estimate_by_bsdf<true>(S, Lds, v, li, ub0, ub1);
+            Ld = Ld + estimate_by_bsdf<true>(S, Lds, v, li, ub0, ub1, active);
         } else if (strategy == KY_DIRECT_LIGHT_MIS) {
-            Ld = Ld + estimate_by_emitter<true>(S, Lds, v, li, ul0, ul1);
+            if (active) Ld = Ld + estimate_by_emitter<true>(S, Lds, v, li, ul0, ul1);
         } else if (strategy == KY_DIRECT_LIGHT) {
-            Ld = Ld + estimate_by_emitter<false>(S, Lds, v, li, ul0, ul1);
+            if (active) Ld = Ld + estimate_by_emitter<false>(S, Lds, v, li, ul0, ul1);
         } else if (strategy == KY_DIRECT_BSDF) {
             const int lk = S->light[li].kind;
             if (!(lk == KY_LIGHT_POINT || lk == KY_LIGHT_DIRECTION)) {  // the third float2 is drawn after the delta test (3894-3900)
-                const float u0 = sampler_next<DEBUG_SAMPLER>(smp), u1 = sampler_next<DEBUG_SAMPLER>(smp);
-                Ld = Ld + estimate_by_bsdf<false>(S, Lds, v, li, u0, u1);
+                float u0 = 0.f, u1 = 0.f;
+                if (active) { u0 = sampler_next<DEBUG_SAMPLER>(smp); u1 = sampler_next<DEBUG_SAMPLER>(smp); }
+                Ld = Ld + estimate_by_bsdf<false>(S, Lds, v, li, u0, u1, active);
             }
         }
         // KY_DIRECT_IDLE: estimate_direct_lighting_idle, 3880-3886
@@ -916,34 +982,37 @@ KY_DEV bool path_intersect(PathState& ps, Vertex& v, const DScene* __restrict__ 
     return true;
 }
 
-// Second half: material, direct lighting, continuation.  Returns false when the path has ended.
+// Second half: material, direct lighting, continuation.  WAVE-UNIFORM call: every lane of the wave calls it, `active`
+// says whether this lane holds a vertex.  Returns true when the (active) lane's path continues.
 template <bool DEBUG_SAMPLER>
-KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, const LdsScene& Lds, const RenderConst& rc) {
-    // material->scattering(isect) for the nearest hit (3083); only plastic draws a lobe number (2663)
-    const DMat& M = Lds.mat[Lds.hit[v.surface].material];
-    float lobe_u = 0.f;
-    if (M.kind == KY_MATERIAL_PLASTIC) lobe_u = sampler_next<DEBUG_SAMPLER>(ps.smp);
-    v.bsdf = make_bsdf(M, lobe_u);
-    v.frame = make_frame(v.normal);
+KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, const LdsScene& Lds, const RenderConst& rc, bool active) {
+    if (active) {
+        // material->scattering(isect) for the nearest hit (3083); only plastic draws a lobe number (2663)
+        const DMat& M = Lds.mat[Lds.hit[v.surface].material];
+        float lobe_u = 0.f;
+        if (M.kind == KY_MATERIAL_PLASTIC) lobe_u = sampler_next<DEBUG_SAMPLER>(ps.smp);
+        v.bsdf = make_bsdf(M, lobe_u);
+        v.frame = make_frame(v.normal);
+    }
 
-    if (rc.integrator < KY_INTEGRATOR_DIRECT_LIGHTING) {  // debug_integrator_t, 4110-4118
-        if (rc.integrator == KY_INTEGRATOR_POSITION) ps.Lo = normalize(v.position);
-        else if (rc.integrator == KY_INTEGRATOR_NORMAL) ps.Lo = v.normal;
-        else {
-            float pdf;
-            bsdf_eval_pdf(v.bsdf, to_local(v.frame, v.wo), to_local(v.frame, v.normal), ps.Lo, pdf);
+    if (rc.integrator < KY_INTEGRATOR_DIRECT_LIGHTING) {  // debug_integrator_t, 4110-4118 (wave-uniform)
+        if (active) {
+            if (rc.integrator == KY_INTEGRATOR_POSITION) ps.Lo = normalize(v.position);
+            else if (rc.integrator == KY_INTEGRATOR_NORMAL) ps.Lo = v.normal;
+            else {
+                float pdf;
+                bsdf_eval_pdf(v.bsdf, to_local(v.frame, v.wo), to_local(v.frame, v.normal), ps.Lo, pdf);
+            }
         }
         return false;
     }
 
-    const bool delta = bsdf_is_delta(v.bsdf);
+    const bool nee = active && !bsdf_is_delta(v.bsdf);  // 4571
     KY_PROBE(6);
-    if (!delta) {  // 4571-4576
-        KY_PROBE(1);
-        const f3 Ld = sample_all_light<DEBUG_SAMPLER>(S, Lds, v, ps.smp, rc.strategy);
-        ps.Lo = ps.Lo + ps.beta * Ld;
-    }
+    const f3 Ld = sample_all_light<DEBUG_SAMPLER>(S, Lds, v, ps.smp, rc.strategy, nee);  // 4575
+    if (nee) ps.Lo = ps.Lo + ps.beta * Ld;
     if (rc.integrator == KY_INTEGRATOR_DIRECT_LIGHTING) return false;  // 4153
+    if (!active) return false;
 
     // sample BSDF to get the new path direction, 4586
     const float u0 = sampler_next<DEBUG_SAMPLER>(ps.smp), u1 = sampler_next<DEBUG_SAMPLER>(ps.smp);
@@ -967,13 +1036,6 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, c
     // when the previous bounce was not specular that last traversal cannot change Lo, so skip it.
     if (ps.bounces >= rc.max_path_depth && !ps.prev_specular) return false;
     return true;
-}
-
-template <bool DEBUG_SAMPLER>
-KY_DEV bool path_step(PathState& ps, const DScene* __restrict__ S, const LdsScene& Lds, const RenderConst& rc) {
-    Vertex v;
-    if (!path_intersect<DEBUG_SAMPLER>(ps, v, S, Lds, rc)) return false;
-    return path_shade<DEBUG_SAMPLER>(ps, v, S, Lds, rc);
 }
 
 }  // namespace kyd

@@ -104,6 +104,9 @@ static ShardConst make_shard(const ky_render_params* p) {
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
+#ifndef KY_MAX_RETRACE
+#define KY_MAX_RETRACE 1
+#endif
 #ifndef KY_WAVES_PER_EU
 #define KY_WAVES_PER_EU 2
 #endif
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DSce
                     alive = false;
                 }
             }
-            if (attempt >= 1) break;
+            if (attempt >= KY_MAX_RETRACE) break;
             // lanes that could start another path right now; worth one more traversal if they would otherwise idle
             // through (2 traversals x lights + shading) that is worth more than the extra traversal
             const int idle = __popcll(__ballot(!alive && !done && s < s_end));
@@ -240,8 +243,9 @@ __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DSce
             continue;  // lanes are between items: (1) serves them on the next turn
         }
         // ---- (3) shade the vertex: direct lighting, continuation ----
-        if (have_vertex) {
-            if (!path_shade<DEBUG_SAMPLER>(ps, v, S, Lds, rc)) {
+        {
+            const bool cont = path_shade<DEBUG_SAMPLER>(ps, v, S, Lds, rc, have_vertex);  // wave-uniform call
+            if (have_vertex && !cont) {
                 Lsum = Lsum + ps.Lo * rc.inv_spp;
                 alive = false;
             }
@@ -362,11 +366,17 @@ __global__ void kat_li_kernel(const DScene* __restrict__ S, RenderConst rc, int 
     __shared__ LdsScene Lds;
     stage_scene(Lds, S);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     PathState ps;
-    path_begin<DEBUG_SAMPLER>(ps, S, rc, x, y, s0 + i);
-    while (path_step<DEBUG_SAMPLER>(ps, S, Lds, rc)) {}
-    out3[3 * (size_t)i] = ps.Lo.x; out3[3 * (size_t)i + 1] = ps.Lo.y; out3[3 * (size_t)i + 2] = ps.Lo.z;
+    bool alive = i < n;
+    if (alive) path_begin<DEBUG_SAMPLER>(ps, S, rc, x, y, s0 + i);
+    while (__any(alive)) {  // path_shade is a wave-uniform call
+        Vertex v;
+        bool have_vertex = false;
+        if (alive) have_vertex = path_intersect<DEBUG_SAMPLER>(ps, v, S, Lds, rc);
+        const bool cont = path_shade<DEBUG_SAMPLER>(ps, v, S, Lds, rc, have_vertex);
+        alive = have_vertex && cont;
+    }
+    if (i < n) { out3[3 * (size_t)i] = ps.Lo.x; out3[3 * (size_t)i + 1] = ps.Lo.y; out3[3 * (size_t)i + 2] = ps.Lo.z; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -496,6 +506,8 @@ static int pack_scene(const ky_scene* in, DScene* out) {
                 d.full = j;
             }
             out->full[j] = fulls[i];
+            out->all[j] = recs[i];
+            out->all[j].full = j;
             DHit& h = out->hit[j];
             cp3(h.n, sh.kind == KY_SHAPE_SPHERE ? sh.p[0] : sh.normal);
             h.kind = sh.kind; h.material = sf.material; h.area_light = sf.area_light;
@@ -529,6 +541,13 @@ static int pack_scene(const ky_scene* in, DScene* out) {
                 cp3(d.p1, sh.p[0]);
             }
             pack_shape(sh, KYHIP_MAX_SURFACES + i, &d.isect, &out->full[KYHIP_MAX_SURFACES + i]);
+            // the surfaces that carry this light (surface_t::area_light == &light, 3994), in sorted order
+            d.n_carriers = 0;
+            for (int j2 = 0; j2 < out->n_surfaces; ++j2) {
+                if (out->hit[j2].area_light != i) continue;
+                if (d.n_carriers >= 0 && d.n_carriers < KY_MAX_CARRIERS) d.carrier[d.n_carriers++] = j2;
+                else d.n_carriers = -1;
+            }
         }
     }
     return KY_OK;

@@ -106,12 +106,20 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: ky_amd has no CPU fallback")
     lib = A.load_kyhip()
+    # KY_BENCH_ONE_GPU=1 (testing only): every rank uses cuda:0 and the gather runs over gloo, so that the N > 1 code
+    # path can be exercised on a single-GPU box; the numbers of such a run are meaningless.
+    one_gpu_test = os.environ.get("KY_BENCH_ONE_GPU") == "1"
+    if one_gpu_test:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu_test:
+            tdist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     scene, params, name = workload(args)
     film = torch.zeros((params.height, params.width, 3), dtype=torch.float32, device=dev) if rank == 0 else None

@@ -155,9 +155,12 @@ typedef struct ky_render_params {
     int32_t  sampler;            /* ky_sampler_kind */
     uint32_t seed;               /* rng_t seed, default 1234 (833) */
     int32_t  width, height;      /* film->get_resolution() (3692): the pixel loop bounds */
-    /* Image-tile sharding.  The film is cut into tile_w x tile_h tiles numbered
-       row-major; this call renders tiles tile_first, tile_first+tile_step, ...  A single-GPU render
-       uses tile_first = 0, tile_step = 1.  tile_w and tile_h must be multiples of 8. */
+    /* Image-tile sharding.  The film is cut into tile_w x tile_h tiles; with
+       tiles_x = ceil(width / tile_w), tile number t lies in tile row t / tiles_x at tile column
+       (t % tiles_x + t / tiles_x) % tiles_x -- row-major with every row rotated by its index, so that
+       an interleaved shard is a comb of diagonals even when tiles_x is a multiple of tile_step.
+       This call renders tiles tile_first, tile_first+tile_step, ...  A single-GPU render uses
+       tile_first = 0, tile_step = 1.  tile_w and tile_h must be multiples of 8. */
     int32_t  tile_w, tile_h;
     int32_t  tile_first, tile_step;
 } ky_render_params;

@@ -229,8 +229,8 @@ struct Sampler {
     uint32_t state, inc;
 };
 // the 64-bit key hashed from (seed, pixel, sample) seeds a PCG-RXS-M-XS-32 stream: state = k0, increment = k1 | 1
-KY_DEV void sampler_start(Sampler& s, uint32_t seed, uint32_t pixel_index, uint32_t sample_index) {
-    const uint32_t h = mix32(pixel_index ^ mix32(seed));
+KY_DEV uint32_t sampler_pixel_key(uint32_t seed, uint32_t pixel_index) { return mix32(pixel_index ^ mix32(seed)); }  // constant per pixel
+KY_DEV void sampler_start(Sampler& s, uint32_t h, uint32_t sample_index) {
     s.state = mix32(h + sample_index * 0x9E3779B9u);
     s.inc = mix32((h ^ 0x6A09E667u) + sample_index * 0x85EBCA6Bu) | 1u;
 }
@@ -940,8 +940,8 @@ struct RenderConst {  // wave-uniform launch constants
 };
 
 template <bool DEBUG_SAMPLER>
-KY_DEV void path_begin(PathState& ps, const DScene* __restrict__ S, const RenderConst& rc, int x, int y, int sample) {
-    sampler_start(ps.smp, rc.seed, (uint32_t)(y * rc.width + x), (uint32_t)sample);
+KY_DEV void path_begin(PathState& ps, const DScene* __restrict__ S, uint32_t pixel_key, int x, int y, int sample) {
+    sampler_start(ps.smp, pixel_key, (uint32_t)sample);
     // get_camera_sample, 943-946 / 971-974
     const float u0 = sampler_next<DEBUG_SAMPLER>(ps.smp), u1 = sampler_next<DEBUG_SAMPLER>(ps.smp);
     generate_ray(S, (float)x + u0, (float)y + u1, ps.o, ps.d);

@@ -52,8 +52,17 @@ static int fail(int code, const char* fmt, ...) {
 // ------------------------------------------------------------------------------------------------
 // shard geometry (host + device)
 // ------------------------------------------------------------------------------------------------
-constexpr int KY_CHUNK = 32;        // samples per work item (fixed: chunk boundaries must not depend on the sharding)
-constexpr int KY_RING = 8;          // fetched-but-not-yet-started items a wave can hold
+// Samples of a pixel are cut into chunks (= work items) by a schedule that depends on spp ONLY (chunk boundaries
+// must not depend on the sharding, or images would differ between GPU counts): KY_CHUNK-sample chunks, except that
+// the last KY_TAIL samples are cut into KY_CHUNK_SMALL-sample chunks.  Items are queued chunk-major, so the small
+// chunks of all blocks come last and the end-of-kernel tail is one small item, not one big one.
+constexpr int KY_CHUNK = 32;
+constexpr int KY_CHUNK_SMALL = 8;
+constexpr int KY_TAIL = 128;
+#ifndef KY_RING_SLOTS
+#define KY_RING_SLOTS 4
+#endif
+constexpr int KY_RING = KY_RING_SLOTS;          // fetched-but-not-yet-started items a wave can hold
 constexpr double KY_FIX_SCALE = 4294967296.0;   // 2^32: accumulator resolution 2.3e-10, range +-2.1e9
 
 struct ShardConst {
@@ -61,7 +70,8 @@ struct ShardConst {
     int tiles_x, tiles_y, n_tiles;     // tiles of the whole film / tiles owned by this shard
     int blocks_w, blocks_per_tile;     // 8x8 pixel blocks inside a tile
     int n_blocks;                      // n_tiles * blocks_per_tile
-    int n_chunks;                      // ceil(spp / KY_CHUNK)
+    int n_chunks;                      // n_big + number of small chunks
+    int n_big, head;                   // chunks of KY_CHUNK samples covering [0, head); small chunks cover [head, spp)
     unsigned n_items;                  // n_blocks * n_chunks
     int n_pix;                         // n_tiles * tile_w * tile_h
 };
@@ -96,7 +106,11 @@ static ShardConst make_shard(const ky_render_params* p) {
     s.blocks_per_tile = s.blocks_w * (p->tile_h / 8);
     s.n_blocks = s.n_tiles * s.blocks_per_tile;
     s.n_pix = s.n_tiles * p->tile_w * p->tile_h;
-    s.n_chunks = (p->samples_per_pixel + KY_CHUNK - 1) / KY_CHUNK;
+    const int spp = p->samples_per_pixel;
+    const int tail = spp < KY_TAIL ? spp : KY_TAIL;
+    s.head = ((spp - tail) / KY_CHUNK) * KY_CHUNK;   // a multiple of KY_CHUNK; the rest goes to the small chunks
+    s.n_big = s.head / KY_CHUNK;
+    s.n_chunks = s.n_big + (spp - s.head + KY_CHUNK_SMALL - 1) / KY_CHUNK_SMALL;
     s.n_items = (unsigned)s.n_blocks * (unsigned)s.n_chunks;
     return s;
 }
@@ -138,21 +152,28 @@ __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DSce
     const int nee_weight = (rc.strategy == KY_DIRECT_IDLE || rc.integrator < KY_INTEGRATOR_DIRECT_LIGHTING) ? 0 : S->n_lights;
 
     const int lane = threadIdx.x & 63;
-    const int lx = lane & 7, ly = lane >> 3;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
     ItemSlot* my_ring = ring[threadIdx.x >> 6];
 
-    int fetched = 0;          // wave-uniform: items this wave has fetched so far
-    bool exhausted = false;   // wave-uniform: the global counter ran past n_items
-    int cur = 0;              // per lane: items this lane has started
+    // wave-uniform: the wave's pool of work is the sequence of (item, pixel) pairs of the items it has fetched;
+    // `cursor` counts the pairs handed out so far (pair n = pixel n % 64 of fetched item n / 64)
+    int fetched = 0;
+    int cursor = 0;
+    bool exhausted = false;   // the global counter ran past n_items
+    // per lane: the pixel chunk being worked on
     int x = 0, y = 0, pix = 0, s = 0, s_end = 0;
+    uint32_t pixel_key = 0;   // hash of (seed, pixel): constant for the chunk
     bool has_item = false, done = false, alive = false;
     f3 Lsum = mk3(0, 0, 0);
     PathState ps;
 
     for (;;) {
-        // ---- (1) lanes whose chunk is finished flush it and move on to the wave's next item ----
+        // ---- (1) lanes whose pixel chunk is finished flush it and take the next (item, pixel) pair of the wave's pool.
+        // A lane is NOT tied to one pixel position: whichever lane is free takes the next pixel, so lanes never wait
+        // for each other and the wave drains within one chunk of the end of the queue.
         const bool need = !alive && !done && s >= s_end;
-        if (__any(need)) {  // wave-uniform branch: every lane runs the bookkeeping below
+        const unsigned long long need_mask = __ballot(need);
+        if (need_mask) {  // wave-uniform branch: every lane runs the bookkeeping below
             if (need && has_item) {
                 const float v[3] = {Lsum.x, Lsum.y, Lsum.z};
                 unsigned fl = 0;
@@ -168,47 +189,49 @@ __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DSce
                 has_item = false;
                 Lsum = mk3(0, 0, 0);
             }
-            if (__any(need && cur >= fetched) && !exhausted) {
-                const int min_cur = wave_min_i32(done ? 0x7fffffff : cur);   // slowest lane still working
-                const int max_want = wave_max_i32(need ? cur : -1);           // highest ordinal a lane is asking for
-                // slot (fetched % KY_RING) may be overwritten once every lane has started ordinal fetched - KY_RING
-                while (fetched <= max_want && fetched - min_cur < KY_RING) {
-                    unsigned id = 0;
-                    if (lane == 0) id = atomicAdd(counter, 1u);
-                    id = __builtin_amdgcn_readfirstlane(id);
-                    if (id >= sh.n_items) { exhausted = true; break; }
-                    const int b = (int)(id / (unsigned)sh.n_chunks), c = (int)(id % (unsigned)sh.n_chunks);
-                    const int k = b / sh.blocks_per_tile, inner = b % sh.blocks_per_tile;
-                    const int bx = inner % sh.blocks_w, by = inner / sh.blocks_w;
-                    const int tile = sh.tile_first + k * sh.tile_step;
-                    if (lane == 0) {
-                        ItemSlot it;
-                        it.x0 = (tile % sh.tiles_x) * sh.tile_w + bx * 8;
-                        it.y0 = (tile / sh.tiles_x) * sh.tile_h + by * 8;
-                        it.pix0 = (k * sh.tile_h + by * 8) * sh.tile_w + bx * 8;
-                        it.s_begin = c * KY_CHUNK;
-                        it.s_end = min(rc.spp, c * KY_CHUNK + KY_CHUNK);
-                        my_ring[fetched % KY_RING] = it;
-                    }
-                    ++fetched;
+            const int n_need = __popcll(need_mask);
+            // fetch until the pool covers every requesting lane (at most two items: n_need <= 64), or the queue is empty.
+            // Slot reuse: item fetched - KY_RING was handed out completely long ago (cursor >= (fetched - 2) * 64).
+            while (!exhausted && cursor + n_need > fetched * 64) {
+                unsigned id = 0;
+                if (lane == 0) id = atomicAdd(counter, 1u);
+                id = __builtin_amdgcn_readfirstlane(id);
+                if (id >= sh.n_items) { exhausted = true; break; }
+                const int c = (int)(id / (unsigned)sh.n_blocks), b = (int)(id % (unsigned)sh.n_blocks);   // chunk-major
+                const int k = b / sh.blocks_per_tile, inner = b % sh.blocks_per_tile;
+                const int bx = inner % sh.blocks_w, by = inner / sh.blocks_w;
+                const int tile = sh.tile_first + k * sh.tile_step;
+                if (lane == 0) {
+                    ItemSlot it;
+                    const int trow = tile / sh.tiles_x, tcol = (tile % sh.tiles_x + trow) % sh.tiles_x;   // rotated rows
+                    it.x0 = tcol * sh.tile_w + bx * 8;
+                    it.y0 = trow * sh.tile_h + by * 8;
+                    it.pix0 = (k * sh.tile_h + by * 8) * sh.tile_w + bx * 8;
+                    it.s_begin = c < sh.n_big ? c * KY_CHUNK : sh.head + (c - sh.n_big) * KY_CHUNK_SMALL;
+                    it.s_end = c < sh.n_big ? it.s_begin + KY_CHUNK : min(rc.spp, it.s_begin + KY_CHUNK_SMALL);
+                    my_ring[fetched % KY_RING] = it;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // lane 0's slot writes before the other lanes' reads
+                ++fetched;
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // lane 0's slot writes before the other lanes' reads
             if (need) {
-                if (cur < fetched) {
-                    const ItemSlot it = my_ring[cur % KY_RING];
-                    ++cur;
-                    x = it.x0 + lx;
-                    y = it.y0 + ly;
-                    pix = it.pix0 + ly * sh.tile_w + lx;
+                const int mine = cursor + __popcll(need_mask & lanes_below);
+                if (mine < fetched * 64) {
+                    const ItemSlot it = my_ring[(mine >> 6) % KY_RING];
+                    const int px = mine & 7, py = (mine >> 3) & 7;
+                    x = it.x0 + px;
+                    y = it.y0 + py;
+                    pix = it.pix0 + py * sh.tile_w + px;
+                    pixel_key = sampler_pixel_key(rc.seed, (uint32_t)(y * rc.width + x));
                     const bool in_range = x < rc.width && y < rc.height;
                     s = in_range ? it.s_begin : it.s_end;
                     s_end = it.s_end;
                     has_item = in_range;
-                } else if (exhausted) {
-                    done = true;
-                }  // else: the ring is full -- wait for the slowest lane
+                } else {
+                    done = true;  // only reachable once the queue is exhausted
+                }
             }
+            cursor = min(cursor + n_need, fetched * 64);
         }
         // ---- (2) regenerate + trace until enough lanes hold a vertex ----
         // A lane whose path ends at the traversal itself (a miss, the depth cap) would sit out the whole shading phase,
@@ -218,7 +241,7 @@ __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DSce
         bool have_vertex = false;
         for (int attempt = 0;; ++attempt) {
             if (!alive && !done && s < s_end) {  // next camera sample of this lane's pixel, 3712-3715
-                path_begin<DEBUG_SAMPLER>(ps, S, rc, x, y, s);
+                path_begin<DEBUG_SAMPLER>(ps, S, pixel_key, x, y, s);
                 ++s;
                 alive = true;
             }
@@ -273,8 +296,9 @@ __global__ void film_add_kernel(const float* __restrict__ tiles, float* __restri
     const int per_tile = sh.tile_w * sh.tile_h;
     const int k = i / per_tile, r = i % per_tile;
     const int tile = sh.tile_first + k * sh.tile_step;
-    const int x = (tile % sh.tiles_x) * sh.tile_w + r % sh.tile_w;
-    const int y = (tile / sh.tiles_x) * sh.tile_h + r / sh.tile_w;
+    const int trow = tile / sh.tiles_x, tcol = (tile % sh.tiles_x + trow) % sh.tiles_x;   // rotated rows (kyhip.h)
+    const int x = tcol * sh.tile_w + r % sh.tile_w;
+    const int y = trow * sh.tile_h + r / sh.tile_w;
     if (x >= width || y >= height) return;
     float* px = film + ((size_t)y * stride_px + x) * 3;
     px[0] += tiles[3 * (size_t)i]; px[1] += tiles[3 * (size_t)i + 1]; px[2] += tiles[3 * (size_t)i + 2];
@@ -368,7 +392,7 @@ __global__ void kat_li_kernel(const DScene* __restrict__ S, RenderConst rc, int 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     PathState ps;
     bool alive = i < n;
-    if (alive) path_begin<DEBUG_SAMPLER>(ps, S, rc, x, y, s0 + i);
+    if (alive) path_begin<DEBUG_SAMPLER>(ps, S, sampler_pixel_key(rc.seed, (uint32_t)(y * rc.width + x)), x, y, s0 + i);
     while (__any(alive)) {  // path_shade is a wave-uniform call
         Vertex v;
         bool have_vertex = false;
@@ -563,6 +587,7 @@ struct DeviceCtx {
     size_t ws_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int blocks_per_cu[3] = {0, 0, 0};
+    bool scene_valid = false;
 };
 static std::mutex g_mutex;
 static DeviceCtx g_ctx[16];
@@ -594,11 +619,18 @@ static int get_ctx(int device, DeviceCtx** out) {
 }
 
 static int upload_scene(DeviceCtx* c, const ky_scene* scene, hipStream_t stream) {
-    // the pinned staging copy must not be overwritten while a previous async copy may still read it
-    HIP_TRY(hipStreamSynchronize(stream));
-    const int rc = pack_scene(scene, c->h_scene);
+    // pack into a scratch copy first: an unchanged scene (every frame of a bench or of a tile-sharded render) is not
+    // uploaded again, which also avoids a host-side stream synchronisation per call
+    static thread_local DScene scratch;
+    const int rc = pack_scene(scene, &scratch);
     if (rc != KY_OK) return rc;
+    if (c->scene_valid && std::memcmp(&scratch, c->h_scene, sizeof(DScene)) == 0) return KY_OK;
+    // the pinned staging copy must not be overwritten while a previous async copy may still read it
+    HIP_TRY(hipDeviceSynchronize());
+    std::memcpy(c->h_scene, &scratch, sizeof(DScene));
     HIP_TRY(hipMemcpyAsync(c->d_scene, c->h_scene, sizeof(DScene), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));   // later launches may come on other streams
+    c->scene_valid = true;
     return KY_OK;
 }
 

@@ -31,6 +31,14 @@ def tiles_total(params):
     return tx * ty
 
 
+def tile_origin(params, t):
+    """Pixel origin of tile number t (numbering of include/kyhip.h: row-major with every tile row rotated by its index)."""
+    tx = (params.width + params.tile_w - 1) // params.tile_w
+    row = t // tx
+    col = (t % tx + row) % tx
+    return col * params.tile_w, row * params.tile_h
+
+
 def shard_tile_count(params, rank, world):
     total = tiles_total(params)
     return 0 if rank >= total else (total - rank + world - 1) // world
@@ -68,7 +76,6 @@ def add_tiles_to_film(film, gathered, params, world, device_index=0):
     """
     H, W = params.height, params.width
     tw, th = params.tile_w, params.tile_h
-    tx = (W + tw - 1) // tw
     total = tiles_total(params)
     if film.is_cuda:
         lib = A.load_kyhip()
@@ -83,7 +90,7 @@ def add_tiles_to_film(film, gathered, params, world, device_index=0):
         for k in range(shard_tile_count(params, r, world)):
             t = r + k * world
             assert t < total
-            x0, y0 = (t % tx) * tw, (t // tx) * th
+            x0, y0 = tile_origin(params, t)
             w, h = min(tw, W - x0), min(th, H - y0)
             film[y0:y0 + h, x0:x0 + w] += gathered[r, k, :h, :w]
     return film

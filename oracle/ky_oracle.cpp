@@ -1022,7 +1022,8 @@ int kyo_render(const ky_scene* cscene, const ky_render_params* p, float* film, s
 #pragma omp for schedule(dynamic, 1)
         for (int y = 0; y < height; y += 1) {
             for (int x = 0; x < width; x += 1) {
-                int tile = (y / p->tile_h) * tiles_x + (x / p->tile_w);
+                const int trow = y / p->tile_h, tcol = x / p->tile_w;   // tile numbering of include/kyhip.h: rows rotated by their index
+                int tile = trow * tiles_x + ((tcol - trow) % tiles_x + tiles_x) % tiles_x;
                 if (tile < p->tile_first || (tile - p->tile_first) % p->tile_step != 0) continue;
                 color_t L{};
                 sampler_t sampler;

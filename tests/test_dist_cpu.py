@@ -18,11 +18,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _tiles_from_film(film, params, rank, world, dist):
     """Pack this rank's tiles of a full-size film into the compact [max_tiles, th, tw, 3] layout render_shard() produces."""
     tw, th = params.tile_w, params.tile_h
-    tx = (params.width + tw - 1) // tw
     out = torch.zeros((dist.shard_tile_count(params, 0, world), th, tw, 3), dtype=torch.float32)
     for k in range(dist.shard_tile_count(params, rank, world)):
         t = rank + k * world
-        x0, y0 = (t % tx) * tw, (t // tx) * th
+        x0, y0 = dist.tile_origin(params, t)
         w, h = min(tw, params.width - x0), min(th, params.height - y0)
         out[k, :h, :w] = torch.from_numpy(film[y0:y0 + h, x0:x0 + w].copy())
     return out

@@ -65,7 +65,7 @@ def mis_scene(width, height):
 
 
 def make_params(width, height, spp, integrator=A.INTEGRATOR_PATH_TRACING_ITERATION, max_path_depth=5,
-                direct_sample=A.DIRECT_BOTH_MIS, sampler=A.SAMPLER_RANDOM, seed=1234, tile_w=32, tile_h=32,
+                direct_sample=A.DIRECT_BOTH_MIS, sampler=A.SAMPLER_RANDOM, seed=1234, tile_w=16, tile_h=16,
                 tile_first=0, tile_step=1):
     return A.RenderParams(integrator, max_path_depth, direct_sample, spp, sampler, seed, width, height, tile_w, tile_h,
                           tile_first, tile_step)

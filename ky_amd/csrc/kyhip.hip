@@ -129,17 +129,6 @@ struct ItemSlot {  // one fetched work item, decoded once (wave-uniform) and rea
     int x0, y0, pix0, s_begin, s_end;
 };
 
-KY_DEV int wave_min_i32(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
-    return v;
-}
-KY_DEV int wave_max_i32(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
-    return v;
-}
-
 // STRATEGY >= 0 fixes direct_sample_enum at compile time (prunes the other estimators); -1 reads rc.strategy.
 template <bool DEBUG_SAMPLER, int STRATEGY>
 __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DScene* __restrict__ S, RenderConst rc, ShardConst sh,

@@ -678,7 +678,7 @@ public:
         p.sampler = original_sampler->kind();
         p.seed = original_sampler->seed();
         p.width = (int)res.x; p.height = (int)res.y;
-        p.tile_w = 32; p.tile_h = 32; p.tile_first = 0; p.tile_step = 1;
+        p.tile_w = 16; p.tile_h = 16; p.tile_first = 0; p.tile_step = 1;
         const int rc = kyhip_render(device_, &scene->flatten(), &p, film->target_origin(), film->row_stride_px());
         if (rc != KY_OK) throw std::runtime_error(std::string("kyhip_render: ") + kyhip_last_error());
     }

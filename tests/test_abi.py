@@ -53,7 +53,7 @@ def test_shard_arithmetic_is_pure_host_code(A, api):
     assert lib.kyhip_shard_float_count(C.byref(p)) == 12 * 32 * 32 * 3
     counts = []
     for r in range(5):
-        q = api.make_params(100, 70, 4, tile_first=r, tile_step=5)
+        q = api.make_params(100, 70, 4, tile_w=32, tile_h=32, tile_first=r, tile_step=5)
         counts.append(lib.kyhip_shard_tile_count(C.byref(q)))
     assert counts == [3, 3, 2, 2, 2] and sum(counts) == 12
     bad = api.make_params(100, 70, 4, tile_w=30)  # not a multiple of 8

@@ -46,7 +46,8 @@ typedef struct ky_shape {
     int32_t kind;      /* ky_shape_kind */
     float   p[4][3];   /* rectangle: p0..p3 (1318-1321); triangle: p0..p2 (1238-1240);
                           disk: p[0] = position_ (1159); sphere: p[0] = center_ (1516) */
-    float   normal[3]; /* stored normal_ after flip_normal (1174-1176, 1256-1258), disk: normalize(normal) (1105) */
+    float   normal[3]; /* stored normal_ after flip_normal (1174-1176, 1256-1258), disk: normalize(normal) (1105); MUST be unit
+                          length (the reference's constructors normalise it); KY_ERR_INVALID_VALUE otherwise */
     float   radius;    /* disk radius_ (1161), sphere radius_ (1517) */
 } ky_shape;
 

@@ -72,7 +72,8 @@ def make_params(width, height, spp, integrator=A.INTEGRATOR_PATH_TRACING_ITERATI
 
 
 def _scene_ptr(scene):
-    return scene.flat if isinstance(scene, SceneHandle) else scene
+    """A SceneHandle, any object with a `.flat` POINTER(Scene) (e.g. a scene assembled from ctypes structs), or the pointer itself."""
+    return scene.flat if hasattr(scene, "flat") else scene
 
 
 def render(scene, params, film=None, device=0, row_stride_px=None, origin_px=(0, 0)):

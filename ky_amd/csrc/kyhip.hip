@@ -470,6 +470,14 @@ static void pack_material(const ky_material& m, DMat* d) {
     d->exp_flags = (integral ? 1 : 0) | ((integral && std::fmod(std::fabs(e), 2.f) == 1.f) ? 2 : 0);
 }
 
+// the stored normal of a disk / triangle / rectangle must be unit length (the reference's constructors normalise it:
+// 1105, 1174, 1256); the device code relies on it
+static bool shape_normal_ok(const ky_shape& sh) {
+    if (sh.kind == KY_SHAPE_SPHERE) return true;
+    const double n2 = (double)sh.normal[0] * sh.normal[0] + (double)sh.normal[1] * sh.normal[1] + (double)sh.normal[2] * sh.normal[2];
+    return std::fabs(n2 - 1.0) < 1e-4;
+}
+
 static int pack_scene(const ky_scene* in, DScene* out) {
     if (!in) return fail(KY_ERR_INVALID_VALUE, "scene is NULL");
     if (in->surface_count < 0 || in->shape_count < 0 || in->material_count < 0 || in->light_count < 0)
@@ -495,6 +503,7 @@ static int pack_scene(const ky_scene* in, DScene* out) {
             return fail(KY_ERR_INVALID_VALUE, "surface %d has an index out of range", i);
         const ky_shape& sh = in->shapes[sf.shape];
         if (sh.kind < KY_SHAPE_DISK || sh.kind > KY_SHAPE_SPHERE) return fail(KY_ERR_INVALID_VALUE, "shape %d has an unknown kind", sf.shape);
+        if (!shape_normal_ok(sh)) return fail(KY_ERR_INVALID_VALUE, "shape %d: the stored normal must be unit length", sf.shape);
         if (sf.area_light >= 0 && in->lights[sf.area_light].kind != KY_LIGHT_AREA)
             return fail(KY_ERR_INVALID_VALUE, "surface %d: area_light must refer to an area light", i);
         pack_shape(sh, 0, &recs[i], &fulls[i]);
@@ -543,6 +552,7 @@ static int pack_scene(const ky_scene* in, DScene* out) {
             if (l.shape < 0 || l.shape >= in->shape_count) return fail(KY_ERR_INVALID_VALUE, "area light %d: shape out of range", i);
             const ky_shape& sh = in->shapes[l.shape];
             if (sh.kind < KY_SHAPE_DISK || sh.kind > KY_SHAPE_SPHERE) return fail(KY_ERR_INVALID_VALUE, "shape %d has an unknown kind", l.shape);
+            if (!shape_normal_ok(sh)) return fail(KY_ERR_INVALID_VALUE, "shape %d: the stored normal must be unit length", l.shape);
             d.shape_kind = sh.kind; d.radius = sh.radius; d.area = host_shape_area(sh); d.inv_area = 1 / d.area;  // area_pdf = 1 / area(), 1313
             cp3(d.n, sh.normal);
             if (sh.kind == KY_SHAPE_RECTANGLE) {  // p1 + (p0 - p1) u0 + (p2 - p1) u1, 1310
@@ -805,6 +815,7 @@ int kyhip_render(int device, const ky_scene* scene, const ky_render_params* p, f
 int kyhip_kat_intersect(int device, const ky_shape* shape, const float* rays7, int n, float* out8) {
     if (!shape || !rays7 || !out8 || n <= 0) return fail(KY_ERR_INVALID_VALUE, "bad KAT arguments");
     if (shape->kind < KY_SHAPE_DISK || shape->kind > KY_SHAPE_SPHERE) return fail(KY_ERR_INVALID_VALUE, "unknown shape kind");
+    if (!shape_normal_ok(*shape)) return fail(KY_ERR_INVALID_VALUE, "the stored normal must be unit length");
     KatShape ks{};
     pack_shape(*shape, 0, &ks.surf, &ks.full);
     cp3(ks.hit.n, shape->kind == KY_SHAPE_SPHERE ? shape->p[0] : shape->normal);

@@ -334,3 +334,62 @@ def test_cpp_driver_matches_the_c_abi_path(A, api, tmp_path):
     want = open(tmp_path / "py.bmp", "rb").read()
     assert len(got) == len(want) == 54 + 3 * 512 * 2 * 308 * 3
     assert got == want
+
+
+def general_shapes_scene(A, api):
+    """A small room that exercises every shape kind as a SURFACE and as a LIGHT: a triangle light, a disk light, a
+    rectangle that is NOT a parallelogram (the reference's edge-test path), triangles and a disk as matte / plastic / mirror
+    geometry, plus a glass sphere -- none of which the two shipped scenes contain."""
+    from helpers import CustomScene, make_light, make_material, make_shape
+    cam = api.cornell_box_scene(A.CB_DEFAULT_SCENE, 48, 40)
+    camera = A.Camera.from_buffer_copy(cam.c.camera)
+    S = A
+    shapes = [
+        make_shape(A, S.SHAPE_RECTANGLE, [(-1.3, -1.3, -1.28), (1.3, -1.3, -1.28), (1.3, 1.3, -1.28), (-1.3, 1.3, -1.28)]),        # 0 floor
+        make_shape(A, S.SHAPE_RECTANGLE, [(-1.3, -1.3, -1.28), (-1.3, -1.3, 1.28), (1.3, -1.3, 1.28), (1.1, -1.3, -1.1)]),         # 1 back wall: NOT a parallelogram
+        make_shape(A, S.SHAPE_TRIANGLE, [(-1.3, -1.3, -1.28), (-1.3, 1.3, -1.28), (-1.3, -1.3, 1.28)]),                             # 2 left wall, lower triangle
+        make_shape(A, S.SHAPE_TRIANGLE, [(-1.3, 1.3, 1.28), (-1.3, -1.3, 1.28), (-1.3, 1.3, -1.28)]),                               # 3 left wall, upper triangle
+        make_shape(A, S.SHAPE_DISK, [(0.9, 0.2, -0.3)], normal=(-0.8, 0.0, 0.6), radius=0.6),                                       # 4 tilted disk (mirror)
+        make_shape(A, S.SHAPE_SPHERE, [(-0.2, 0.1, -0.8)], radius=0.45),                                                            # 5 glass ball
+        make_shape(A, S.SHAPE_TRIANGLE, [(-0.4, -0.4, 1.25), (0.4, -0.4, 1.25), (0.0, 0.4, 1.25)], flip=True),                      # 6 triangle light (faces down)
+        make_shape(A, S.SHAPE_DISK, [(0.6, -1.0, 0.4)], normal=tuple(unit(np.array([0.0, 1.0, -0.2]))), radius=0.3),                                       # 7 disk light
+        make_shape(A, S.SHAPE_RECTANGLE, [(-1.3, 1.3, -1.28), (1.3, 1.3, -1.28), (1.3, 1.3, 1.28), (-1.3, 1.3, 1.28)]),              # 8 unused shape (front, not a surface)
+    ]
+    materials = [
+        make_material(A, S.MATERIAL_MATTE, (0.7, 0.7, 0.7)), make_material(A, S.MATERIAL_MATTE, (0.2, 0.6, 0.3)),
+        make_material(A, S.MATERIAL_PLASTIC, (0.2, 0.15, 0.1), (0.6, 0.6, 0.6), exponent=33.0), make_material(A, S.MATERIAL_MIRROR, (0.9, 0.9, 0.9)),
+        make_material(A, S.MATERIAL_GLASS, (1, 1, 1), (1, 1, 1), eta=1.5), make_material(A, S.MATERIAL_MATTE, (0, 0, 0)),
+    ]
+    lights = [make_light(A, S.LIGHT_AREA, (18, 16, 12), shape=6), make_light(A, S.LIGHT_AREA, (3, 6, 12), shape=7),
+              make_light(A, S.LIGHT_POINT, (0.3, 0.3, 0.3), position=(0.0, 0.9, 0.9))]
+    surfaces = [A.Surface(0, 2, -1), A.Surface(1, 0, -1), A.Surface(2, 1, -1), A.Surface(3, 1, -1), A.Surface(4, 3, -1), A.Surface(5, 4, -1),
+                A.Surface(6, 5, 0), A.Surface(7, 5, 1)]
+    return CustomScene(A, camera, shapes, materials, lights, surfaces)
+
+
+@pytest.mark.parametrize("strategy", STRATEGIES)
+def test_general_shapes_scene(strategy, A, api, O):
+    scene = general_shapes_scene(A, api)
+    W, H = 48, 40
+    params = api.make_params(W, H, 128, direct_sample=strategy)
+    pixels = [(24, 20), (6, 30), (40, 30), (24, 4), (10, 10), (36, 12), (30, 34), (16, 26)]
+    bad, tot, sg, sc = li_agreement(api, O, scene, params, pixels)
+    assert bad <= 0.03 * tot, (bad, tot)
+    assert abs(sg - sc) <= 0.03 * max(sc, 1.0)
+    if strategy == 48:
+        p = api.make_params(W, H, 512, tile_w=16, tile_h=8)
+        g, c = api.render(scene, p), O.render(scene, p)
+        assert c.mean() > 0.02 and np.isfinite(g).all()
+        assert rmse(g, c) < film_tolerance(512), rmse(g, c)
+        rays = random_rays(np.random.default_rng(5), 4096, origin_box=1.2, target=np.random.default_rng(6).uniform(-1.2, 1.2, (4096, 3)))
+        gi, ci = api.kat_scene_intersect(scene, rays), O.kat_scene_intersect(scene, rays)
+        assert ((gi[:, 0] == ci[:, 0]) & (gi[:, 8] == ci[:, 8])).mean() > 0.997
+        for light in range(2):  # triangle and disk light sampling / pdf
+            pts = np.random.default_rng(7 + light).uniform(-1.0, 1.0, (2048, 3))
+            nrm = unit(np.random.default_rng(9).normal(size=(2048, 3)))
+            u = np.random.default_rng(11).uniform(size=(2048, 2))
+            x = np.concatenate([pts, nrm, u, unit(np.random.default_rng(13).normal(size=(2048, 3)))], 1).astype(np.float32)
+            gl, cl = api.kat_light(scene, light, x), O.kat_light(scene, light, x)
+            assert_close_q(gl[:, 0:6], cl[:, 0:6], 2e-5, q=0.998, hard=5e-2)
+            ok = np.isfinite(cl).all(1) & np.isfinite(gl).all(1)
+            assert_close_q(gl[ok][:, 6:], cl[ok][:, 6:], 5e-4, q=0.995, hard=np.inf)

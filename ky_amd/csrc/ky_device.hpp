@@ -586,7 +586,8 @@ KY_DEV BsdfSample bsdf_sample_local(const Bsdf& B, f3 wo, float u0, float u1) {
 // path vertex (isect_t, 642-690)
 // ---------------------------------------------------------------------------------------------
 struct Vertex {
-    f3 position, normal, wo;
+    f3 position, normal;
+    f3 wo_l;      // wo = -ray.direction (3125) in the shading frame
     Frame frame;
     Bsdf bsdf;
     int surface;
@@ -779,7 +780,7 @@ KY_DEV f3 estimate_by_bsdf(const DScene* __restrict__ S, const LdsScene& Lds, co
     bs.pdf = 0.f;
     bool live = false;
     if (active) {
-        bs = bsdf_sample_local(v.bsdf, to_local(v.frame, v.wo), u0, u1);
+        bs = bsdf_sample_local(v.bsdf, v.wo_l, u0, u1);
         bs.wi = to_world(v.frame, bs.wi);  // 2176
         f_cos = bs.f * fabsf(dot(bs.wi, v.normal));
         live = !(is_black(f_cos) || (MIS ? (bs.pdf <= 0) : (bs.pdf == 0)));
@@ -810,13 +811,17 @@ KY_DEV f3 estimate_by_bsdf(const DScene* __restrict__ S, const LdsScene& Lds, co
             if (pending) blocked = trace_any(S, o, bs.wi, t_l);
         } else {
             const int lane = (int)__lane_id();
-            const DSurf& mine = Lds.trav[lane < S->n_surfaces ? lane : 0];
             while (queries) {
                 const int src = __ffsll((long long)queries) - 1;
                 queries &= queries - 1;
                 const f3 qo = mk3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
                 const f3 qd = mk3(__shfl(bs.wi.x, src), __shfl(bs.wi.y, src), __shfl(bs.wi.z, src));
                 const float qt = __shfl(t_l, src);
+                // this lane's surface record is read INSIDE the loop (the empty asm makes the index opaque, so the loads
+                // cannot be hoisted): queries are rare and the record would otherwise pin 14 VGPRs across the estimator
+                int idx = lane < S->n_surfaces ? lane : 0;
+                asm volatile("" : "+v"(idx));
+                const DSurf& mine = Lds.trav[idx];
                 float t;
                 const bool ok = (lane < S->n_surfaces) && surf_hit(mine, S->full, qo, qd, qt, t);
                 const bool any = __any(ok);
@@ -870,7 +875,7 @@ KY_DEV f3 estimate_by_emitter(const DScene* __restrict__ S, const LdsScene& Lds,
             KY_PROBE(5);
             f3 f;
             float bsdf_pdf;
-            bsdf_eval_pdf(v.bsdf, to_local(v.frame, v.wo), to_local(v.frame, ls.wi), f, bsdf_pdf);
+            bsdf_eval_pdf(v.bsdf, v.wo_l, to_local(v.frame, ls.wi), f, bsdf_pdf);
             const f3 f_cos = f * fabsf(dot(ls.wi, v.normal));
             if (!is_black(f_cos)) {
                 const bool delta_light = L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION;
@@ -964,9 +969,8 @@ KY_DEV bool path_intersect(PathState& ps, Vertex& v, const DScene* __restrict__ 
     if (hit) {
         v.position = ps.o + t * ps.d;
         v.normal = hit_normal(Lds.hit[hs], v.position, ps.d);
-        v.wo = -ps.d;
         v.surface = hs;
-        emission = surface_emission(Lds, hs, v.normal, v.wo);
+        emission = surface_emission(Lds, hs, v.normal, -ps.d);
     }
 
     if (rc.integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION || rc.integrator == KY_INTEGRATOR_DIRECT_LIGHTING) {
@@ -993,6 +997,7 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, c
         if (M.kind == KY_MATERIAL_PLASTIC) lobe_u = sampler_next<DEBUG_SAMPLER>(ps.smp);
         v.bsdf = make_bsdf(M, lobe_u);
         v.frame = make_frame(v.normal);
+        v.wo_l = to_local(v.frame, -ps.d);   // ps.d still holds the direction of the ray that found this vertex
     }
 
     if (rc.integrator < KY_INTEGRATOR_DIRECT_LIGHTING) {  // debug_integrator_t, 4110-4118 (wave-uniform)
@@ -1001,7 +1006,7 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, c
             else if (rc.integrator == KY_INTEGRATOR_NORMAL) ps.Lo = v.normal;
             else {
                 float pdf;
-                bsdf_eval_pdf(v.bsdf, to_local(v.frame, v.wo), to_local(v.frame, v.normal), ps.Lo, pdf);
+                bsdf_eval_pdf(v.bsdf, v.wo_l, to_local(v.frame, v.normal), ps.Lo, pdf);
             }
         }
         return false;
@@ -1017,7 +1022,7 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, c
     // sample BSDF to get the new path direction, 4586
     const float u0 = sampler_next<DEBUG_SAMPLER>(ps.smp), u1 = sampler_next<DEBUG_SAMPLER>(ps.smp);
     KY_PROBE(7);
-    BsdfSample bs = bsdf_sample_local(v.bsdf, to_local(v.frame, v.wo), u0, u1);
+    BsdfSample bs = bsdf_sample_local(v.bsdf, v.wo_l, u0, u1);
     bs.wi = to_world(v.frame, bs.wi);
     if (is_black(bs.f) || bs.pdf == 0.f) return false;  // 4588
     ps.beta = ps.beta * (bs.f * (fabsf(dot(bs.wi, v.normal)) * rcp(bs.pdf)));  // 4592

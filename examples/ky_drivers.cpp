@@ -5,6 +5,7 @@
  *
  *   ky_drivers single [spp4]     render_single_scene       (4675): 1024x1024 Cornell + environment light
  *   ky_drivers debug             render_debug              (4715): Veach position / normal / basecolor, 1x3 grid
+ *   ky_drivers multiple_integrator render_multiple_integrator (4740): 4 Cornell lights x 5 integrators, 4x5 grid
  *   ky_drivers direct_sample     render_direct_sample_enum (4779): 4 Cornell lights x 5 strategies, 4x5 grid
  *   ky_drivers multiple_scene    render_multiple_scene     (4819): 3 strategies x 4 Cornell lights, 3x4 grid
  *   ky_drivers mis               render_mis_scene          (4878): Veach x 6 strategies, 2x3 grid
@@ -63,6 +64,23 @@ static const std::vector<std::pair<cornell_box_enum_t, int>>& scene_params(bool 
     return multiple_scene ? b : a;
 }
 
+static void render_multiple_integrator() {
+    const std::vector<integrator_enum_t> integrator_enums{integrator_enum_t::direct_lighting, integrator_enum_t::simple_path_tracing_recursion,
+                                                          integrator_enum_t::path_tracing_recursion, integrator_enum_t::path_tracing_recursion_defered,
+                                                          integrator_enum_t::path_tracing_iteration};
+    film_grid_t film(4, 5, 256, 256);
+    for (auto [scene_enum, spp] : scene_params(false)) {
+        scene_t scene = scene_t::create_cornell_box_scene(cornell_box_enum_t::both_small_spheres | scene_enum, film.get_resolution());
+        std::unique_ptr<sampler_t> sampler = std::make_unique<random_sampler_t>(spp * g_spp_scale);
+        for (auto integrator_enum : integrator_enums) {
+            auto integrator = create_integrator(integrator_enum, 5, direct_sample_enum_t::both_mis);
+            integrator->render(&scene, sampler.get(), &film);
+            film.next_subfilm();
+        }
+    }
+    film.store_image("direct_sample");   // (sic) the reference writes this driver's mosaic under the same name, 4776
+}
+
 static void render_direct_sample_enum() {
     const std::vector<direct_sample_enum_t> sample_enums{direct_sample_enum_t::bsdf, direct_sample_enum_t::light, direct_sample_enum_t::bsdf_mis,
                                                         direct_sample_enum_t::light_mis, direct_sample_enum_t::both_mis};
@@ -117,6 +135,7 @@ int main(int argc, char* argv[]) {
             if (argc > 2) g_spp_scale = std::atoi(argv[2]);
             if (g_spp_scale < 1) g_spp_scale = 1;
             if (!std::strcmp(which, "debug")) render_debug();
+            else if (!std::strcmp(which, "multiple_integrator")) render_multiple_integrator();
             else if (!std::strcmp(which, "direct_sample")) render_direct_sample_enum();
             else if (!std::strcmp(which, "multiple_scene")) render_multiple_scene();
             else if (!std::strcmp(which, "mis")) render_mis_scene();

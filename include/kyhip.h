@@ -128,6 +128,9 @@ typedef enum ky_integrator_kind {
     KY_INTEGRATOR_NORMAL                 = 1,  /* debug_integrator_t, 4114 */
     KY_INTEGRATOR_BASECOLOR              = 2,  /* debug_integrator_t, 4116 */
     KY_INTEGRATOR_DIRECT_LIGHTING        = 6,  /* direct_lighting_t, 4125 */
+    KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION   = 8,   /* simple_path_tracing_recursion_t, 4191 (BSDF sampling only) */
+    KY_INTEGRATOR_PATH_TRACING_RECURSION          = 9,   /* path_tracing_recursion_t, 4305 */
+    KY_INTEGRATOR_PATH_TRACING_RECURSION_DEFERED  = 10,  /* path_tracing_recursion_defered_t, 4409 */
     KY_INTEGRATOR_PATH_TRACING_ITERATION = 11  /* path_tracing_iteration_t, 4523 -- the hot path */
 } ky_integrator_kind;
 

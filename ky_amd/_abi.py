@@ -16,6 +16,7 @@ MATERIAL_MATTE, MATERIAL_MIRROR, MATERIAL_GLASS, MATERIAL_PLASTIC = 0, 1, 2, 3
 LIGHT_POINT, LIGHT_DIRECTION, LIGHT_AREA, LIGHT_ENVIRONMENT = 0, 1, 2, 3
 INTEGRATOR_POSITION, INTEGRATOR_NORMAL, INTEGRATOR_BASECOLOR = 0, 1, 2
 INTEGRATOR_DIRECT_LIGHTING, INTEGRATOR_PATH_TRACING_ITERATION = 6, 11
+INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION, INTEGRATOR_PATH_TRACING_RECURSION, INTEGRATOR_PATH_TRACING_RECURSION_DEFERED = 8, 9, 10
 DIRECT_IDLE, DIRECT_BSDF, DIRECT_LIGHT, DIRECT_BSDF_MIS, DIRECT_LIGHT_MIS, DIRECT_BOTH_MIS = 0, 4, 8, 16, 32, 48
 SAMPLER_DEBUG, SAMPLER_RANDOM = 0, 1
 KY_OK, KY_ERR_INVALID_VALUE, KY_ERR_LIMIT, KY_ERR_DEVICE, KY_ERR_NO_DEVICE = 0, -1, -2, -3, -4

@@ -973,13 +973,19 @@ KY_DEV bool path_intersect(PathState& ps, Vertex& v, const DScene* __restrict__ 
         emission = surface_emission(Lds, hs, v.normal, -ps.d);
     }
 
-    if (rc.integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION || rc.integrator == KY_INTEGRATOR_DIRECT_LIGHTING) {
-        if (ps.bounces == 0 || ps.prev_specular) {  // 4548-4559
-            if (hit) ps.Lo = ps.Lo + ps.beta * emission;
-            else if (S->env_light >= 0) ps.Lo = ps.Lo + ps.beta * ld3(S->light[S->env_light].color);  // environment_lighting, 3231
-        }
-        if (!hit) return false;  // 4563 / 4141
-        if (rc.integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION && ps.bounces >= rc.max_path_depth) return false;  // 4563
+    const f3 env = S->env_light >= 0 ? ld3(S->light[S->env_light].color) : mk3(0, 0, 0);  // environment_lighting, 3231
+    if (rc.integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION || rc.integrator == KY_INTEGRATOR_DIRECT_LIGHTING ||
+        rc.integrator == KY_INTEGRATOR_PATH_TRACING_RECURSION_DEFERED) {
+        if (ps.bounces == 0 || ps.prev_specular) ps.Lo = ps.Lo + ps.beta * (hit ? emission : env);  // 4548-4559 / 4449-4452
+        if (!hit) return false;  // 4563 / 4141 / 4454
+        if (rc.integrator != KY_INTEGRATOR_DIRECT_LIGHTING && ps.bounces >= rc.max_path_depth) return false;  // 4563 / 4454
+    } else if (rc.integrator == KY_INTEGRATOR_PATH_TRACING_RECURSION) {
+        if (ps.bounces == 0) ps.Lo = ps.Lo + ps.beta * (hit ? emission : env);  // 4328-4331
+        if (!hit || ps.bounces >= rc.max_path_depth) return false;              // 4333
+    } else if (rc.integrator == KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION) {
+        // every way out of 4201-4237 returns the hit's emission (or the environment on a miss)
+        ps.Lo = ps.Lo + ps.beta * (hit ? emission : env);
+        if (!hit || ps.bounces >= rc.max_path_depth) return false;              // 4204-4210
     } else if (!hit) {
         return false;  // debug integrators return black on a miss (4121)
     }
@@ -1012,34 +1018,74 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, c
         return false;
     }
 
-    const bool nee = active && !bsdf_is_delta(v.bsdf);  // 4571
+    const bool recursion = rc.integrator == KY_INTEGRATOR_PATH_TRACING_RECURSION;
+    const bool defered = rc.integrator == KY_INTEGRATOR_PATH_TRACING_RECURSION_DEFERED;
+    const bool simple = rc.integrator == KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION;
+    const bool delta = bsdf_is_delta(v.bsdf);
+    const bool nee = active && !delta;  // 4571
     KY_PROBE(6);
-    const f3 Ld = sample_all_light<DEBUG_SAMPLER>(S, Lds, v, ps.smp, rc.strategy, nee);  // 4575
-    if (nee) ps.Lo = ps.Lo + ps.beta * Ld;
+    if (!simple) {  // simple_path_tracing_recursion_t samples the BSDF only
+        const f3 Ld = sample_all_light<DEBUG_SAMPLER>(S, Lds, v, ps.smp, rc.strategy, nee);  // 4575 / 4337 / 4458
+        if (nee) ps.Lo = ps.Lo + ps.beta * Ld;
+    }
     if (rc.integrator == KY_INTEGRATOR_DIRECT_LIGHTING) return false;  // 4153
     if (!active) return false;
 
-    // sample BSDF to get the new path direction, 4586
+    if (recursion && delta) {
+        // path_tracing_recursion_t, specular vertex (4341-4349): look the emitter up along a sampled direction, from the
+        // un-offset hit point; the continuation below draws a NEW sample
+        const float e0 = sampler_next<DEBUG_SAMPLER>(ps.smp), e1 = sampler_next<DEBUG_SAMPLER>(ps.smp);
+        BsdfSample es = bsdf_sample_local(v.bsdf, v.wo_l, e0, e1);
+        es.wi = to_world(v.frame, es.wi);
+        float t = K_INF;
+        const int hs = trace_nearest(S, v.position, es.wi, t);
+        f3 Le = S->env_light >= 0 ? ld3(S->light[S->env_light].color) : mk3(0, 0, 0);
+        if (hs >= 0) {
+            const f3 hp = v.position + t * es.wi;
+            Le = surface_emission(Lds, hs, hit_normal(Lds.hit[hs], hp, es.wi), -es.wi);
+            // scene->intersect builds the hit's BSDF: a plastic surface draws its lobe number (2663)
+            if (Lds.mat[Lds.hit[hs].material].kind == KY_MATERIAL_PLASTIC) (void)sampler_next<DEBUG_SAMPLER>(ps.smp);
+        }
+        ps.Lo = ps.Lo + ps.beta * ((es.f * Le) * (fabsf(dot(es.wi, v.normal)) / es.pdf));  // 0/0 = NaN on total internal reflection, as in 4349
+    }
+
+    // sample BSDF to get the new path direction, 4586 / 4213 / 4383 / 4495
     const float u0 = sampler_next<DEBUG_SAMPLER>(ps.smp), u1 = sampler_next<DEBUG_SAMPLER>(ps.smp);
     KY_PROBE(7);
     BsdfSample bs = bsdf_sample_local(v.bsdf, v.wo_l, u0, u1);
     bs.wi = to_world(v.frame, bs.wi);
-    if (is_black(bs.f) || bs.pdf == 0.f) return false;  // 4588
-    ps.beta = ps.beta * (bs.f * (fabsf(dot(bs.wi, v.normal)) * rcp(bs.pdf)));  // 4592
-    ps.prev_specular = (bs.flags & BSDF_SPECULAR) != 0;  // 4596
-    ps.o = offset_ray_origin(v.position, v.normal, bs.wi);  // 4597
-    ps.d = bs.wi;
-
-    if (ps.bounces > 3) {  // Russian roulette, 4601-4612
-        const float q = fmaxf(0.05f, 1 - max3(ps.beta));
-        const float u = sampler_next<DEBUG_SAMPLER>(ps.smp);
-        if (u < q) return false;
-        ps.beta = ps.beta * rcp(1 - q);
+    if (is_black(bs.f) || bs.pdf == 0.f) return false;  // 4588 / 4215 / 4385 / 4497
+    if (rc.integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION) {
+        ps.beta = ps.beta * (bs.f * (fabsf(dot(bs.wi, v.normal)) * rcp(bs.pdf)));  // 4592
+        ps.prev_specular = (bs.flags & BSDF_SPECULAR) != 0;  // 4596
+        ps.o = offset_ray_origin(v.position, v.normal, bs.wi);  // 4597
+        ps.d = bs.wi;
+        if (ps.bounces > 3) {  // Russian roulette, 4601-4612
+            const float q = fmaxf(0.05f, 1 - max3(ps.beta));
+            const float u = sampler_next<DEBUG_SAMPLER>(ps.smp);
+            if (u < q) return false;
+            ps.beta = ps.beta * rcp(1 - q);
+        }
+        ps.bounces += 1;
+        // The vertex at bounces == max_depth can only add emission after a delta bounce (4548, 4563):
+        // when the previous bounce was not specular that last traversal cannot change Lo, so skip it.
+        if (ps.bounces >= rc.max_path_depth && !ps.prev_specular) return false;
+        return true;
     }
+    // the recursive integrators: roulette on the BSDF value once ++depth > 3 (4219-4226, 4389-4397, 4501-4509)
+    if (ps.bounces + 1 > 3) {
+        const float m = max3(bs.f);
+        const float u = sampler_next<DEBUG_SAMPLER>(ps.smp);
+        if (!(u < m)) return false;
+        bs.f = bs.f * (1 / m);
+    }
+    ps.beta = ps.beta * (bs.f * (fabsf(dot(bs.wi, v.normal)) * rcp(bs.pdf)));  // 4233 / 4400 / 4512
+    ps.prev_specular = delta;  // isect.bsdf()->is_delta(), 4512 (only the defered variant reads it)
+    ps.o = recursion ? offset_ray_origin(v.position, v.normal, bs.wi) : v.position;  // 4399 vs 4232 / 4511
+    ps.d = bs.wi;
     ps.bounces += 1;
-    // The vertex at bounces == max_depth can only add emission after a delta bounce (4548, 4563):
-    // when the previous bounce was not specular that last traversal cannot change Lo, so skip it.
-    if (ps.bounces >= rc.max_path_depth && !ps.prev_specular) return false;
+    // a traversal at depth == max_depth adds nothing for the two NEE recursions unless (defered) the bounce was specular
+    if (ps.bounces >= rc.max_path_depth && (recursion || (defered && !ps.prev_specular))) return false;
     return true;
 }
 

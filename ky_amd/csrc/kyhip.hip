@@ -83,7 +83,9 @@ static bool valid_params(const ky_render_params* p) {
     if (p->tile_first < 0 || p->tile_step <= 0) return false;
     switch (p->integrator) {
     case KY_INTEGRATOR_POSITION: case KY_INTEGRATOR_NORMAL: case KY_INTEGRATOR_BASECOLOR:
-    case KY_INTEGRATOR_DIRECT_LIGHTING: case KY_INTEGRATOR_PATH_TRACING_ITERATION: break;
+    case KY_INTEGRATOR_DIRECT_LIGHTING: case KY_INTEGRATOR_PATH_TRACING_ITERATION:
+    case KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION: case KY_INTEGRATOR_PATH_TRACING_RECURSION:
+    case KY_INTEGRATOR_PATH_TRACING_RECURSION_DEFERED: break;
     default: return false;   // create_integrator returns nullptr (ky.cpp:4638)
     }
     switch (p->direct_sample) {
@@ -137,8 +139,9 @@ __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DSce
     __shared__ LdsScene Lds;
     __shared__ ItemSlot ring[4][KY_RING];
     stage_scene(Lds, S);
-    if (STRATEGY >= 0) rc.strategy = STRATEGY;
-    const int nee_weight = (rc.strategy == KY_DIRECT_IDLE || rc.integrator < KY_INTEGRATOR_DIRECT_LIGHTING) ? 0 : S->n_lights;
+    if (STRATEGY >= 0) { rc.strategy = STRATEGY; rc.integrator = KY_INTEGRATOR_PATH_TRACING_ITERATION; }  // the hot instantiation
+    const int nee_weight = (rc.strategy == KY_DIRECT_IDLE || rc.integrator < KY_INTEGRATOR_DIRECT_LIGHTING ||
+                            rc.integrator == KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION) ? 0 : S->n_lights;
 
     const int lane = threadIdx.x & 63;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;

@@ -721,11 +721,33 @@ public:
         : path_integrator_t(integrator_enum_t::path_tracing_iteration, max_path_depth, direct_sample_enum, device) {}
 };
 
-// create_integrator, ky.cpp:4621-4639.  nullptr for enums the reference's switch does not handle (4638) and
-// for the three recursive teaching integrators, which have no device path.
+// the three recursive integrators (ky.cpp:4191-4514): the same estimators, run as modes of the device kernel
+class simple_path_tracing_recursion_t : public path_integrator_t {
+public:
+    simple_path_tracing_recursion_t(int max_path_depth, direct_sample_enum_t direct_sample_enum, int device = 0)
+        : path_integrator_t(integrator_enum_t::simple_path_tracing_recursion, max_path_depth, direct_sample_enum, device) {}
+};
+class path_tracing_recursion_t : public path_integrator_t {
+public:
+    path_tracing_recursion_t(int max_path_depth, direct_sample_enum_t direct_sample_enum, int device = 0)
+        : path_integrator_t(integrator_enum_t::path_tracing_recursion, max_path_depth, direct_sample_enum, device) {}
+};
+enum class lighting_enum_t { emit = 1, direct = 2, indirect = 4, all_lighting = 7, diffuse = 8, specular = 16, all_scattering = 24, all = 31 };  // 3591-3603
+class path_tracing_recursion_defered_t : public path_integrator_t {
+public:
+    // lighting_enum is stored and never read by the reference either (4412)
+    path_tracing_recursion_defered_t(int max_path_depth, direct_sample_enum_t direct_sample_enum, lighting_enum_t = lighting_enum_t::all, int device = 0)
+        : path_integrator_t(integrator_enum_t::path_tracing_recursion_defered, max_path_depth, direct_sample_enum, device) {}
+};
+
+// create_integrator, ky.cpp:4621-4639.  nullptr for enums the reference's switch does not handle (4638).
 inline std::unique_ptr<integrator_t> create_integrator(integrator_enum_t integrator_enum, int depth, direct_sample_enum_t direct_sample_enum, int device = 0) {
     switch (integrator_enum) {
     case integrator_enum_t::direct_lighting: return std::make_unique<direct_lighting_t>(direct_sample_enum, device);
+    case integrator_enum_t::simple_path_tracing_recursion: return std::make_unique<simple_path_tracing_recursion_t>(depth, direct_sample_enum, device);
+    case integrator_enum_t::path_tracing_recursion: return std::make_unique<path_tracing_recursion_t>(depth, direct_sample_enum, device);
+    case integrator_enum_t::path_tracing_recursion_defered:
+        return std::make_unique<path_tracing_recursion_defered_t>(depth, direct_sample_enum, lighting_enum_t::all, device);
     case integrator_enum_t::path_tracing_iteration: return std::make_unique<path_tracing_iteration_t>(depth, direct_sample_enum, device);
     default: return nullptr;
     }

@@ -971,8 +971,81 @@ struct integrator_t {
         return Lo;
     }
 
+    // simple_path_tracing_recursion_t::Li, 4201-4237 (BSDF sampling only; rays leave from the un-offset hit point)
+    color_t Li_simple(ray_t ray, sampler_t& sampler, counters_t* c, int depth) const {
+        isect_t isect;
+        if (!scene->intersect(ray, &isect, c, &sampler)) return scene->environment_lighting();
+        if (depth >= max_path_depth) return isect.emission;
+        bsdf_sample_t bs = isect.bsdf.sample(isect.wo, sampler.get_float2());
+        if (bs.f.is_black() || bs.pdf == 0.f) return isect.emission;
+        if (++depth > 3) {                                                       // russian roulette, 4219-4226
+            float bsdf_max_comp = bs.f.max_component_value();
+            if (sampler.get_float() < bsdf_max_comp) bs.f *= (1 / bsdf_max_comp);
+            else return isect.emission;
+        }
+        ray_t wi{isect.position, bs.wi, k_infinity};                             // 4232
+        color_t Ls = bs.f * Li_simple(wi, sampler, c, depth) * abs_dot(bs.wi, isect.normal) / bs.pdf;
+        return isect.emission + Ls;
+    }
+
+    // shared by the two NEE recursions: indirect_lighting, 4381-4401 / 4493-4513
+    //   offset: path_tracing_recursion_t spawns from the offset origin (4399), the defered variant does not (4511)
+    color_t indirect_lighting(const isect_t& isect, sampler_t& sampler, counters_t* c, int depth, bool defered) const {
+        bsdf_sample_t bs = isect.bsdf.sample(isect.wo, sampler.get_float2());
+        if (bs.f.is_black() || bs.pdf == 0.f) return color_t{};
+        if (++depth > 3) {
+            float bsdf_max_comp = bs.f.max_component_value();
+            if (sampler.get_float() < bsdf_max_comp) bs.f *= 1 / bsdf_max_comp;
+            else return color_t{};
+        }
+        if (defered) {
+            ray_t wi_ray{isect.position, bs.wi, k_infinity};
+            return bs.f * Li_defered(wi_ray, sampler, c, depth, isect.bsdf.is_delta()) * abs_dot(bs.wi, isect.normal) / bs.pdf;
+        }
+        ray_t wi_ray{offset_ray_origin(isect.position, isect.normal, bs.wi), bs.wi, k_infinity};
+        return bs.f * Li_recursion(wi_ray, sampler, c, depth) * abs_dot(bs.wi, isect.normal) / bs.pdf;
+    }
+
+    // path_tracing_recursion_t::Li, 4321-4356
+    color_t Li_recursion(ray_t ray, sampler_t& sampler, counters_t* c, int depth) const {
+        color_t Lo;
+        isect_t isect;
+        bool hit = scene->intersect(ray, &isect, c, &sampler);
+        if (depth == 0) Lo += hit ? isect.emission : scene->environment_lighting();      // emission_lighting, 4358-4372
+        if (hit && depth < max_path_depth) {
+            if (!isect.bsdf.is_delta()) {
+                Lo += sample_all_light(isect, sampler, c);
+            } else {  // specular vertex: look the emitter up along the sampled direction, 4341-4349
+                bsdf_sample_t bs = isect.bsdf.sample(isect.wo, sampler.get_float2());
+                ray_t wi_ray{isect.position, bs.wi, k_infinity};
+                isect_t next_isect;
+                bool next_hit = scene->intersect(wi_ray, &next_isect, c, &sampler);
+                color_t Le = next_hit ? next_isect.emission : scene->environment_lighting();
+                Lo += bs.f * Le * abs_dot(bs.wi, isect.normal) / bs.pdf;
+            }
+            Lo += indirect_lighting(isect, sampler, c, depth, false);
+        }
+        return Lo;
+    }
+
+    // path_tracing_recursion_defered_t::Li, 4440-4466
+    color_t Li_defered(ray_t ray, sampler_t& sampler, counters_t* c, int depth, bool is_prev_specular) const {
+        color_t Lo;
+        isect_t isect;
+        bool hit = scene->intersect(ray, &isect, c, &sampler);
+        if (depth == 0 || is_prev_specular) Lo += hit ? isect.emission : scene->environment_lighting();
+        if (hit && depth < max_path_depth) {
+            if (!isect.bsdf.is_delta()) Lo += sample_all_light(isect, sampler, c);
+            Lo += indirect_lighting(isect, sampler, c, depth, true);
+        }
+        return Lo;
+    }
+
     color_t Li(ray_t ray, sampler_t& sampler, counters_t* c) const {
         switch (kind) {
+        case KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION: return Li_simple(ray, sampler, c, 0);
+        case KY_INTEGRATOR_PATH_TRACING_RECURSION: return Li_recursion(ray, sampler, c, 0);
+        case KY_INTEGRATOR_PATH_TRACING_RECURSION_DEFERED: return Li_defered(ray, sampler, c, 0, false);
         case KY_INTEGRATOR_PATH_TRACING_ITERATION: return Li_path(ray, sampler, c);
         case KY_INTEGRATOR_DIRECT_LIGHTING: return Li_direct(ray, sampler, c);
         default: return Li_debug(ray, sampler, c);
@@ -988,7 +1061,7 @@ inline bool valid_direct_sample(int v) {
 }
 inline bool valid_integrator(int v) {
     return v == KY_INTEGRATOR_POSITION || v == KY_INTEGRATOR_NORMAL || v == KY_INTEGRATOR_BASECOLOR || v == KY_INTEGRATOR_DIRECT_LIGHTING ||
-           v == KY_INTEGRATOR_PATH_TRACING_ITERATION;
+           (v >= KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION && v <= KY_INTEGRATOR_PATH_TRACING_ITERATION);
 }
 
 }  // namespace kyo

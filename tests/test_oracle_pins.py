@@ -167,3 +167,16 @@ def test_published_images(A, api, O):
     flat = np.abs(rb - rb[0, 0]).max(axis=2) < 0.004   # the gray (0.4/pi) background blocks
     d = np.abs(bc - rb)[flat]
     assert flat.sum() > 250 and d.max() < 0.004, (flat.sum(), d.max())
+
+
+def test_recursive_integrators_agree_with_the_iterative_one(A, api, O):
+    """render_multiple_integrator's premise (ky.cpp:4740-4777): path_tracing_recursion, its defered variant and the
+    iterative integrator estimate the same image (they differ in roulette rule and ray offsets only); the BSDF-only
+    simple recursion is brighter on the Cornell floor because it has no self-occluded light samples (quirk 1)."""
+    scene = api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | A.CB_LIGHT_POINT, 32, 32)
+    mean = {i: float(O.render(scene, api.make_params(32, 32, 256, integrator=i)).mean()) for i in (9, 10, 11)}
+    assert abs(mean[9] - mean[11]) < 0.03 * mean[11] and abs(mean[10] - mean[11]) < 0.03 * mean[11], mean
+    scene = api.cornell_box_scene(A.CB_DEFAULT_SCENE, 32, 32)
+    simple = float(O.render(scene, api.make_params(32, 32, 256, integrator=8)).mean())
+    nee = float(O.render(scene, api.make_params(32, 32, 256, integrator=11)).mean())
+    assert nee < simple < 1.3 * nee, (simple, nee)

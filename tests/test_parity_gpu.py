@@ -293,8 +293,11 @@ def test_film_grid_target(A, api):
     rest = grid.copy()
     rest[24:48, 32:64] = 0
     assert rest.max() == 0
-    # create_integrator returns nullptr for integrators without a device path (ky.cpp:4638)
-    assert api.render_host_api(scene, 9, 5, 48, A.SAMPLER_RANDOM, 1, 32, 24) is None
+    # create_integrator returns nullptr for enums its switch does not handle (ky.cpp:4638) ...
+    assert api.render_host_api(scene, 7, 5, 48, A.SAMPLER_RANDOM, 1, 32, 24) is None
+    # ... and an integrator for each of the five it does (4626-4635)
+    for e in (6, 8, 9, 10, 11):
+        assert api.render_host_api(scene, e, 5, 48, A.SAMPLER_RANDOM, 2, 32, 24).max() > 0
     # debug_integrator_t through the host API
     aov = api.render_host_api(scene, 1, 0, 0, A.SAMPLER_DEBUG, 1, 32, 24)
     assert aov.max() <= 1.0 and aov.max() > 0.5
@@ -393,3 +396,41 @@ def test_general_shapes_scene(strategy, A, api, O):
             assert_close_q(gl[:, 0:6], cl[:, 0:6], 2e-5, q=0.998, hard=5e-2)
             ok = np.isfinite(cl).all(1) & np.isfinite(gl).all(1)
             assert_close_q(gl[ok][:, 6:], cl[ok][:, 6:], 5e-4, q=0.995, hard=np.inf)
+
+
+RECURSIVE = [8, 9, 10]   # simple_path_tracing_recursion, path_tracing_recursion, path_tracing_recursion_defered
+
+
+@pytest.mark.parametrize("integrator", RECURSIVE)
+@pytest.mark.parametrize("flag", ["area", "direction", "point", "environment", "veach"])
+def test_recursive_integrators(flag, integrator, A, api, O):
+    """the reference's recursive integrators (ky.cpp:4191-4514) as modes of the device kernel, per camera
+    sample against the oracle's (truly recursive) restatement, plus the film."""
+    if flag == "veach":
+        scene, W, H = api.mis_scene(96, 54), 96, 54
+        pixels = [(48, 27), (5, 5), (30, 40), (70, 30), (48, 50), (20, 20)]
+    else:
+        f = {"area": A.CB_LIGHT_AREA, "direction": A.CB_LIGHT_DIRECTION, "point": A.CB_LIGHT_POINT, "environment": A.CB_LIGHT_ENVIRONMENT}[flag]
+        scene, W, H = api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | f, 64, 64), 64, 64
+        pixels = [(32, 32), (5, 5), (21, 42), (44, 45), (60, 61), (32, 4), (18, 50), (46, 52)]
+    params = api.make_params(W, H, 128, integrator=integrator)
+    bad, tot, sg, sc = li_agreement(api, O, scene, params, pixels)
+    assert bad <= 0.03 * tot, (bad, tot)
+    assert abs(sg - sc) <= 0.03 * max(sc, 1.0)
+    if flag in ("area", "veach"):
+        p = api.make_params(W, H, 256, integrator=integrator, tile_w=16, tile_h=8)
+        g, c = api.render(scene, p), O.render(scene, p)
+        fin = np.isfinite(c).all(axis=2)
+        assert (~fin).sum() <= 2 and rmse(g[fin], c[fin]) < film_tolerance(256)
+
+
+def test_integrators_agree_in_expectation(A, api):
+    """The reference's own check (render_multiple_integrator, ky.cpp:4740-4777): the NEE integrators estimate the same
+    image; GPU only, unclamped radiance at a few pixels."""
+    scene = api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | A.CB_LIGHT_POINT, 64, 64)
+    means = {}
+    for integ in (9, 10, 11):
+        p = api.make_params(64, 64, 16384, integrator=integ)
+        li = np.concatenate([api.kat_li(scene, p, x, y, 0, 16384) for (x, y) in ((20, 40), (40, 20), (32, 50), (10, 30))])
+        means[integ] = np.minimum(li, 50.0).mean()
+    assert abs(means[9] - means[11]) < 0.04 * means[11] and abs(means[10] - means[11]) < 0.04 * means[11], means

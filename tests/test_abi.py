@@ -65,7 +65,7 @@ def test_invalid_enums_are_rejected_without_a_device(A, api):
     """create_integrator returns nullptr for unknown integrators (ky.cpp:4638); sample_all_light has no
     estimator for OR-ed / unknown strategy values (ky.cpp:3860)."""
     lib = A.load_kyhip()
-    for bad in (api.make_params(8, 8, 1, integrator=9), api.make_params(8, 8, 1, direct_sample=50),
+    for bad in (api.make_params(8, 8, 1, integrator=7), api.make_params(8, 8, 1, integrator=12), api.make_params(8, 8, 1, direct_sample=50),
                 api.make_params(8, 8, 1, direct_sample=2 | 48), api.make_params(8, 8, 0), api.make_params(0, 8, 1)):
         assert lib.kyhip_shard_float_count(C.byref(bad)) == A.KY_ERR_INVALID_VALUE
 

@@ -179,6 +179,12 @@ typedef enum ky_status {
 } ky_status;
 
 const char* kyhip_last_error(void);
+/* Selects the render kernel for path_tracing_iteration_t: 0 = lane engine (default: one lane walks one path, state in
+   registers), 1 = queue engine (experimental: path state in LDS, one queue per path state, wavefronts take full batches
+   from the fullest queue -- ky_amd/csrc/ky_queue.hpp).  Both run the same per-sample arithmetic and random streams; the
+   images differ by float summation order only.  The default is read from the environment variable KYHIP_ENGINE
+   ("lane" / "queue").  Returns the previous engine.  Not part of the reference's interface: a tuning knob. */
+int         kyhip_set_engine(int engine);
 int         kyhip_abi_version(void);
 int         kyhip_device_count(void);
 

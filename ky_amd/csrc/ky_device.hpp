@@ -460,6 +460,25 @@ KY_DEV Bsdf make_bsdf(const DMat& M, float lobe_random) {
     return B;
 }
 
+// the same with the lobe already decided (the queue engine picks it in its first stage, to sort the vertices by lobe)
+KY_DEV int pick_lobe(const DMat& M, float lobe_random) {
+    if (M.kind == KY_MATERIAL_MIRROR) return LOBE_MIRROR;
+    if (M.kind == KY_MATERIAL_GLASS) return LOBE_GLASS;
+    if (M.kind == KY_MATERIAL_PLASTIC && lobe_random < M.p_specular) return LOBE_PHONG;
+    return LOBE_LAMBERT;
+}
+KY_DEV Bsdf make_bsdf_for_lobe(const DMat& M, int lobe) {
+    Bsdf B;
+    B.a = ld3(M.c0);
+    B.b = ld3(M.c1);
+    B.eta_t = M.eta;
+    B.exponent = M.exponent;
+    B.exp_flags = M.exp_flags;
+    B.lobe = lobe;
+    if (M.kind == KY_MATERIAL_PLASTIC) B.a = lobe == LOBE_PHONG ? ld3(M.c1) * rcp(M.p_specular) : ld3(M.c0) * rcp(M.p_diffuse);
+    return B;
+}
+
 // fresnel_dielectric, 1963-1996
 KY_DEV float fresnel_dielectric(float cos_theta_i, float eta_i, float eta_t) {
     cos_theta_i = fminf(fmaxf(cos_theta_i, -1.f), 1.f);
@@ -586,6 +605,7 @@ KY_DEV BsdfSample bsdf_sample_local(const Bsdf& B, f3 wo, float u0, float u1) {
 // path vertex (isect_t, 642-690)
 // ---------------------------------------------------------------------------------------------
 struct Vertex {
+    float t;      // distance along the ray that found the vertex
     f3 position, normal;
     f3 wo_l;      // wo = -ray.direction (3125) in the shading frame
     Frame frame;
@@ -967,6 +987,7 @@ KY_DEV bool path_intersect(PathState& ps, Vertex& v, const DScene* __restrict__ 
 
     f3 emission = mk3(0, 0, 0);
     if (hit) {
+        v.t = t;
         v.position = ps.o + t * ps.d;
         v.normal = hit_normal(Lds.hit[hs], v.position, ps.d);
         v.surface = hs;
@@ -992,16 +1013,31 @@ KY_DEV bool path_intersect(PathState& ps, Vertex& v, const DScene* __restrict__ 
     return true;
 }
 
+// material->scattering's lobe decision on its own (3083, 2663): draws the plastic lobe number from the path's stream
+template <bool DEBUG_SAMPLER>
+KY_DEV int path_pick_lobe(PathState& ps, int surface, const LdsScene& Lds) {
+    const DMat& M = Lds.mat[Lds.hit[surface].material];
+    float lobe_u = 0.f;
+    if (M.kind == KY_MATERIAL_PLASTIC) lobe_u = sampler_next<DEBUG_SAMPLER>(ps.smp);
+    return pick_lobe(M, lobe_u);
+}
+
 // Second half: material, direct lighting, continuation.  WAVE-UNIFORM call: every lane of the wave calls it, `active`
 // says whether this lane holds a vertex.  Returns true when the (active) lane's path continues.
 template <bool DEBUG_SAMPLER>
-KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, const LdsScene& Lds, const RenderConst& rc, bool active) {
+KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, const LdsScene& Lds, const RenderConst& rc, bool active,
+                       int lobe = -1) {
     if (active) {
-        // material->scattering(isect) for the nearest hit (3083); only plastic draws a lobe number (2663)
+        // material->scattering(isect) for the nearest hit (3083); only plastic draws a lobe number (2663).
+        // lobe >= 0: the caller has already made that draw (path_pick_lobe).
         const DMat& M = Lds.mat[Lds.hit[v.surface].material];
-        float lobe_u = 0.f;
-        if (M.kind == KY_MATERIAL_PLASTIC) lobe_u = sampler_next<DEBUG_SAMPLER>(ps.smp);
-        v.bsdf = make_bsdf(M, lobe_u);
+        if (lobe < 0) {
+            float lobe_u = 0.f;
+            if (M.kind == KY_MATERIAL_PLASTIC) lobe_u = sampler_next<DEBUG_SAMPLER>(ps.smp);
+            v.bsdf = make_bsdf(M, lobe_u);
+        } else {
+            v.bsdf = make_bsdf_for_lobe(M, lobe);
+        }
         v.frame = make_frame(v.normal);
         v.wo_l = to_local(v.frame, -ps.d);   // ps.d still holds the direction of the ray that found this vertex
     }

@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -78,7 +79,8 @@ struct ShardConst {
 
 static bool valid_params(const ky_render_params* p) {
     if (!p) return false;
-    if (p->width <= 0 || p->height <= 0 || p->samples_per_pixel <= 0 || p->max_path_depth < 0) return false;
+    if (p->width <= 0 || p->height <= 0 || p->samples_per_pixel <= 0 || p->max_path_depth < 0 || p->max_path_depth > 250) return false;
+    if (p->width > 32767 || p->height > 32767) return false;
     if (p->tile_w <= 0 || p->tile_h <= 0 || (p->tile_w % 8) || (p->tile_h % 8)) return false;
     if (p->tile_first < 0 || p->tile_step <= 0) return false;
     switch (p->integrator) {
@@ -267,6 +269,8 @@ __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DSce
         }
     }
 }
+
+#include "ky_queue.hpp"   // the queue engine: render_kernel_q
 
 // fixed-point accumulator -> clamp01(L) (3726) -> fp32 tile buffer
 __global__ void resolve_kernel(const unsigned long long* __restrict__ accum, const unsigned* __restrict__ flags, float* __restrict__ tiles, int n_floats) {
@@ -579,6 +583,17 @@ static int pack_scene(const ky_scene* in, DScene* out) {
     return KY_OK;
 }
 
+// which render kernel runs path_tracing_iteration_t: the lane engine (render_kernel, default) or the queue engine (render_kernel_q)
+enum { KY_ENGINE_LANE = 0, KY_ENGINE_QUEUE = 1 };
+static int g_engine = -1;
+static int current_engine() {
+    if (g_engine < 0) {
+        const char* e = std::getenv("KYHIP_ENGINE");
+        g_engine = (e && (!std::strcmp(e, "queue") || !std::strcmp(e, "1"))) ? KY_ENGINE_QUEUE : KY_ENGINE_LANE;
+    }
+    return g_engine;
+}
+
 struct DeviceCtx {
     bool init = false;
     int cus = 0;
@@ -589,6 +604,7 @@ struct DeviceCtx {
     size_t ws_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int blocks_per_cu[3] = {0, 0, 0};
+    int q_blocks_per_cu[3] = {0, 0, 0};
     bool scene_valid = false;
 };
 static std::mutex g_mutex;
@@ -614,6 +630,9 @@ static int get_ctx(int device, DeviceCtx** out) {
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[0], render_kernel<false, KY_DIRECT_BOTH_MIS>, 256, 0));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[1], render_kernel<false, -1>, 256, 0));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[2], render_kernel<true, -1>, 256, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.q_blocks_per_cu[0], render_kernel_q<false, KY_DIRECT_BOTH_MIS>, QE_THREADS, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.q_blocks_per_cu[1], render_kernel_q<false, -1>, QE_THREADS, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.q_blocks_per_cu[2], render_kernel_q<true, -1>, QE_THREADS, 0));
         c.init = true;
     }
     *out = &c;
@@ -683,6 +702,19 @@ int kyhip_debug_lane_probe(unsigned long long* out32) {
 #endif
 
 const char* kyhip_last_error(void) { return g_error.c_str(); }
+#ifdef KY_QE_STATS
+int kyhip_debug_stats(unsigned long long* out32, int reset) {
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(kyd::g_qe_stats), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[32] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(kyd::g_qe_stats), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
+
+int kyhip_set_engine(int engine) {
+    const int prev = current_engine();
+    if (engine == KY_ENGINE_LANE || engine == KY_ENGINE_QUEUE) g_engine = engine;
+    return prev;
+}
 int kyhip_abi_version(void) { return KYHIP_ABI_VERSION; }
 int kyhip_device_count(void) {
     int n = 0;
@@ -741,15 +773,27 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
     HIP_TRY(hipMemsetAsync(c->d_counter, 0, sizeof(unsigned), stream));
 
     const int variant = dbg ? 2 : (p->direct_sample == KY_DIRECT_BOTH_MIS && p->integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION ? 0 : 1);
-    const int per_cu = c->blocks_per_cu[variant] > 0 ? c->blocks_per_cu[variant] : 1;
-    unsigned grid = (unsigned)(c->cus * per_cu);
-    const unsigned need_blocks = (sh.n_items + 3) / 4;
-    if (grid > need_blocks) grid = need_blocks;
-    if (grid < 1) grid = 1;
     HIP_TRY(hipEventRecord(c->ev0, stream));
-    if (variant == 0) hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_BOTH_MIS>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags);
-    else if (variant == 1) hipLaunchKernelGGL((render_kernel<false, -1>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags);
-    else hipLaunchKernelGGL((render_kernel<true, -1>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags);
+    // the queue engine implements path_tracing_iteration_t; every other integrator runs on the lane engine
+    if (current_engine() == KY_ENGINE_QUEUE && p->integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION) {
+        const int per_cu = c->q_blocks_per_cu[variant] > 0 ? c->q_blocks_per_cu[variant] : 1;
+        unsigned grid = (unsigned)(c->cus * per_cu);
+        const unsigned need_blocks = (sh.n_items * 64u + QE_SLOTS - 1) / QE_SLOTS;
+        if (grid > need_blocks) grid = need_blocks;
+        if (grid < 1) grid = 1;
+        if (variant == 0) hipLaunchKernelGGL((render_kernel_q<false, KY_DIRECT_BOTH_MIS>), dim3(grid), dim3(QE_THREADS), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags);
+        else if (variant == 1) hipLaunchKernelGGL((render_kernel_q<false, -1>), dim3(grid), dim3(QE_THREADS), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags);
+        else hipLaunchKernelGGL((render_kernel_q<true, -1>), dim3(grid), dim3(QE_THREADS), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags);
+    } else {
+        const int per_cu = c->blocks_per_cu[variant] > 0 ? c->blocks_per_cu[variant] : 1;
+        unsigned grid = (unsigned)(c->cus * per_cu);
+        const unsigned need_blocks = (sh.n_items + 3) / 4;
+        if (grid > need_blocks) grid = need_blocks;
+        if (grid < 1) grid = 1;
+        if (variant == 0) hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_BOTH_MIS>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags);
+        else if (variant == 1) hipLaunchKernelGGL((render_kernel<false, -1>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags);
+        else hipLaunchKernelGGL((render_kernel<true, -1>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, stream));
     const int nf = sh.n_pix * 3;

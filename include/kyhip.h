@@ -264,6 +264,43 @@ int kyhip_kat_occluded(int device, const ky_scene* scene, const float* in9, int 
 int kyhip_kat_li(int device, const ky_scene* scene, const ky_render_params* params,
                  int x, int y, int s0, int n, float* out3);
 
+/* ---- the smallpt lineage's own scene, in double precision -----------------------------------------
+   smallpt2pbrt/smallpt.cpp is the 99-line path tracer ky grew out of (smallpt_milo.cpp is its 256 x 256 build):
+   9 spheres -- the walls are spheres of radius 1e5, which is why ky's fp32 sphere test cannot render this scene
+    -- recursive radiance() with Russian roulette after 5 bounces and a two-way split at the glass
+   sphere for the first two bounces (smallpt.cpp:56-89), 2 x 2 subpixels with a tent filter, per-subpixel clamp
+   (91-118).  Random numbers: smallpt seeds erand48 per image ROW and walks the row sequentially (98); this library
+   gives every (pixel, subpixel, sample) its own stream keyed by (seed, pixel, subpixel, sample) and consumes numbers in
+   radiance()'s order, reflection subtree before transmission subtree. */
+enum ky_smallpt_refl { KY_SP_DIFF = 0, KY_SP_SPEC = 1, KY_SP_REFR = 2 };   /* Refl_t, smallpt.cpp:24 */
+
+typedef struct ky_smallpt_sphere {   /* struct Sphere, smallpt.cpp:26-39 */
+    double rad;
+    double p[3], e[3], c[3];         /* position, emission, colour */
+    int refl;
+    int pad_;
+} ky_smallpt_sphere;
+
+typedef struct ky_smallpt_params {
+    int width, height;
+    int samps;                       /* samples per SUBPIXEL (smallpt.cpp:92: argv[1] / 4); spp = 4 * samps */
+    uint32_t seed;
+    int max_depth;                   /* `if (depth > 10) return obj.e` (smallpt.cpp:63): 10 */
+} ky_smallpt_params;
+
+/* The scene of smallpt.cpp:42-52; `out` has room for 9 spheres.  Returns 9.  Pure host code. */
+int kyhip_smallpt_scene(ky_smallpt_sphere* out);
+
+/* main()'s loop nest (smallpt.cpp:91-118) with the fixed camera of 93-94.  image_rgb: width * height * 3 doubles in
+   smallpt's own order, c[(height - y - 1) * width + x], i.e. row 0 is the TOP of the picture; the image is overwritten. */
+int kyhip_smallpt_render(int device, const ky_smallpt_sphere* spheres, int n_spheres, const ky_smallpt_params* params,
+                         double* image_rgb);
+
+/* radiance(Ray(cam.o + d * 140, d.norm()), 0, Xi) (smallpt.cpp:109) for samples [s0, s0 + n) of subpixel (sx, sy) of
+   pixel (x, y): 3 doubles per sample, unclamped. */
+int kyhip_smallpt_kat_radiance(int device, const ky_smallpt_sphere* spheres, int n_spheres, const ky_smallpt_params* params,
+                               int x, int y, int sx, int sy, int s0, int n, double* out3);
+
 #ifdef __cplusplus
 }
 #endif

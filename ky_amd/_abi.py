@@ -72,6 +72,18 @@ SP = C.POINTER(Scene)
 PP = C.POINTER(RenderParams)
 
 # every symbol include/kyhip.h declares: name -> (restype, argtypes)
+class SmallptSphere(C.Structure):   # ky_smallpt_sphere
+    _fields_ = [("rad", C.c_double), ("p", C.c_double * 3), ("e", C.c_double * 3), ("c", C.c_double * 3), ("refl", C.c_int), ("pad_", C.c_int)]
+
+
+class SmallptParams(C.Structure):   # ky_smallpt_params
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("samps", C.c_int), ("seed", C.c_uint32), ("max_depth", C.c_int)]
+
+
+SP_DIFF, SP_SPEC, SP_REFR = 0, 1, 2
+SSP = C.POINTER(SmallptSphere)
+SPP = C.POINTER(SmallptParams)
+
 KYHIP_SYMBOLS = {
     "kyhip_last_error": (C.c_char_p, []),
     "kyhip_set_engine": (C.c_int, [C.c_int]),
@@ -84,6 +96,9 @@ KYHIP_SYMBOLS = {
     "kyhip_render_tiles_device": (C.c_int, [C.c_int, SP, PP, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "kyhip_film_add_tiles_device": (C.c_int, [C.c_int, PP, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "kyhip_kernel_ms": (C.c_float, [C.c_int]),
+    "kyhip_smallpt_scene": (C.c_int, [SSP]),
+    "kyhip_smallpt_render": (C.c_int, [C.c_int, SSP, C.c_int, SPP, C.c_void_p]),
+    "kyhip_smallpt_kat_radiance": (C.c_int, [C.c_int, SSP, C.c_int, SPP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "kyhip_kat_intersect": (C.c_int, [C.c_int, C.POINTER(Shape), C.c_void_p, C.c_int, C.c_void_p]),
     "kyhip_kat_camera": (C.c_int, [C.c_int, C.POINTER(Camera), C.c_void_p, C.c_int, C.c_void_p]),
     "kyhip_kat_bsdf": (C.c_int, [C.c_int, C.POINTER(Material), C.c_void_p, C.c_int, C.c_void_p]),

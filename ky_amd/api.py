@@ -165,6 +165,36 @@ def kat_li(scene, params, x, y, s0, n, device=0):
     return out
 
 
+# ---- smallpt's own scene in double precision --------------------------------------
+
+def smallpt_scene():
+    """The 9 spheres of smallpt2pbrt/smallpt.cpp:42-52 as a ctypes array."""
+    spheres = (A.SmallptSphere * 9)()
+    n = A.load_kyhip().kyhip_smallpt_scene(spheres)
+    assert n == 9
+    return spheres
+
+
+def smallpt_params(width, height, samps, seed=1234, max_depth=10):
+    return A.SmallptParams(width, height, samps, seed, max_depth)
+
+
+def smallpt_render(spheres, params, device=0):
+    """kyhip_smallpt_render: smallpt's main() loop nest on the GPU; returns float64 [H, W, 3], row 0 = top of the picture."""
+    lib = A.load_kyhip()
+    img = np.zeros((params.height, params.width, 3), np.float64)
+    _check(lib.kyhip_smallpt_render(device, spheres, len(spheres), C.byref(params), img.ctypes.data_as(C.c_void_p)), lib)
+    return img
+
+
+def smallpt_kat_radiance(spheres, params, x, y, sx, sy, s0, n, device=0):
+    lib = A.load_kyhip()
+    out = np.zeros((n, 3), np.float64)
+    _check(lib.kyhip_smallpt_kat_radiance(device, spheres, len(spheres), C.byref(params), x, y, sx, sy, s0, n,
+                                          out.ctypes.data_as(C.c_void_p)), lib)
+    return out
+
+
 def store_image(filename, rgb, kind="bmp"):
     """film_t::store_{ppm,bmp,hdr}_impl -- ky.cpp:1646-1782."""
     host = A.load_kyhost()

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "ky_device.hpp"
+#include "ky_smallpt.hpp"
 
 using namespace kyd;
 
@@ -941,6 +942,96 @@ int kyhip_kat_li(int device, const ky_scene* scene, const ky_render_params* p, i
         else hipLaunchKernelGGL(kat_li_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, 0, c->d_scene, rc, x, y, s0, n, d_out);
         return (int)KY_OK;
     });
+}
+
+// ---- smallpt's scene in double precision (ky_smallpt.hpp) ----
+int kyhip_smallpt_scene(ky_smallpt_sphere* out) {
+    if (!out) return fail(KY_ERR_INVALID_VALUE, "null output");
+    struct Row { double rad, p[3], e[3], c[3]; int refl; };
+    static const Row rows[9] = {   // smallpt.cpp:42-52
+        {1e5, {1e5 + 1, 40.8, 81.6}, {0, 0, 0}, {.75, .25, .25}, KY_SP_DIFF},     // Left
+        {1e5, {-1e5 + 99, 40.8, 81.6}, {0, 0, 0}, {.25, .25, .75}, KY_SP_DIFF},   // Rght
+        {1e5, {50, 40.8, 1e5}, {0, 0, 0}, {.75, .75, .75}, KY_SP_DIFF},           // Back
+        {1e5, {50, 40.8, -1e5 + 170}, {0, 0, 0}, {0, 0, 0}, KY_SP_DIFF},          // Frnt
+        {1e5, {50, 1e5, 81.6}, {0, 0, 0}, {.75, .75, .75}, KY_SP_DIFF},           // Botm
+        {1e5, {50, -1e5 + 81.6, 81.6}, {0, 0, 0}, {.75, .75, .75}, KY_SP_DIFF},   // Top
+        {16.5, {27, 16.5, 47}, {0, 0, 0}, {1 * .999, 1 * .999, 1 * .999}, KY_SP_SPEC},   // Mirr
+        {16.5, {73, 16.5, 78}, {0, 0, 0}, {1 * .999, 1 * .999, 1 * .999}, KY_SP_REFR},   // Glas
+        {600, {50, 681.6 - .27, 81.6}, {12, 12, 12}, {0, 0, 0}, KY_SP_DIFF}};     // Lite
+    for (int i = 0; i < 9; ++i) {
+        out[i].rad = rows[i].rad;
+        for (int j = 0; j < 3; ++j) { out[i].p[j] = rows[i].p[j]; out[i].e[j] = rows[i].e[j]; out[i].c[j] = rows[i].c[j]; }
+        out[i].refl = rows[i].refl;
+        out[i].pad_ = 0;
+    }
+    return 9;
+}
+
+static int smallpt_check(const ky_smallpt_sphere* spheres, int n, const ky_smallpt_params* p) {
+    if (!spheres || !p) return fail(KY_ERR_INVALID_VALUE, "null argument");
+    if (n <= 0 || n > kysp::SP_MAX_SPHERES) return fail(KY_ERR_INVALID_VALUE, "1..%d spheres", kysp::SP_MAX_SPHERES);
+    if (p->width <= 0 || p->height <= 0 || p->width > 16384 || p->height > 16384 || p->samps <= 0 || p->max_depth < 0)
+        return fail(KY_ERR_INVALID_VALUE, "invalid smallpt params");
+    for (int i = 0; i < n; ++i)
+        if (spheres[i].refl < KY_SP_DIFF || spheres[i].refl > KY_SP_REFR || !(spheres[i].rad > 0)) return fail(KY_ERR_INVALID_VALUE, "sphere %d is invalid", i);
+    return KY_OK;
+}
+
+int kyhip_smallpt_render(int device, const ky_smallpt_sphere* spheres, int n, const ky_smallpt_params* p, double* image_rgb) {
+    int rcode = smallpt_check(spheres, n, p);
+    if (rcode != KY_OK) return rcode;
+    if (!image_rgb) return fail(KY_ERR_INVALID_VALUE, "null image");
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceCtx* c = nullptr;
+    rcode = get_ctx(device, &c);
+    if (rcode != KY_OK) return rcode;
+    kysp::SpSphere packed[kysp::SP_MAX_SPHERES];
+    kysp::sp_pack(spheres, n, packed);
+    kysp::SpConst k;
+    kysp::sp_make_const(p, n, k);
+    const size_t n_px = (size_t)p->width * p->height;
+    kysp::SpSphere* d_sph = nullptr;
+    double *d_sub = nullptr, *d_img = nullptr;
+    HIP_TRY(hipMalloc(&d_sph, sizeof(packed)));
+    HIP_TRY(hipMalloc(&d_sub, n_px * 12 * sizeof(double)));
+    HIP_TRY(hipMalloc(&d_img, n_px * 3 * sizeof(double)));
+    HIP_TRY(hipMemcpy(d_sph, packed, sizeof(packed), hipMemcpyHostToDevice));
+    const int blocks = ((p->width + 7) / 8) * ((p->height + 7) / 8);
+    HIP_TRY(hipEventRecord(c->ev0, 0));
+    hipLaunchKernelGGL(kysp::smallpt_kernel, dim3(blocks), dim3(256), 0, 0, d_sph, k, d_sub);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, 0));
+    hipLaunchKernelGGL(kysp::smallpt_resolve_kernel, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, 0, d_sub, d_img, p->width, p->height);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(image_rgb, d_img, n_px * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(d_sph)); HIP_TRY(hipFree(d_sub)); HIP_TRY(hipFree(d_img));
+    return KY_OK;
+}
+
+int kyhip_smallpt_kat_radiance(int device, const ky_smallpt_sphere* spheres, int n_spheres, const ky_smallpt_params* p,
+                               int x, int y, int sx, int sy, int s0, int n, double* out3) {
+    int rcode = smallpt_check(spheres, n_spheres, p);
+    if (rcode != KY_OK) return rcode;
+    if (!out3 || n <= 0 || s0 < 0 || x < 0 || y < 0 || x >= p->width || y >= p->height || (sx | sy) < 0 || sx > 1 || sy > 1)
+        return fail(KY_ERR_INVALID_VALUE, "bad KAT arguments");
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceCtx* c = nullptr;
+    rcode = get_ctx(device, &c);
+    if (rcode != KY_OK) return rcode;
+    kysp::SpSphere packed[kysp::SP_MAX_SPHERES];
+    kysp::sp_pack(spheres, n_spheres, packed);
+    kysp::SpConst k;
+    kysp::sp_make_const(p, n_spheres, k);
+    kysp::SpSphere* d_sph = nullptr;
+    double* d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_sph, sizeof(packed)));
+    HIP_TRY(hipMalloc(&d_out, (size_t)n * 3 * sizeof(double)));
+    HIP_TRY(hipMemcpy(d_sph, packed, sizeof(packed), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kysp::smallpt_kat_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d_sph, k, x, y, sx, sy, s0, n, d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out3, d_out, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(d_sph)); HIP_TRY(hipFree(d_out));
+    return KY_OK;
 }
 
 }  // extern "C"

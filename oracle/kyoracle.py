@@ -40,6 +40,9 @@ def load():
         _lib.kyo_kat_occluded.argtypes = [A.SP, C.c_void_p, C.c_int, C.c_void_p]
         _lib.kyo_world_bounding_sphere.argtypes = [A.SP, C.c_void_p]
         _lib.kyo_max_threads.restype = C.c_int
+        _lib.kyo_smallpt_render.argtypes = [A.SSP, C.c_int, A.SPP, C.c_int, C.c_void_p]
+        _lib.kyo_smallpt_radiance.argtypes = [A.SSP, C.c_int, A.SPP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _lib.kyo_smallpt_scene.argtypes = [A.SSP]
     return _lib
 
 
@@ -132,3 +135,28 @@ def world_bounding_sphere(scene):
 
 def max_threads():
     return int(load().kyo_max_threads())
+
+
+# ---- smallpt_oracle.cpp: smallpt2pbrt/smallpt.cpp restated (double precision) ----
+
+def smallpt_scene():
+    spheres = (A.SmallptSphere * 9)()
+    assert load().kyo_smallpt_scene(spheres) == 9
+    return spheres
+
+
+def smallpt_render(spheres, params, rng_mode=0):
+    """rng_mode 0: the HIP path's per-sample streams; 1: smallpt's own erand48 walk along each image row."""
+    img = np.zeros((params.height, params.width, 3), np.float64)
+    rc = load().kyo_smallpt_render(spheres, len(spheres), C.byref(params), rng_mode, img.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise ValueError(f"kyo_smallpt_render returned {rc}")
+    return img
+
+
+def smallpt_radiance(spheres, params, x, y, sx, sy, s0, n):
+    out = np.zeros((n, 3), np.float64)
+    rc = load().kyo_smallpt_radiance(spheres, len(spheres), C.byref(params), x, y, sx, sy, s0, n, out.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise ValueError(f"kyo_smallpt_radiance returned {rc}")
+    return out

@@ -471,3 +471,72 @@ def test_engines_agree(A, api):
                 assert np.array_equal(a, b)
     finally:
         lib.kyhip_set_engine(prev)
+
+
+def test_edge_cases(A, api, O):
+    """Empty, ragged and maximum-size inputs (the reference has no tests of its own; these are the boundaries of the C ABI)."""
+    from helpers import CustomScene, make_light, make_material, make_shape
+    cam_handle = api.cornell_box_scene(A.CB_DEFAULT_SCENE, 40, 24)
+    cam = A.Camera.from_buffer_copy(cam_handle.c.camera)
+    lib = A.load_kyhip()
+
+    # (1) nothing in the scene: every path misses; black without an environment light, its radiance (clamped) with one
+    empty = CustomScene(A, cam, [make_shape(A, A.SHAPE_SPHERE, [(0, 0, 0)], radius=1.0)], [make_material(A, A.MATERIAL_MATTE, (1, 1, 1))], [], [])
+    empty.scene.surface_count = 0
+    assert api.render(empty, api.make_params(40, 24, 4)).max() == 0
+    env = CustomScene(A, cam, [make_shape(A, A.SHAPE_SPHERE, [(0, 0, 0)], radius=1.0)], [make_material(A, A.MATERIAL_MATTE, (1, 1, 1))],
+                      [make_light(A, A.LIGHT_ENVIRONMENT, (0.25, 0.5, 2.0), world_radius=1.0)], [], environment_light=0)
+    env.scene.surface_count = 0
+    img = api.render(env, api.make_params(40, 24, 4))
+    assert np.allclose(img, np.array([0.25, 0.5, 1.0], np.float32))
+    assert np.array_equal(img, O.render(env, api.make_params(40, 24, 4)))
+
+    # (2) ragged frames: 1 x 1, a prime-sized frame, one sample, depth 0 (emission of the first hit only) and a deep path cap
+    cornell = api.cornell_box_scene(A.CB_DEFAULT_SCENE, 13, 7)
+    for (w, h, spp, depth) in ((1, 1, 1, 5), (13, 7, 3, 5), (13, 7, 64, 0), (13, 7, 16, 250)):
+        sc = api.cornell_box_scene(A.CB_DEFAULT_SCENE, w, h)
+        p = api.make_params(w, h, spp, max_path_depth=depth)
+        g, c = api.render(sc, p), O.render(sc, p)
+        assert g.shape == (h, w, 3) and np.isfinite(g).all()
+        assert rmse(g, c) < 0.05 / np.sqrt(spp) + 1e-6, (w, h, spp, depth, rmse(g, c))
+    d0 = api.render(cornell, api.make_params(13, 7, 8, max_path_depth=0))
+    assert set(np.unique(d0)) <= {0.0, 1.0}        # only the light's own surface shows (radiance 25, clamped)
+
+    # (3) the largest scene the ABI accepts: KYHIP_MAX_SURFACES surfaces, KYHIP_MAX_LIGHTS lights (5 walls + 59 small spheres,
+    # 16 of them emitters) -- and one surface more is refused with KY_ERR_LIMIT, not truncated
+    box_handle = api.cornell_box_scene(A.CB_DEFAULT_SCENE, 40, 24)   # keep the handle alive while its flat view is read
+    box = box_handle.c
+    shapes = [A.Shape.from_buffer_copy(box.shapes[box.surfaces[i].shape]) for i in range(5)]
+    mats = [make_material(A, A.MATERIAL_MATTE, (0.7, 0.7, 0.7)), make_material(A, A.MATERIAL_MATTE, (0, 0, 0)), make_material(A, A.MATERIAL_MIRROR, (0.9, 0.9, 0.9)),
+            make_material(A, A.MATERIAL_PLASTIC, (0.3, 0.2, 0.1), (0.5, 0.5, 0.5), exponent=20.0)]
+    surfaces = [A.Surface(i, 0, -1) for i in range(5)]
+    lights = []
+    r = np.random.default_rng(3)
+    for k in range(60):
+        shapes.append(make_shape(A, A.SHAPE_SPHERE, [(r.uniform(-1.0, 1.0), r.uniform(-1.0, 1.0), r.uniform(-1.1, 1.0))], radius=0.08))
+        if k < 16:
+            lights.append(make_light(A, A.LIGHT_AREA, (6 + k, 20 - k, 10), shape=5 + k))
+            surfaces.append(A.Surface(5 + k, 1, k))
+        else:
+            surfaces.append(A.Surface(5 + k, 2 + (k & 1), -1))
+    cam40 = A.Camera.from_buffer_copy(box.camera)
+    full = CustomScene(A, cam40, shapes[:64], mats, lights, surfaces[:64])
+    p = api.make_params(40, 24, 64)
+    g, c = api.render(full, p), O.render(full, p)
+    assert g.mean() > 0.05 and rmse(g, c) < film_tolerance(64), rmse(g, c)
+    too_many = CustomScene(A, cam40, shapes, mats, lights, surfaces)
+    film = np.zeros((24, 40, 3), np.float32)
+    import ctypes as C
+    assert lib.kyhip_render(0, too_many.flat, C.byref(p), film.ctypes.data_as(C.c_void_p), 40) == A.KY_ERR_LIMIT
+    assert film.max() == 0
+
+    # (4) a camera INSIDE a glass sphere (total internal reflection on the way out) and inside a sphere light
+    inside = CustomScene(A, cam40, [make_shape(A, A.SHAPE_SPHERE, [tuple(cam40.position)], radius=0.5), shapes[0], shapes[1], shapes[2], shapes[3], shapes[4],
+                                    make_shape(A, A.SHAPE_SPHERE, [(0.0, 0.0, 0.9)], radius=0.25)],
+                         [make_material(A, A.MATERIAL_GLASS, (1, 1, 1), (1, 1, 1), eta=1.6), mats[0], mats[1]],
+                         [make_light(A, A.LIGHT_AREA, (30, 30, 30), shape=6)],
+                         [A.Surface(0, 0, -1)] + [A.Surface(i, 1, -1) for i in range(1, 6)] + [A.Surface(6, 2, 0)])
+    p = api.make_params(40, 24, 256)
+    g, c = api.render(inside, p), O.render(inside, p)
+    fin = np.isfinite(c).all(axis=2)
+    assert g.mean() > 0.01 and rmse(g[fin], c[fin]) < film_tolerance(256), rmse(g[fin], c[fin])

@@ -43,6 +43,26 @@ __device__ unsigned long long g_lane_probe[32];
 #define KY_PROBE(k) do { } while (0)
 #endif
 
+// phase clocks (debug builds with -DKY_PROFILE_CLOCKS): KY_CLK(k) charges the wave's time since its previous mark to bucket k
+#ifdef KY_PROFILE_CLOCKS
+__device__ unsigned long long g_clk[16];
+__device__ __noinline__ void ky_clk_mark(int k) {
+    __shared__ unsigned long long last[16], acc[16][16];
+    const int w = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(1);
+    if ((int)__lane_id() == __ffsll((long long)m) - 1) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (k == -1) { for (int i = 0; i < 16; ++i) acc[w][i] = 0; }
+        else if (k == -2) { for (int i = 0; i < 16; ++i) atomicAdd(&g_clk[i], acc[w][i]); }
+        else acc[w][k] += t - last[w];
+        last[w] = __builtin_amdgcn_s_memtime();
+    }
+}
+#define KY_CLK(k) ky_clk_mark(k)
+#else
+#define KY_CLK(k) do { } while (0)
+#endif
+
 namespace kyd {
 
 // ---------------------------------------------------------------------------------------------
@@ -76,6 +96,15 @@ KY_DEV float length_sq(f3 a) { return dot(a, a); }
 KY_DEV f3 normalize(f3 a) { return a * rsq(dot(a, a)); }  // vec3_t::normalize, 314
 KY_DEV float max3(f3 a) { return fmaxf(a.x, fmaxf(a.y, a.z)); }
 KY_DEV bool is_black(f3 c) { return (c.x <= 0) && (c.y <= 0) && (c.z <= 0); }  // color_t::is_black, 258
+
+// float -> 32.32 fixed point (|a| <= 2e9): exact for |a| >= 2^-8, truncated below
+KY_DEV long long to_fixed32(float a) {
+    const float aa = fabsf(a);
+    const float hi = floorf(aa);
+    const float fr = aa - hi;
+    const unsigned long long v = ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)(fr * 4294967296.0f);
+    return a < 0 ? -(long long)v : (long long)v;
+}
 
 constexpr float K_PI = 3.14159265358979323846f;
 constexpr float K_INV_PI = 0.318309886183790671538f;
@@ -161,20 +190,29 @@ struct DPar {  // planar parallelogram, 48 B: q0 = (n, n.p0), q1 = (a*, a*.p1 + 
 struct DSph {  // sphere, 16 B: centre, radius^2
     float4 c;
 };
+// axis-aligned rectangle in the plane x_axis = c, 32 B.  With (u, v) = the other two axes in cyclic order and [lo, hi] the
+// rectangle's extent along them: q0 = (c, su, ou, sv), q1.x = ov with s = 1 / (hi - lo), o = lo * s + 0.5, so that a point h
+// of the plane is inside iff |h_u su - ou| <= 0.5 and |h_v sv - ov| <= 0.5 (the parallelogram test's convention).
+struct DAar {
+    float4 q0, q1;
+};
 
-// The surfaces are stored SORTED BY TRAVERSAL KIND -- parallelograms, then spheres, then everything else -- keeping the
+// The surfaces are stored SORTED BY TRAVERSAL KIND -- axis-aligned rectangles (x, y, z planes), other parallelograms, then
+// spheres, then everything else -- keeping the
 // reference's surface order inside each group, so that each traversal loop is branch-free.  `hit[]` and every surface
 // index used on the device are in this sorted order; orig[] maps back to the caller's surface index.  (Ties: the
 // reference's "first surface in list order wins an exactly equal distance" (3177-3180) is preserved inside a group;
 // an exact tie between shapes of different kinds has measure zero.)
 struct DScene {
     int32_t n_surfaces, n_lights, n_materials, env_light;
-    int32_t n_par, n_sph, n_gen, pad_n;
+    int32_t n_par, n_sph, n_gen, n_aar;   // n_aar = n_aar_axis[0] + [1] + [2]
+    int32_t n_aar_axis[3], pad_n;         // rectangles per axis plane (x, y, z), stored in that order
     float cam_position[3], cam_inv_w;
     float cam_front[3], cam_inv_h;
     float cam_right[3], pad0;
     float cam_up[3], pad1;
-    DPar par[KYHIP_MAX_SURFACES + 1];   // one readable record past the end: the traversal prefetches i + 1
+    DAar aar[KYHIP_MAX_SURFACES + 1];   // grouped by axis; one readable record past the end: the traversal reads i + 1
+    DPar par[KYHIP_MAX_SURFACES + 1];
     DSph sph[KYHIP_MAX_SURFACES + 1];
     DSurf gen[KYHIP_MAX_SURFACES];
     DSurf all[KYHIP_MAX_SURFACES];      // every surface as a generic record, sorted order (carrier tests, surface-parallel queries)
@@ -311,6 +349,42 @@ KY_DEV bool par_hit(const float4 q0, const float4 q1, const float4 q2, f3 o, f3 
     return (fabsf(u) <= 0.5f) & (fabsf(v) <= 0.5f) & (t > K_SHAPE_EPS) & (t < tmax);
 }
 
+// rectangle_t::intersect (1261-1297) for a rectangle in an axis plane: the plane hit is one subtraction and one multiply
+// by the ray's reciprocal direction, the inside test needs only the two in-plane coordinates (12 VALU instead of 26).
+// A zero direction component gives inf / NaN, which compare false.
+template <int AXIS>
+KY_DEV bool aar_hit(const float4 q0, const float ov, f3 o, f3 d, f3 inv_d, float tmax, float& t_out) {
+    const float oa = AXIS == 0 ? o.x : (AXIS == 1 ? o.y : o.z), ia = AXIS == 0 ? inv_d.x : (AXIS == 1 ? inv_d.y : inv_d.z);
+    const float ou_ = AXIS == 0 ? o.y : (AXIS == 1 ? o.z : o.x), du_ = AXIS == 0 ? d.y : (AXIS == 1 ? d.z : d.x);
+    const float ov_ = AXIS == 0 ? o.z : (AXIS == 1 ? o.x : o.y), dv_ = AXIS == 0 ? d.z : (AXIS == 1 ? d.x : d.y);
+    const float t = (q0.x - oa) * ia;
+    const float u = (ou_ + t * du_) * q0.y - q0.z;
+    const float v = (ov_ + t * dv_) * q0.w - ov;
+    t_out = t;
+    return (fabsf(u) <= 0.5f) & (fabsf(v) <= 0.5f) & (t > K_SHAPE_EPS) & (t < tmax);
+}
+
+// the axis-aligned rectangles of one axis: records [first, first + n) of S->aar, whose sorted surface indices are the same
+template <int AXIS, bool NEAREST>
+KY_DEV void aar_scan(const DScene* __restrict__ S, int first, int n, f3 o, f3 d, f3 inv_d, float& tmax, int& best, bool& occ) {
+    if (n <= 0) return;
+    float4 q0 = S->aar[first].q0;
+    float ov = S->aar[first].q1.x;
+    for (int i = first; i < first + n; ++i) {
+        const float4 n0 = S->aar[i + 1].q0;   // record n_aar exists (padding)
+        const float nv = S->aar[i + 1].q1.x;
+        float t;
+        const bool ok = aar_hit<AXIS>(q0, ov, o, d, inv_d, tmax, t);
+        if (NEAREST) {
+            tmax = ok ? t : tmax;
+            best = ok ? i : best;
+        } else {
+            occ = occ | ok;
+        }
+        q0 = n0; ov = nv;
+    }
+}
+
 // sphere_t::intersect, 1336-1393.  sqrt of a negative discriminant is NaN, which fails both range tests.
 KY_DEV bool sph_hit(const float4 c, f3 o, f3 d, float tmax, float& t_out) {
     const f3 oc = mk3(c.x, c.y, c.z) - o;
@@ -337,7 +411,15 @@ KY_DEV bool surf_hit(const DSurf& S, const DShapeFull* __restrict__ full, f3 o, 
 // overlaps the VALU work instead of being exposed once per surface.
 KY_DEV int trace_nearest(const DScene* __restrict__ S, f3 o, f3 d, float& tmax) {
     int best = -1;
-    const int n_par = S->n_par, n_sph = S->n_sph, n_gen = S->n_gen;
+    const int n_aar = S->n_aar, n_par = S->n_par, n_sph = S->n_sph, n_gen = S->n_gen;
+    if (n_aar > 0) {
+        const f3 inv_d = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
+        bool unused = false;
+        const int n0 = S->n_aar_axis[0], n1 = S->n_aar_axis[1], n2 = S->n_aar_axis[2];
+        aar_scan<0, true>(S, 0, n0, o, d, inv_d, tmax, best, unused);
+        aar_scan<1, true>(S, n0, n1, o, d, inv_d, tmax, best, unused);
+        aar_scan<2, true>(S, n0 + n1, n2, o, d, inv_d, tmax, best, unused);
+    }
     if (n_par > 0) {
         float4 q0 = S->par[0].q0, q1 = S->par[0].q1, q2 = S->par[0].q2;
         for (int i = 0; i < n_par; ++i) {
@@ -345,7 +427,7 @@ KY_DEV int trace_nearest(const DScene* __restrict__ S, f3 o, f3 d, float& tmax) 
             float t;
             const bool ok = par_hit(q0, q1, q2, o, d, tmax, t);
             tmax = ok ? t : tmax;
-            best = ok ? i : best;
+            best = ok ? n_aar + i : best;
             q0 = n0; q1 = n1; q2 = n2;
         }
     }
@@ -356,7 +438,7 @@ KY_DEV int trace_nearest(const DScene* __restrict__ S, f3 o, f3 d, float& tmax) 
             float t;
             const bool ok = sph_hit(c, o, d, tmax, t);
             tmax = ok ? t : tmax;
-            best = ok ? n_par + i : best;
+            best = ok ? n_aar + n_par + i : best;
             c = nc;
         }
     }
@@ -364,7 +446,7 @@ KY_DEV int trace_nearest(const DScene* __restrict__ S, f3 o, f3 d, float& tmax) 
         float t;
         if (full_shape_hit(S->full[S->gen[i].full], o, d, tmax, t)) {
             tmax = t;
-            best = n_par + n_sph + i;
+            best = n_aar + n_par + n_sph + i;
         }
     }
     return best;
@@ -373,8 +455,16 @@ KY_DEV int trace_nearest(const DScene* __restrict__ S, f3 o, f3 d, float& tmax) 
 // scene_t::occluded's traversal (3193-3195): any hit inside (eps, tmax) occludes.
 KY_DEV bool trace_any(const DScene* __restrict__ S, f3 o, f3 d, float tmax) {
     bool occ = false;
-    const int n_par = S->n_par, n_sph = S->n_sph, n_gen = S->n_gen;
+    const int n_aar = S->n_aar, n_par = S->n_par, n_sph = S->n_sph, n_gen = S->n_gen;
     float t;
+    if (n_aar > 0) {
+        const f3 inv_d = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
+        int unused = -1;
+        const int n0 = S->n_aar_axis[0], n1 = S->n_aar_axis[1], n2 = S->n_aar_axis[2];
+        aar_scan<0, false>(S, 0, n0, o, d, inv_d, tmax, unused, occ);
+        aar_scan<1, false>(S, n0, n1, o, d, inv_d, tmax, unused, occ);
+        aar_scan<2, false>(S, n0 + n1, n2, o, d, inv_d, tmax, unused, occ);
+    }
     if (n_par > 0) {
         float4 q0 = S->par[0].q0, q1 = S->par[0].q1, q2 = S->par[0].q2;
         for (int i = 0; i < n_par; ++i) {
@@ -881,6 +971,7 @@ KY_DEV f3 estimate_by_emitter(const DScene* __restrict__ S, const LdsScene& Lds,
     KY_PROBE(3);
     const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1);
     const bool dead = is_black(ls.Li) || (MIS ? (ls.pdf <= 0) : (ls.pdf == 0));
+    KY_CLK(5);
     if (!dead) {
         // scene_t::occluded(isect, ls.position), 3187-3201
         const f3 to = ls.position - v.position;
@@ -891,6 +982,7 @@ KY_DEV f3 estimate_by_emitter(const DScene* __restrict__ S, const LdsScene& Lds,
         const f3 o = offset_ray_origin(v.position, v.normal, dir);
         KY_PROBE(4);
         const bool occ = trace_any(S, o, dir, dist - 2e-3f);
+        KY_CLK(6);
         if (!occ) {
             KY_PROBE(5);
             f3 f;
@@ -902,6 +994,7 @@ KY_DEV f3 estimate_by_emitter(const DScene* __restrict__ S, const LdsScene& Lds,
                 if (!MIS || delta_light) Ld = (f_cos * ls.Li) * rcp(ls.pdf);          // 3956 / 4057
                 else Ld = (f_cos * ls.Li) * (2.f * rcp(ls.pdf + bsdf_pdf));            // 4070
             }
+            KY_CLK(7);
         }
     }
     return Ld;
@@ -920,8 +1013,10 @@ KY_DEV f3 sample_all_light(const DScene* __restrict__ S, const LdsScene& Lds, co
             ub0 = sampler_next<DEBUG_SAMPLER>(smp); ub1 = sampler_next<DEBUG_SAMPLER>(smp);
             ul0 = sampler_next<DEBUG_SAMPLER>(smp); ul1 = sampler_next<DEBUG_SAMPLER>(smp);
         }
+        KY_CLK(3);
         if (strategy == KY_DIRECT_BOTH_MIS) {  // 4076-4088
             const f3 Lb = estimate_by_bsdf<true>(S, Lds, v, li, ub0, ub1, active);
+            KY_CLK(4);
             f3 Ll = mk3(0, 0, 0);
             if (active) Ll = estimate_by_emitter<true>(S, Lds, v, li, ul0, ul1);
             Ld = Ld + (0.5f * Lb + 0.5f * Ll);
@@ -1054,6 +1149,7 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, c
         return false;
     }
 
+    KY_CLK(2);
     const bool recursion = rc.integrator == KY_INTEGRATOR_PATH_TRACING_RECURSION;
     const bool defered = rc.integrator == KY_INTEGRATOR_PATH_TRACING_RECURSION_DEFERED;
     const bool simple = rc.integrator == KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION;
@@ -1064,6 +1160,7 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, c
         const f3 Ld = sample_all_light<DEBUG_SAMPLER>(S, Lds, v, ps.smp, rc.strategy, nee);  // 4575 / 4337 / 4458
         if (nee) ps.Lo = ps.Lo + ps.beta * Ld;
     }
+    KY_CLK(8);
     if (rc.integrator == KY_INTEGRATOR_DIRECT_LIGHTING) return false;  // 4153
     if (!active) return false;
 

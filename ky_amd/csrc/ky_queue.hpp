@@ -77,15 +77,6 @@ __device__ unsigned long long g_qe_stats[32];   // [q] batches, [8+q] lanes, [16
 KY_DEV unsigned lds_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 KY_DEV int lds_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-// float -> 32.32 fixed point (|a| <= 2e9): exact for |a| >= 2^-8, truncated below
-KY_DEV long long to_fixed32(float a) {
-    const float aa = fabsf(a);
-    const float hi = floorf(aa);
-    const float fr = aa - hi;
-    const unsigned long long v = ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)(fr * 4294967296.0f);
-    return a < 0 ? -(long long)v : (long long)v;
-}
-
 // L = L + Li * (1. / spp) (3717-3721) for one finished sample, straight into the pixel's fixed-point accumulator
 KY_DEV void film_add_sample(unsigned long long* __restrict__ accum, unsigned* __restrict__ flags, int pix, f3 L) {
     const float v[3] = {L.x, L.y, L.z};

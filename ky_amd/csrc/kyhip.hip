@@ -17,6 +17,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -162,7 +163,9 @@ __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DSce
     f3 Lsum = mk3(0, 0, 0);
     PathState ps;
 
+    KY_CLK(-1);
     for (;;) {
+        KY_CLK(9);   // continuation sampling, roulette, loop overhead
         // ---- (1) lanes whose pixel chunk is finished flush it and take the next (item, pixel) pair of the wave's pool.
         // A lane is NOT tied to one pixel position: whichever lane is free takes the next pixel, so lanes never wait
         // for each other and the wave drains within one chunk of the end of the queue.
@@ -228,6 +231,7 @@ __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DSce
             }
             cursor = min(cursor + n_need, fetched * 64);
         }
+        KY_CLK(0);
         // ---- (2) regenerate + trace until enough lanes hold a vertex ----
         // A lane whose path ends at the traversal itself (a miss, the depth cap) would sit out the whole shading phase,
         // which costs 2 traversals per light.  When many lanes are in that state, they regenerate and trace once more
@@ -256,6 +260,7 @@ __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DSce
             const int idle = __popcll(__ballot(!alive && !done && s < s_end));
             if (idle * (2 * nee_weight + 1) < 40) break;
         }
+        KY_CLK(1);
         if (!__any(alive)) {
             if (__all(done)) break;
             continue;  // lanes are between items: (1) serves them on the next turn
@@ -269,6 +274,7 @@ __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DSce
             }
         }
     }
+    KY_CLK(-2);
 }
 
 #include "ky_queue.hpp"   // the queue engine: render_kernel_q
@@ -469,6 +475,35 @@ static void pack_shape(const ky_shape& sh, int full_index, DSurf* surf, DShapeFu
     surf->f[11] = (float)(dot3(bs, p1) + 0.5);
 }
 
+// A parallelogram (pack_shape has checked that) lying in an axis plane with its edges along the other two axes:
+// returns that axis and the DAar record, or -1.  Exact comparisons on the caller's floats: nothing is snapped.
+static int axis_aligned_rectangle(const ky_shape& sh, DAar* out) {
+    for (int axis = 0; axis < 3; ++axis) {
+        const float c = sh.p[0][axis];
+        if (!(sh.p[1][axis] == c && sh.p[2][axis] == c && sh.p[3][axis] == c)) continue;
+        const int u = (axis + 1) % 3, v = (axis + 2) % 3;
+        // edges p1->p0 and p1->p2 must each run along one in-plane axis
+        const bool a_u = sh.p[0][v] == sh.p[1][v] && sh.p[0][u] != sh.p[1][u];   // a = p0 - p1 along u
+        const bool a_v = sh.p[0][u] == sh.p[1][u] && sh.p[0][v] != sh.p[1][v];
+        const bool b_u = sh.p[2][v] == sh.p[1][v] && sh.p[2][u] != sh.p[1][u];
+        const bool b_v = sh.p[2][u] == sh.p[1][u] && sh.p[2][v] != sh.p[1][v];
+        if (!((a_u && b_v) || (a_v && b_u))) continue;
+        double lo[2], hi[2];
+        const int ax[2] = {u, v};
+        for (int k = 0; k < 2; ++k) {
+            lo[k] = hi[k] = sh.p[0][ax[k]];
+            for (int q = 1; q < 4; ++q) { lo[k] = std::min(lo[k], (double)sh.p[q][ax[k]]); hi[k] = std::max(hi[k], (double)sh.p[q][ax[k]]); }
+        }
+        // the fourth corner must complete the rectangle exactly
+        if (!((sh.p[3][u] == lo[0] || sh.p[3][u] == hi[0]) && (sh.p[3][v] == lo[1] || sh.p[3][v] == hi[1]))) continue;
+        const double su = 1.0 / (hi[0] - lo[0]), sv = 1.0 / (hi[1] - lo[1]);
+        out->q0 = make_float4(c, (float)su, (float)(lo[0] * su + 0.5), (float)sv);
+        out->q1 = make_float4((float)(lo[1] * sv + 0.5), 0.f, 0.f, 0.f);
+        return axis;
+    }
+    return -1;
+}
+
 static void pack_material(const ky_material& m, DMat* d) {
     std::memset(d, 0, sizeof *d);
     cp3(d->c0, m.color0); cp3(d->c1, m.color1);
@@ -517,13 +552,20 @@ static int pack_scene(const ky_scene* in, DScene* out) {
         pack_shape(sh, 0, &recs[i], &fulls[i]);
     }
     int j = 0;
-    for (int pass = 0; pass < 3; ++pass) {
+    std::vector<DAar> aar_groups[3];
+    for (int pass = -3; pass < 3; ++pass) {   // -3, -2, -1: axis-aligned rectangles in the x, y, z planes
         for (int i = 0; i < in->surface_count; ++i) {
-            const int group = recs[i].kind == TK_PARALLELOGRAM ? 0 : (recs[i].kind == TK_SPHERE ? 1 : 2);
-            if (group != pass) continue;
             const ky_surface& sf = in->surfaces[i];
             const ky_shape& sh = in->shapes[sf.shape];
-            if (pass == 0) {
+            DAar aar;
+            const int axis = recs[i].kind == TK_PARALLELOGRAM ? axis_aligned_rectangle(sh, &aar) : -1;
+            const int group = axis >= 0 ? axis - 3 : (recs[i].kind == TK_PARALLELOGRAM ? 0 : (recs[i].kind == TK_SPHERE ? 1 : 2));
+            if (group != pass) continue;
+            if (pass < 0) {
+                out->n_aar_axis[axis]++;
+                out->n_aar++;
+                aar_groups[axis].push_back(aar);
+            } else if (pass == 0) {
                 DPar& d = out->par[out->n_par++];
                 std::memcpy(&d.q0, &recs[i].f[0], 16); std::memcpy(&d.q1, &recs[i].f[4], 16); std::memcpy(&d.q2, &recs[i].f[8], 16);
                 out->par[out->n_par] = d;   // readable padding record for the prefetch of i + 1
@@ -544,6 +586,12 @@ static int pack_scene(const ky_scene* in, DScene* out) {
             out->orig[j] = i;
             ++j;
         }
+    }
+    {   // lay the axis groups out one after the other (x, y, z planes), plus one readable record past the end
+        int pos = 0;
+        for (int axis = 0; axis < 3; ++axis)
+            for (const DAar& r : aar_groups[axis]) out->aar[pos++] = r;
+        if (pos > 0) out->aar[pos] = out->aar[pos - 1];
     }
     for (int i = 0; i < in->material_count; ++i) {
         const ky_material& m = in->materials[i];
@@ -703,6 +751,13 @@ int kyhip_debug_lane_probe(unsigned long long* out32) {
 #endif
 
 const char* kyhip_last_error(void) { return g_error.c_str(); }
+#ifdef KY_PROFILE_CLOCKS
+int kyhip_debug_clocks(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_clk), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_clk), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 #ifdef KY_QE_STATS
 int kyhip_debug_stats(unsigned long long* out32, int reset) {
     if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(kyd::g_qe_stats), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;

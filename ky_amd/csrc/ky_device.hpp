@@ -191,8 +191,9 @@ struct DSph {  // sphere, 16 B: centre, radius^2
     float4 c;
 };
 // axis-aligned rectangle in the plane x_axis = c, 32 B.  With (u, v) = the other two axes in cyclic order and [lo, hi] the
-// rectangle's extent along them: q0 = (c, su, ou, sv), q1.x = ov with s = 1 / (hi - lo), o = lo * s + 0.5, so that a point h
-// of the plane is inside iff |h_u su - ou| <= 0.5 and |h_v sv - ov| <= 0.5 (the parallelogram test's convention).
+// rectangle's extent along them: q0 = (c, mu, ru, mv), q1.x = rv with m = (lo + hi) / 2, r = (hi - lo) / 2: a point h of
+// the plane is inside iff |h_u - mu| <= ru and |h_v - mv| <= rv (borders inclusive, like the parallelogram test; each
+// test is one subtract and one compare with a single scalar operand).
 struct DAar {
     float4 q0, q1;
 };
@@ -358,10 +359,10 @@ KY_DEV bool aar_hit(const float4 q0, const float ov, f3 o, f3 d, f3 inv_d, float
     const float ou_ = AXIS == 0 ? o.y : (AXIS == 1 ? o.z : o.x), du_ = AXIS == 0 ? d.y : (AXIS == 1 ? d.z : d.x);
     const float ov_ = AXIS == 0 ? o.z : (AXIS == 1 ? o.x : o.y), dv_ = AXIS == 0 ? d.z : (AXIS == 1 ? d.x : d.y);
     const float t = (q0.x - oa) * ia;
-    const float u = (ou_ + t * du_) * q0.y - q0.z;
-    const float v = (ov_ + t * dv_) * q0.w - ov;
+    const float u = (ou_ + t * du_) - q0.y;
+    const float v = (ov_ + t * dv_) - q0.w;
     t_out = t;
-    return (fabsf(u) <= 0.5f) & (fabsf(v) <= 0.5f) & (t > K_SHAPE_EPS) & (t < tmax);
+    return (fabsf(u) <= q0.z) & (fabsf(v) <= ov) & (t > K_SHAPE_EPS) & (t < tmax);
 }
 
 // the axis-aligned rectangles of one axis: records [first, first + n) of S->aar, whose sorted surface indices are the same

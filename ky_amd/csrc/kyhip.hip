@@ -496,9 +496,8 @@ static int axis_aligned_rectangle(const ky_shape& sh, DAar* out) {
         }
         // the fourth corner must complete the rectangle exactly
         if (!((sh.p[3][u] == lo[0] || sh.p[3][u] == hi[0]) && (sh.p[3][v] == lo[1] || sh.p[3][v] == hi[1]))) continue;
-        const double su = 1.0 / (hi[0] - lo[0]), sv = 1.0 / (hi[1] - lo[1]);
-        out->q0 = make_float4(c, (float)su, (float)(lo[0] * su + 0.5), (float)sv);
-        out->q1 = make_float4((float)(lo[1] * sv + 0.5), 0.f, 0.f, 0.f);
+        out->q0 = make_float4(c, (float)(0.5 * (lo[0] + hi[0])), (float)(0.5 * (hi[0] - lo[0])), (float)(0.5 * (lo[1] + hi[1])));
+        out->q1 = make_float4((float)(0.5 * (hi[1] - lo[1])), 0.f, 0.f, 0.f);
         return axis;
     }
     return -1;

@@ -59,9 +59,15 @@ static int fail(int code, const char* fmt, ...) {
 // must not depend on the sharding, or images would differ between GPU counts): KY_CHUNK-sample chunks, except that
 // the last KY_TAIL samples are cut into KY_CHUNK_SMALL-sample chunks.  Items are queued chunk-major, so the small
 // chunks of all blocks come last and the end-of-kernel tail is one small item, not one big one.
-constexpr int KY_CHUNK = 32;
+#ifndef KY_CHUNK_BIG
+#define KY_CHUNK_BIG 32
+#endif
+#ifndef KY_TAIL_SAMPLES
+#define KY_TAIL_SAMPLES 128
+#endif
+constexpr int KY_CHUNK = KY_CHUNK_BIG;
 constexpr int KY_CHUNK_SMALL = 8;
-constexpr int KY_TAIL = 128;
+constexpr int KY_TAIL = KY_TAIL_SAMPLES;
 #ifndef KY_RING_SLOTS
 #define KY_RING_SLOTS 4
 #endif

@@ -6,7 +6,7 @@ import torch
 from ky_amd import api, dist, _abi as A
 lib = A.load_kyhip()
 scene = api.cornell_box_scene(A.CB_DEFAULT_SCENE, 1024, 768)
-p = api.make_params(1024, 768, 1024, tile_w=int(os.environ.get("TILE", "32")), tile_h=int(os.environ.get("TILE", "32")))
+p = api.make_params(1024, 768, 1024, tile_w=int(os.environ.get("TILE", "16")), tile_h=int(os.environ.get("TILE", "16")))
 full = None
 for N in (1, 2, 4, 8):
     times = []

@@ -133,6 +133,9 @@ static ShardConst make_shard(const ky_render_params* p) {
 #ifndef KY_MAX_RETRACE
 #define KY_MAX_RETRACE 1
 #endif
+#ifndef KY_RETRACE_THRESHOLD
+#define KY_RETRACE_THRESHOLD 40
+#endif
 #ifndef KY_WAVES_PER_EU
 #define KY_WAVES_PER_EU 2
 #endif
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DSce
             // lanes that could start another path right now; worth one more traversal if they would otherwise idle
             // through (2 traversals x lights + shading) that is worth more than the extra traversal
             const int idle = __popcll(__ballot(!alive && !done && s < s_end));
-            if (idle * (2 * nee_weight + 1) < 40) break;
+            if (idle * (2 * nee_weight + 1) < KY_RETRACE_THRESHOLD) break;
         }
         KY_CLK(1);
         if (!__any(alive)) {

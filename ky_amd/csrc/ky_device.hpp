@@ -182,7 +182,10 @@ struct DLight {  // light_t + the shape an area light samples; wave-uniform inde
     DSurf isect;          // traversal record of the sampled shape (pdf_direction re-intersects it, 1057-1061)
 };
 constexpr int KY_MAX_CARRIERS = 4;
-constexpr int KY_TRANSPOSE_MAX = 4;   // at most this many occlusion queries per wave are resolved surface-parallel
+#ifndef KY_TRANSPOSE_QUERIES
+#define KY_TRANSPOSE_QUERIES 4
+#endif
+constexpr int KY_TRANSPOSE_MAX = KY_TRANSPOSE_QUERIES;   // at most this many occlusion queries per wave are resolved surface-parallel
 
 struct DPar {  // planar parallelogram, 48 B: q0 = (n, n.p0), q1 = (a*, a*.p1 + 0.5), q2 = (b*, b*.p1 + 0.5)
     float4 q0, q1, q2;

@@ -142,3 +142,20 @@ def test_custom_spheres_and_seed(A, api, O):
     g, c = api.smallpt_render(arr, p), O.smallpt_render(arr, p, 0)
     assert g.max() > 0.05 and (np.abs(g - c) > 1e-9).mean() < 0.01
     assert not np.array_equal(g, api.smallpt_render(arr, api.smallpt_params(48, 40, 8, seed=100)))
+
+
+@pytest.mark.gpu
+def test_cpp_driver_writes_smallpts_ppm(A, api, tmp_path):
+    """examples/smallpt_driver.cpp = smallpt's main() with the loop nest replaced by the C ABI call; its plain-text PPM
+    (gamma 2.2, toInt, smallpt.cpp:55, 119-123) must equal the one computed from the Python path's film."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "bin", "smallpt_driver")
+    out = tmp_path / "image.ppm"
+    subprocess.check_call([exe, "16", "48", "36", str(out)], stderr=subprocess.DEVNULL)
+    tok = out.read_text().split()
+    assert tok[:4] == ["P3", "48", "36", "255"]
+    got = np.array(tok[4:], dtype=np.int64).reshape(36, 48, 3)
+    img = api.smallpt_render(api.smallpt_scene(), api.smallpt_params(48, 36, 4))
+    want = (np.clip(img, 0, 1) ** (1 / 2.2) * 255 + .5).astype(np.int64)
+    assert np.array_equal(got, want)

@@ -540,3 +540,35 @@ def test_edge_cases(A, api, O):
     g, c = api.render(inside, p), O.render(inside, p)
     fin = np.isfinite(c).all(axis=2)
     assert g.mean() > 0.01 and rmse(g[fin], c[fin]) < film_tolerance(256), rmse(g[fin], c[fin])
+
+
+def test_axis_aligned_rectangles_special_rays(A, api, O):
+    """The axis-plane rectangle test divides by a direction component: rays running exactly parallel to one or two axes
+    (zero components, reciprocal = inf), rays starting exactly on a wall's plane, and rays along the box diagonals must
+    agree with the oracle's edge-cross test (rectangle_t::intersect, 1261-1297) like any other ray."""
+    scene = api.cornell_box_scene(A.CB_DEFAULT_SCENE, 64, 64)
+    rng = np.random.default_rng(77)
+    o = rng.uniform(-1.0, 1.0, (4096, 3))
+    d = rng.normal(size=(4096, 3))
+    d[:1024, 0] = 0.0                                  # parallel to the x planes
+    d[1024:2048, 1] = 0.0
+    d[2048:2560, 2] = 0.0
+    d[2560:2816, :2] = 0.0                             # straight up / down
+    d[2816:3072, 1:] = 0.0                             # along +-x
+    d[3072:3328] = np.sign(d[3072:3328])               # box diagonals
+    o[3328:3584, 0] = np.float32(-1.27029)             # origins exactly on the left wall's plane
+    o[3584:3840, 2] = np.float32(-1.28002)             # ... and on the floor's
+    d = unit(d)
+    rays = np.concatenate([o, d, np.full((4096, 1), np.inf)], 1).astype(np.float32)
+    g, c = api.kat_scene_intersect(scene, rays), O.kat_scene_intersect(scene, rays)
+    same = (g[:, 0] == c[:, 0]) & (g[:, 8] == c[:, 8])
+    assert same.mean() > 0.999, same.mean()
+    hit = same & (c[:, 0] > 0)
+    assert hit.sum() > 3000
+    assert_close_q(g[hit][:, 1:8], c[hit][:, 1:8], 2e-5, q=0.999, hard=1e-2)
+    # occlusion queries along the same special directions
+    tgt = o + d * rng.uniform(0.2, 2.5, (4096, 1))
+    nrm = unit(rng.normal(size=(4096, 3)))
+    q = np.concatenate([o, nrm, tgt], 1).astype(np.float32)
+    go, co = api.kat_occluded(scene, q), O.kat_occluded(scene, q)
+    assert (go == co).mean() > 0.998

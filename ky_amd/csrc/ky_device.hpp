@@ -155,13 +155,15 @@ struct DHit {  // what is needed once the nearest surface is known; gathered per
 };  // 32 B
 
 struct DMat {  // ky_material, gathered per lane from LDS
-    float c0[3];
+    float c0[3];        // lambert albedo | mirror R | glass R; plastic: Kd / P_diff, the Lambert lobe's albedo (2667)
     int32_t kind;
-    float c1[3];
+    float c1[3];        // glass T; plastic: Ks
     float eta;
     float exponent, p_diffuse, p_specular;
     int32_t exp_flags;  // bit 0: exponent is integral, bit 1: it is odd (sign of pow(negative, n))
-};  // 48 B
+    float cs[3];        // plastic: Ks / P_spec, the Phong lobe's colour (2665)
+    int32_t pad;
+};  // 64 B
 
 struct DLight {  // light_t + the shape an area light samples; wave-uniform index
     float color[3];
@@ -526,52 +528,23 @@ KY_DEV f3 to_world(const Frame& f, f3 l) { return f.s * l.x + f.t * l.y + f.n * 
 enum : int { LOBE_LAMBERT = 0, LOBE_MIRROR = 1, LOBE_GLASS = 2, LOBE_PHONG = 3 };
 enum : int { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16 };
 
+// The BSDF a material builds at a hit (material_t::scattering x4: 2587, 2604, 2628, 2661) is a lobe plus the material's
+// record: colours and exponents are read from the record (LDS) where they are used instead of living in registers.
 struct Bsdf {
     int lobe;
-    f3 a;          // lambert albedo | mirror R | glass R | phong Ks
-    f3 b;          // glass T
-    float eta_t;   // glass (eta_i = 1, 2630)
-    float exponent;
-    int exp_flags;
+    const DMat* m;
 };
 KY_DEV bool bsdf_is_delta(const Bsdf& B) { return B.lobe == LOBE_MIRROR || B.lobe == LOBE_GLASS; }
+KY_DEV f3 bsdf_a(const Bsdf& B) { return B.lobe == LOBE_PHONG ? ld3(B.m->cs) : ld3(B.m->c0); }   // lambert albedo | mirror R | glass R | phong Ks
 
-// material_t::scattering x4 (2587, 2604, 2628, 2661)
-KY_DEV Bsdf make_bsdf(const DMat& M, float lobe_random) {
-    Bsdf B;
-    B.a = ld3(M.c0);
-    B.b = ld3(M.c1);
-    B.eta_t = M.eta;
-    B.exponent = M.exponent;
-    B.exp_flags = M.exp_flags;
-    B.lobe = LOBE_LAMBERT;
-    if (M.kind == KY_MATERIAL_MIRROR) B.lobe = LOBE_MIRROR;
-    else if (M.kind == KY_MATERIAL_GLASS) B.lobe = LOBE_GLASS;
-    else if (M.kind == KY_MATERIAL_PLASTIC) {
-        if (lobe_random < M.p_specular) { B.lobe = LOBE_PHONG; B.a = ld3(M.c1) * rcp(M.p_specular); }
-        else { B.a = ld3(M.c0) * rcp(M.p_diffuse); }
-    }
-    return B;
-}
-
-// the same with the lobe already decided (the queue engine picks it in its first stage, to sort the vertices by lobe)
 KY_DEV int pick_lobe(const DMat& M, float lobe_random) {
     if (M.kind == KY_MATERIAL_MIRROR) return LOBE_MIRROR;
     if (M.kind == KY_MATERIAL_GLASS) return LOBE_GLASS;
-    if (M.kind == KY_MATERIAL_PLASTIC && lobe_random < M.p_specular) return LOBE_PHONG;
+    if (M.kind == KY_MATERIAL_PLASTIC && lobe_random < M.p_specular) return LOBE_PHONG;   // 2663
     return LOBE_LAMBERT;
 }
-KY_DEV Bsdf make_bsdf_for_lobe(const DMat& M, int lobe) {
-    Bsdf B;
-    B.a = ld3(M.c0);
-    B.b = ld3(M.c1);
-    B.eta_t = M.eta;
-    B.exponent = M.exponent;
-    B.exp_flags = M.exp_flags;
-    B.lobe = lobe;
-    if (M.kind == KY_MATERIAL_PLASTIC) B.a = lobe == LOBE_PHONG ? ld3(M.c1) * rcp(M.p_specular) : ld3(M.c0) * rcp(M.p_diffuse);
-    return B;
-}
+KY_DEV Bsdf make_bsdf_for_lobe(const DMat& M, int lobe) { return Bsdf{lobe, &M}; }
+KY_DEV Bsdf make_bsdf(const DMat& M, float lobe_random) { return Bsdf{pick_lobe(M, lobe_random), &M}; }
 
 // fresnel_dielectric, 1963-1996
 KY_DEV float fresnel_dielectric(float cos_theta_i, float eta_i, float eta_t) {
@@ -603,16 +576,17 @@ KY_DEV void bsdf_eval_pdf(const Bsdf& B, f3 wo, f3 wi, f3& f, float& pdf) {
     pdf = 0.f;
     const bool same = wo.z * wi.z > 0;  // same_hemisphere, 1921
     if (B.lobe == LOBE_LAMBERT) {       // 2227-2240
-        if (same) { f = B.a * K_INV_PI; pdf = fabsf(wi.z) * K_INV_PI; }
+        if (same) { f = ld3(B.m->c0) * K_INV_PI; pdf = fabsf(wi.z) * K_INV_PI; }
     } else if (B.lobe == LOBE_PHONG) {  // 2489-2508, 2545-2550; wr = reflect(wo, z) = (-wo.x, -wo.y, wo.z)
         const float cos_alpha = wo.z * wi.z - wo.x * wi.x - wo.y * wi.y;
         // eval: cos_alpha is not clamped (a negative base with an even integral exponent is positive);
         // pdf: clamped at 0, no hemisphere test (quirk 6)
-        const float pe = phong_pow(cos_alpha, B.exponent, B.exp_flags);
-        const float p0 = B.exponent == 0.f ? 1.f : (B.exponent > 0.f ? 0.f : K_INF);
+        const float exponent = B.m->exponent;
+        const float pe = phong_pow(cos_alpha, exponent, B.m->exp_flags);
+        const float p0 = exponent == 0.f ? 1.f : (exponent > 0.f ? 0.f : K_INF);
         const float pp = cos_alpha > 0.f ? pe : p0;
-        if (same) f = (B.a * ((B.exponent + 2.f) * K_INV_2PI)) * pe;
-        pdf = (B.exponent + 1.f) * pp * K_INV_2PI;
+        if (same) f = (ld3(B.m->cs) * ((exponent + 2.f) * K_INV_2PI)) * pe;
+        pdf = (exponent + 1.f) * pp * K_INV_2PI;
     }
     // mirror / glass: eval 0, pdf 0 (2289-2290, 2352-2353)
 }
@@ -652,21 +626,22 @@ KY_DEV BsdfSample bsdf_sample_local(const Bsdf& B, f3 wo, float u0, float u1) {
         s.flags = BSDF_REFLECTION | BSDF_DIFFUSE;
     } else if (B.lobe == LOBE_MIRROR) {  // 2292-2307
         s.wi = mk3(-wo.x, -wo.y, wo.z);
-        s.f = B.a * rcp(fabsf(s.wi.z));
+        s.f = ld3(B.m->c0) * rcp(fabsf(s.wi.z));
         s.pdf = 1;
         s.flags = BSDF_REFLECTION | BSDF_SPECULAR;
     } else if (B.lobe == LOBE_GLASS) {  // 2355-2412
-        const float reflect_percent = fresnel_dielectric(wo.z, 1.f, B.eta_t);
+        const float eta_t = B.m->eta;
+        const float reflect_percent = fresnel_dielectric(wo.z, 1.f, eta_t);
         const float refract_percent = 1 - reflect_percent;
         if (u0 < reflect_percent) {
             s.wi = mk3(-wo.x, -wo.y, wo.z);
             s.pdf = reflect_percent;
-            s.f = (B.a * reflect_percent) * rcp(fabsf(s.wi.z));
+            s.f = (ld3(B.m->c0) * reflect_percent) * rcp(fabsf(s.wi.z));
             s.flags = BSDF_REFLECTION | BSDF_SPECULAR;
         } else {
             const bool into = wo.z > 0;
             const float nz = into ? 1.f : -1.f;
-            const float eta = into ? rcp(B.eta_t) : B.eta_t;
+            const float eta = into ? rcp(eta_t) : eta_t;
             // refract(wo, (0,0,nz), eta), 1931-1957
             const float cos_theta_i = nz * wo.z;
             const float sin_theta_i_sq = fmaxf(0.f, 1 - cos_theta_i * cos_theta_i);
@@ -676,13 +651,13 @@ KY_DEV BsdfSample bsdf_sample_local(const Bsdf& B, f3 wo, float u0, float u1) {
                 const float k = eta * cos_theta_i - cos_theta_t;
                 s.wi = mk3(eta * -wo.x, eta * -wo.y, eta * -wo.z + k * nz);
                 s.pdf = refract_percent;
-                s.f = (B.b * refract_percent) * rcp(fabsf(s.wi.z));
+                s.f = (ld3(B.m->c1) * refract_percent) * rcp(fabsf(s.wi.z));
                 s.flags = BSDF_TRANSMISSION | BSDF_SPECULAR;
             }
             // else total internal reflection: f = 0, pdf = 0 (2407)
         }
     } else {  // phong, 2510-2529 + 2533-2543
-        const float ct = pow_nonneg(u1, rcp(B.exponent + 1.f));
+        const float ct = pow_nonneg(u1, rcp(B.m->exponent + 1.f));
         const float st = fsqrt(1.f - ct * ct);
         const f3 local = mk3(cos_rev(u0) * st, sin_rev(u0) * st, ct);   // phi = 2 pi u0
         const Frame fr = make_frame(mk3(-wo.x, -wo.y, wo.z));           // frame_t(wr): wr is unit because wo is

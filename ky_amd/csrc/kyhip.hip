@@ -516,6 +516,9 @@ static void pack_material(const ky_material& m, DMat* d) {
     std::memset(d, 0, sizeof *d);
     cp3(d->c0, m.color0); cp3(d->c1, m.color1);
     d->kind = m.kind; d->eta = m.eta; d->exponent = m.exponent; d->p_diffuse = m.diffuse_probability; d->p_specular = m.specular_probability;
+    if (m.kind == KY_MATERIAL_PLASTIC) {   // the two lobes' colours, plastic_material_t::scattering 2665 / 2667
+        for (int j = 0; j < 3; ++j) { d->c0[j] = m.color0[j] / m.diffuse_probability; d->cs[j] = m.color1[j] / m.specular_probability; }
+    }
     const float e = m.exponent;
     const bool integral = std::isfinite(e) && std::fabs(e) < 16777216.f && std::floor(e) == e;
     d->exp_flags = (integral ? 1 : 0) | ((integral && std::fmod(std::fabs(e), 2.f) == 1.f) ? 2 : 0);

@@ -673,14 +673,46 @@ KY_DEV BsdfSample bsdf_sample_local(const Bsdf& B, f3 wo, float u0, float u1) {
 // ---------------------------------------------------------------------------------------------
 // path vertex (isect_t, 642-690)
 // ---------------------------------------------------------------------------------------------
+// The lane engine keeps a vertex's shading frame and local wo in LDS (read back where a direction changes space) instead
+// of in nine registers that would be live -- in practice: spilled to scratch memory -- across the whole lights loop.
+struct VertexLds {
+    float s[3][256], t[3][256], wo[3][256];   // [component][thread of the workgroup]
+};
+__shared__ VertexLds g_vertex_lds;   // allocated only in kernels that set Vertex::in_lds
 struct Vertex {
     float t;      // distance along the ray that found the vertex
     f3 position, normal;
-    f3 wo_l;      // wo = -ray.direction (3125) in the shading frame
-    Frame frame;
+    f3 wo_l;      // wo = -ray.direction (3125) in the shading frame   } used when !in_lds
+    Frame frame;  //                                                    }
     Bsdf bsdf;
     int surface;
+    bool in_lds = false;
 };
+KY_DEV void vertex_set_frame(Vertex& v, const Frame& f, f3 wo_l) {
+    if (v.in_lds) {
+        const int i = threadIdx.x;
+        g_vertex_lds.s[0][i] = f.s.x; g_vertex_lds.s[1][i] = f.s.y; g_vertex_lds.s[2][i] = f.s.z;
+        g_vertex_lds.t[0][i] = f.t.x; g_vertex_lds.t[1][i] = f.t.y; g_vertex_lds.t[2][i] = f.t.z;
+        g_vertex_lds.wo[0][i] = wo_l.x; g_vertex_lds.wo[1][i] = wo_l.y; g_vertex_lds.wo[2][i] = wo_l.z;
+    } else {
+        v.frame = f;
+        v.wo_l = wo_l;
+    }
+}
+KY_DEV Frame vertex_frame(const Vertex& v) {
+    if (!v.in_lds) return v.frame;
+    const int i = threadIdx.x;
+    Frame f;
+    f.s = mk3(g_vertex_lds.s[0][i], g_vertex_lds.s[1][i], g_vertex_lds.s[2][i]);
+    f.t = mk3(g_vertex_lds.t[0][i], g_vertex_lds.t[1][i], g_vertex_lds.t[2][i]);
+    f.n = v.normal;
+    return f;
+}
+KY_DEV f3 vertex_wo(const Vertex& v) {
+    if (!v.in_lds) return v.wo_l;
+    const int i = threadIdx.x;
+    return mk3(g_vertex_lds.wo[0][i], g_vertex_lds.wo[1][i], g_vertex_lds.wo[2][i]);
+}
 
 // ---------------------------------------------------------------------------------------------
 // lights (ky.cpp:2764-3062) and the shape sampling they call (1028-1090, 1404-1513)
@@ -869,8 +901,8 @@ KY_DEV f3 estimate_by_bsdf(const DScene* __restrict__ S, const LdsScene& Lds, co
     bs.pdf = 0.f;
     bool live = false;
     if (active) {
-        bs = bsdf_sample_local(v.bsdf, v.wo_l, u0, u1);
-        bs.wi = to_world(v.frame, bs.wi);  // 2176
+        bs = bsdf_sample_local(v.bsdf, vertex_wo(v), u0, u1);
+        bs.wi = to_world(vertex_frame(v), bs.wi);  // 2176
         f_cos = bs.f * fabsf(dot(bs.wi, v.normal));
         live = !(is_black(f_cos) || (MIS ? (bs.pdf <= 0) : (bs.pdf == 0)));
         o = offset_ray_origin(v.position, v.normal, bs.wi);  // isect.spawn_ray, 665-668
@@ -966,7 +998,7 @@ KY_DEV f3 estimate_by_emitter(const DScene* __restrict__ S, const LdsScene& Lds,
             KY_PROBE(5);
             f3 f;
             float bsdf_pdf;
-            bsdf_eval_pdf(v.bsdf, v.wo_l, to_local(v.frame, ls.wi), f, bsdf_pdf);
+            bsdf_eval_pdf(v.bsdf, vertex_wo(v), to_local(vertex_frame(v), ls.wi), f, bsdf_pdf);
             const f3 f_cos = f * fabsf(dot(ls.wi, v.normal));
             if (!is_black(f_cos)) {
                 const bool delta_light = L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION;
@@ -1112,8 +1144,8 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, c
         } else {
             v.bsdf = make_bsdf_for_lobe(M, lobe);
         }
-        v.frame = make_frame(v.normal);
-        v.wo_l = to_local(v.frame, -ps.d);   // ps.d still holds the direction of the ray that found this vertex
+        const Frame fr = make_frame(v.normal);
+        vertex_set_frame(v, fr, to_local(fr, -ps.d));   // ps.d still holds the direction of the ray that found this vertex
     }
 
     if (rc.integrator < KY_INTEGRATOR_DIRECT_LIGHTING) {  // debug_integrator_t, 4110-4118 (wave-uniform)
@@ -1122,7 +1154,7 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, c
             else if (rc.integrator == KY_INTEGRATOR_NORMAL) ps.Lo = v.normal;
             else {
                 float pdf;
-                bsdf_eval_pdf(v.bsdf, v.wo_l, to_local(v.frame, v.normal), ps.Lo, pdf);
+                bsdf_eval_pdf(v.bsdf, vertex_wo(v), to_local(vertex_frame(v), v.normal), ps.Lo, pdf);
             }
         }
         return false;
@@ -1147,8 +1179,8 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, c
         // path_tracing_recursion_t, specular vertex (4341-4349): look the emitter up along a sampled direction, from the
         // un-offset hit point; the continuation below draws a NEW sample
         const float e0 = sampler_next<DEBUG_SAMPLER>(ps.smp), e1 = sampler_next<DEBUG_SAMPLER>(ps.smp);
-        BsdfSample es = bsdf_sample_local(v.bsdf, v.wo_l, e0, e1);
-        es.wi = to_world(v.frame, es.wi);
+        BsdfSample es = bsdf_sample_local(v.bsdf, vertex_wo(v), e0, e1);
+        es.wi = to_world(vertex_frame(v), es.wi);
         float t = K_INF;
         const int hs = trace_nearest(S, v.position, es.wi, t);
         f3 Le = S->env_light >= 0 ? ld3(S->light[S->env_light].color) : mk3(0, 0, 0);
@@ -1164,8 +1196,8 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, c
     // sample BSDF to get the new path direction, 4586 / 4213 / 4383 / 4495
     const float u0 = sampler_next<DEBUG_SAMPLER>(ps.smp), u1 = sampler_next<DEBUG_SAMPLER>(ps.smp);
     KY_PROBE(7);
-    BsdfSample bs = bsdf_sample_local(v.bsdf, v.wo_l, u0, u1);
-    bs.wi = to_world(v.frame, bs.wi);
+    BsdfSample bs = bsdf_sample_local(v.bsdf, vertex_wo(v), u0, u1);
+    bs.wi = to_world(vertex_frame(v), bs.wi);
     if (is_black(bs.f) || bs.pdf == 0.f) return false;  // 4588 / 4215 / 4385 / 4497
     if (rc.integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION) {
         ps.beta = ps.beta * (bs.f * (fabsf(dot(bs.wi, v.normal)) * rcp(bs.pdf)));  // 4592

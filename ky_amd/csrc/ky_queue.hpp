@@ -224,7 +224,7 @@ KY_DEV bool emitter_sample(const DScene* __restrict__ S, const Vertex& v, int li
     tmax = d2 * inv_d - 2e-3f;
     f3 f;
     float bsdf_pdf;
-    bsdf_eval_pdf(v.bsdf, v.wo_l, to_local(v.frame, ls.wi), f, bsdf_pdf);
+    bsdf_eval_pdf(v.bsdf, vertex_wo(v), to_local(vertex_frame(v), ls.wi), f, bsdf_pdf);
     const f3 f_cos = f * fabsf(dot(ls.wi, v.normal));
     if (is_black(f_cos)) return false;
     const bool delta_light = L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION;

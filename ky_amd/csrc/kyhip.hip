@@ -137,7 +137,7 @@ static ShardConst make_shard(const ky_render_params* p) {
 #define KY_RETRACE_THRESHOLD 40
 #endif
 #ifndef KY_WAVES_PER_EU
-#define KY_WAVES_PER_EU 2
+#define KY_WAVES_PER_EU 6
 #endif
 
 struct ItemSlot {  // one fetched work item, decoded once (wave-uniform) and read per lane
@@ -151,13 +151,17 @@ __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DSce
                                                                      unsigned* __restrict__ flags) {
     __shared__ LdsScene Lds;
     __shared__ ItemSlot ring[4][KY_RING];
+    // the lane's pixel chunk (touched when a path starts or ends, not while a vertex is shaded) lives in LDS, not in registers
+    __shared__ float c_lsum[3][256];
+    __shared__ int c_xy[256], c_pix[256], c_s[256], c_s_end[256];
+    __shared__ uint32_t c_key[256];
+    const int tid = threadIdx.x;
     stage_scene(Lds, S);
     if (STRATEGY >= 0) { rc.strategy = STRATEGY; rc.integrator = KY_INTEGRATOR_PATH_TRACING_ITERATION; }  // the hot instantiation
     const int nee_weight = (rc.strategy == KY_DIRECT_IDLE || rc.integrator < KY_INTEGRATOR_DIRECT_LIGHTING ||
                             rc.integrator == KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION) ? 0 : S->n_lights;
 
     const int lane = threadIdx.x & 63;
-    const unsigned long long lanes_below = (1ull << lane) - 1ull;
     ItemSlot* my_ring = ring[threadIdx.x >> 6];
 
     // wave-uniform: the wave's pool of work is the sequence of (item, pixel) pairs of the items it has fetched;
@@ -166,10 +170,9 @@ __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DSce
     int cursor = 0;
     bool exhausted = false;   // the global counter ran past n_items
     // per lane: the pixel chunk being worked on
-    int x = 0, y = 0, pix = 0, s = 0, s_end = 0;
-    uint32_t pixel_key = 0;   // hash of (seed, pixel): constant for the chunk
+    c_lsum[0][tid] = 0.f; c_lsum[1][tid] = 0.f; c_lsum[2][tid] = 0.f;
+    bool open = false;        // the chunk has samples left to start (s < s_end)
     bool has_item = false, done = false, alive = false;
-    f3 Lsum = mk3(0, 0, 0);
     PathState ps;
 
     KY_CLK(-1);
@@ -178,11 +181,13 @@ __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DSce
         // ---- (1) lanes whose pixel chunk is finished flush it and take the next (item, pixel) pair of the wave's pool.
         // A lane is NOT tied to one pixel position: whichever lane is free takes the next pixel, so lanes never wait
         // for each other and the wave drains within one chunk of the end of the queue.
-        const bool need = !alive && !done && s >= s_end;
+        const bool need = !alive && !done && !open;
         const unsigned long long need_mask = __ballot(need);
         if (need_mask) {  // wave-uniform branch: every lane runs the bookkeeping below
             if (need && has_item) {
-                const float v[3] = {Lsum.x, Lsum.y, Lsum.z};
+                const float v[3] = {c_lsum[0][tid], c_lsum[1][tid], c_lsum[2][tid]};
+                const int pix = c_pix[tid];
+                c_lsum[0][tid] = 0.f; c_lsum[1][tid] = 0.f; c_lsum[2][tid] = 0.f;
                 unsigned fl = 0;
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
@@ -194,7 +199,6 @@ __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DSce
                 }
                 if (fl) atomicOr(&flags[pix], fl);
                 has_item = false;
-                Lsum = mk3(0, 0, 0);
             }
             const int n_need = __popcll(need_mask);
             // fetch until the pool covers every requesting lane (at most two items: n_need <= 64), or the queue is empty.
@@ -222,17 +226,19 @@ __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DSce
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // lane 0's slot writes before the other lanes' reads
             if (need) {
-                const int mine = cursor + __popcll(need_mask & lanes_below);
+                // number of requesting lanes below this one: v_mbcnt, no lane mask kept in registers
+                const int mine = cursor + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(need_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need_mask, 0u));
                 if (mine < fetched * 64) {
                     const ItemSlot it = my_ring[(mine >> 6) % KY_RING];
                     const int px = mine & 7, py = (mine >> 3) & 7;
-                    x = it.x0 + px;
-                    y = it.y0 + py;
-                    pix = it.pix0 + py * sh.tile_w + px;
-                    pixel_key = sampler_pixel_key(rc.seed, (uint32_t)(y * rc.width + x));
+                    const int x = it.x0 + px, y = it.y0 + py;
                     const bool in_range = x < rc.width && y < rc.height;
-                    s = in_range ? it.s_begin : it.s_end;
-                    s_end = it.s_end;
+                    c_xy[tid] = x | (y << 16);
+                    c_pix[tid] = it.pix0 + py * sh.tile_w + px;
+                    c_key[tid] = sampler_pixel_key(rc.seed, (uint32_t)(y * rc.width + x));
+                    c_s[tid] = it.s_begin;
+                    c_s_end[tid] = it.s_end;
+                    open = in_range && it.s_begin < it.s_end;
                     has_item = in_range;
                 } else {
                     done = true;  // only reachable once the queue is exhausted
@@ -246,11 +252,14 @@ __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DSce
         // which costs 2 traversals per light.  When many lanes are in that state, they regenerate and trace once more
         // before the wave moves on (wave-uniform decision), so the expensive phase runs with fuller lanes.
         Vertex v;
+        v.in_lds = true;   // shading frame and local wo in LDS (ky_device.hpp, VertexLds)
         bool have_vertex = false;
         for (int attempt = 0;; ++attempt) {
-            if (!alive && !done && s < s_end) {  // next camera sample of this lane's pixel, 3712-3715
-                path_begin<DEBUG_SAMPLER>(ps, S, pixel_key, x, y, s);
-                ++s;
+            if (!alive && !done && open) {  // next camera sample of this lane's pixel, 3712-3715
+                const int xy = c_xy[tid], s = c_s[tid];
+                path_begin<DEBUG_SAMPLER>(ps, S, c_key[tid], xy & 0xffff, xy >> 16, s);
+                c_s[tid] = s + 1;
+                open = s + 1 < c_s_end[tid];
                 alive = true;
             }
             const bool tracing = alive && !have_vertex;
@@ -259,14 +268,14 @@ __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DSce
                 if (path_intersect<DEBUG_SAMPLER>(ps, v, S, Lds, rc)) {
                     have_vertex = true;
                 } else {
-                    Lsum = Lsum + ps.Lo * rc.inv_spp;  // L = L + Li * (1. / spp), 3717-3721
+                    c_lsum[0][tid] += ps.Lo.x * rc.inv_spp; c_lsum[1][tid] += ps.Lo.y * rc.inv_spp; c_lsum[2][tid] += ps.Lo.z * rc.inv_spp;
                     alive = false;
                 }
             }
             if (attempt >= KY_MAX_RETRACE) break;
             // lanes that could start another path right now; worth one more traversal if they would otherwise idle
             // through (2 traversals x lights + shading) that is worth more than the extra traversal
-            const int idle = __popcll(__ballot(!alive && !done && s < s_end));
+            const int idle = __popcll(__ballot(!alive && !done && open));
             if (idle * (2 * nee_weight + 1) < KY_RETRACE_THRESHOLD) break;
         }
         KY_CLK(1);
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DSce
         {
             const bool cont = path_shade<DEBUG_SAMPLER>(ps, v, S, Lds, rc, have_vertex);  // wave-uniform call
             if (have_vertex && !cont) {
-                Lsum = Lsum + ps.Lo * rc.inv_spp;
+                c_lsum[0][tid] += ps.Lo.x * rc.inv_spp; c_lsum[1][tid] += ps.Lo.y * rc.inv_spp; c_lsum[2][tid] += ps.Lo.z * rc.inv_spp;
                 alive = false;
             }
         }

@@ -230,7 +230,6 @@ struct DScene {
 };
 
 struct LdsScene {  // the per-workgroup LDS copy of the tables that are indexed per lane
-    DSurf trav[KYHIP_MAX_SURFACES];   // traversal records, one per LANE in the surface-parallel occlusion query
     DHit hit[KYHIP_MAX_SURFACES];
     DMat mat[KYHIP_MAX_MATERIALS];
     float light_color[KYHIP_MAX_LIGHTS][4];
@@ -244,9 +243,6 @@ KY_DEV void stage_scene(LdsScene& L, const DScene* __restrict__ S) {
     const uint32_t* src_h = reinterpret_cast<const uint32_t*>(S->hit);
     uint32_t* dst_h = reinterpret_cast<uint32_t*>(L.hit);
     for (int i = tid; i < S->n_surfaces * (int)(sizeof(DHit) / 4); i += nt) dst_h[i] = src_h[i];
-    const uint32_t* src_t = reinterpret_cast<const uint32_t*>(S->all);
-    uint32_t* dst_t = reinterpret_cast<uint32_t*>(L.trav);
-    for (int i = tid; i < S->n_surfaces * (int)(sizeof(DSurf) / 4); i += nt) dst_t[i] = src_t[i];
     const uint32_t* src_m = reinterpret_cast<const uint32_t*>(S->mat);
     uint32_t* dst_m = reinterpret_cast<uint32_t*>(L.mat);
     for (int i = tid; i < S->n_materials * (int)(sizeof(DMat) / 4); i += nt) dst_m[i] = src_m[i];
@@ -942,7 +938,7 @@ KY_DEV f3 estimate_by_bsdf(const DScene* __restrict__ S, const LdsScene& Lds, co
                 // cannot be hoisted): queries are rare and the record would otherwise pin 14 VGPRs across the estimator
                 int idx = lane < S->n_surfaces ? lane : 0;
                 asm volatile("" : "+v"(idx));
-                const DSurf& mine = Lds.trav[idx];
+                const DSurf& mine = S->all[idx];   // per-lane record from L2: queries are rare, LDS is worth more as wave capacity
                 float t;
                 const bool ok = (lane < S->n_surfaces) && surf_hit(mine, S->full, qo, qd, qt, t);
                 const bool any = __any(ok);

@@ -63,7 +63,7 @@ static int fail(int code, const char* fmt, ...) {
 #define KY_CHUNK_BIG 32
 #endif
 #ifndef KY_TAIL_SAMPLES
-#define KY_TAIL_SAMPLES 128
+#define KY_TAIL_SAMPLES 256
 #endif
 constexpr int KY_CHUNK = KY_CHUNK_BIG;
 constexpr int KY_CHUNK_SMALL = 8;

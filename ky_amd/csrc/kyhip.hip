@@ -137,7 +137,10 @@ static ShardConst make_shard(const ky_render_params* p) {
 #define KY_RETRACE_THRESHOLD 40
 #endif
 #ifndef KY_WAVES_PER_EU
-#define KY_WAVES_PER_EU 6
+#define KY_WAVES_PER_EU 6           // the hot instantiation <false, both_mis>: 80 VGPRs
+#endif
+#ifndef KY_WAVES_PER_EU_GENERIC
+#define KY_WAVES_PER_EU_GENERIC 5   // strategy / integrator read at run time: more code alive at once, 96 VGPRs measured best
 #endif
 
 struct ItemSlot {  // one fetched work item, decoded once (wave-uniform) and read per lane
@@ -146,7 +149,7 @@ struct ItemSlot {  // one fetched work item, decoded once (wave-uniform) and rea
 
 // STRATEGY >= 0 fixes direct_sample_enum at compile time (prunes the other estimators); -1 reads rc.strategy.
 template <bool DEBUG_SAMPLER, int STRATEGY>
-__global__ __launch_bounds__(256, KY_WAVES_PER_EU) void render_kernel(const DScene* __restrict__ S, RenderConst rc, ShardConst sh,
+__global__ __launch_bounds__(256, STRATEGY >= 0 ? KY_WAVES_PER_EU : KY_WAVES_PER_EU_GENERIC) void render_kernel(const DScene* __restrict__ S, RenderConst rc, ShardConst sh,
                                                                      unsigned* __restrict__ counter, unsigned long long* __restrict__ accum,
                                                                      unsigned* __restrict__ flags) {
     __shared__ LdsScene Lds;

@@ -1,16 +1,17 @@
 /*
  * ky_device.hpp -- gfx950 device code of the path-tracing hot path (one path vertex per call).
  *
- * Written for CDNA4: 64-lane wavefronts, one lane = one pixel.  The primitive list is read with
+ * Written for CDNA4: 64-lane wavefronts, one lane = one path.  The primitive list is read with
  * wave-uniform indices (scalar loads into SGPRs: no VGPR or LDS traffic for the traversal); the
  * tables that are looked up with a per-lane index AFTER the nearest hit is known (surface ->
  * normal / material / light, materials, light radiance) are staged in LDS once per workgroup.
  * No MFMA: there is no dense contraction on this path.
  *
  * Arithmetic is fp32 like the reference, but organised for the VALU rather than transcribed:
- *   - planar parallelograms (every rectangle_t of the shipped scenes) are tested with a plane hit plus
- *     two precomputed dual-basis dot products instead of the reference's four edge cross products;
- *     quads that are not parallelograms, triangles and disks keep the reference's formulation;
+ *   - rectangles lying in an axis plane are tested with the ray's reciprocal direction (12 VALU), other planar
+ *     parallelograms with a plane hit plus two precomputed dual-basis dot products (26 VALU) instead of the
+ *     reference's four edge cross products; quads that are not parallelograms, triangles and disks keep the
+ *     reference's formulation;
  *   - 1/x, 1/sqrt(x), sqrt(x), sin/cos(2 pi x), exp2 and log2 use the hardware instructions
  *     (v_rcp/v_rsq/v_sqrt/v_sin/v_cos/v_exp/v_log, about 1 ulp);
  *   - vectors that are unit by construction are not normalised again.

@@ -2,14 +2,18 @@
  * kyhip.hip -- kernels and C ABI of libkyhip.so (see include/kyhip.h).
  *
  * Kernel structure (DESIGN.md "Kernels"):
- *   render_kernel     persistent workgroups; each wavefront pulls work items (an 8x8 pixel block x a
- *                     chunk of KY_CHUNK samples) from a device counter; one lane owns one pixel of the
- *                     block and runs a flat state machine over path vertices, regenerating a new camera
- *                     sample the moment its path ends; a lane that finishes its chunk moves on to the
- *                     wave's next item without waiting for the other lanes (per-wave ring of fetched
- *                     items), so lanes stay busy and no path state ever goes to HBM.  A finished chunk's
- *                     pixel sum is added to a 64-bit fixed-point accumulator with integer atomics
- *                     (order-independent => bit-identical images for every tiling / GPU count).
+ *   render_kernel     persistent workgroups (the lane engine); each wavefront pulls work items (an 8x8 pixel
+ *                     block x a chunk of samples) from a device counter; whichever lane is free takes the next
+ *                     (item, pixel) pair and runs a flat state machine over path vertices, regenerating a new
+ *                     camera sample the moment its path ends, so lanes never wait for each other and no path state
+ *                     ever goes to HBM.  What is hot stays in registers (ray, position, normal, throughput, sampler);
+ *                     what is merely alive (the lane's pixel chunk, the vertex's shading frame) lives in LDS, which
+ *                     is what lets 6 wavefronts per SIMD be resident.  A finished chunk's pixel sum is added to a
+ *                     64-bit fixed-point accumulator with integer atomics (order-independent => bit-identical
+ *                     images for every tiling / GPU count).
+ *   render_kernel_q   (ky_queue.hpp) the wavefront formulation with the path pool and per-state queues in LDS;
+ *                     experimental, off by default.
+ *   smallpt_kernel    (ky_smallpt.hpp) smallpt's own scene and radiance() in double precision.
  *   resolve_kernel    fixed-point accumulator -> clamp01 -> fp32 tile buffer.
  *   film_add_kernel   film_t::add_color (ky.cpp:1586) for a shard's compact tile buffer.
  *   kat_*             function-level known-answer-test kernels.

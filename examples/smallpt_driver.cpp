@@ -17,7 +17,7 @@ int main(int argc, char* argv[]) {
     const char* path = argc > 4 ? argv[4] : "image.ppm";
     ky_smallpt_sphere spheres[9];
     const int n = kyhip_smallpt_scene(spheres);
-    ky_smallpt_params p = {w, h, samps < 1 ? 1 : samps, 1234u, 10};
+    ky_smallpt_params p = {w, h, samps < 1 ? 1 : samps, 1234u, 10, KY_SP_VARIANT_SMALLPT};
     std::vector<double> c(3 * (size_t)w * h);
     if (kyhip_smallpt_render(0, spheres, n, &p, c.data()) != KY_OK) {
         std::fprintf(stderr, "error: %s\n", kyhip_last_error());

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define KYHIP_ABI_VERSION 1
+#define KYHIP_ABI_VERSION 2
 
 /* ------------------------------------------------------------------------------------------
  * Scene description: a flat restatement of what scene_t holds (ky.cpp:3535-3546) and what the
@@ -281,18 +281,33 @@ typedef struct ky_smallpt_sphere {   /* struct Sphere, smallpt.cpp:26-39 */
     int pad_;
 } ky_smallpt_sphere;
 
+/* Which program of the smallpt lineage the fp64 path restates.
+   KY_SP_VARIANT_SMALLPT  smallpt2pbrt/smallpt.cpp as described above.
+   KY_SP_VARIANT_REWRITE  smallpt2pbrt/smallpt_rewrite.cpp ("structured smallpt", the pbrt-style step towards ky.cpp; the one
+                          reference program that builds in this image and therefore pins this path, oracle/_ref): the nine
+                          spheres mirrored in z (1199-1244), PerspectiveCamera fov 53 (1391), RandomSampler (uniform jitter,
+                          `samps` samples per PIXEL, 369-392), RecursionPathIntegrater(max_depth 10) (1335-1372), one clamp per
+                          pixel (1316).  Streams are keyed (seed, pixel, sample). */
+enum ky_smallpt_variant { KY_SP_VARIANT_SMALLPT = 0, KY_SP_VARIANT_REWRITE = 1 };
+
 typedef struct ky_smallpt_params {
     int width, height;
-    int samps;                       /* samples per SUBPIXEL (smallpt.cpp:92: argv[1] / 4); spp = 4 * samps */
+    int samps;                       /* variant 0: samples per SUBPIXEL (smallpt.cpp:92: argv[1] / 4), spp = 4 * samps;
+                                        variant 1: samples per pixel (smallpt_rewrite.cpp:1388: argv[1] / 4) */
     uint32_t seed;
-    int max_depth;                   /* `if (depth > 10) return obj.e` (smallpt.cpp:63): 10 */
+    int max_depth;                   /* `if (depth > 10) return obj.e` (smallpt.cpp:63) / RecursionPathIntegrater(10) (1396): 10 */
+    int variant;                     /* ky_smallpt_variant */
 } ky_smallpt_params;
 
 /* The scene of smallpt.cpp:42-52; `out` has room for 9 spheres.  Returns 9.  Pure host code. */
 int kyhip_smallpt_scene(ky_smallpt_sphere* out);
+/* Scene::CreateSmallptScene of smallpt_rewrite.cpp:1199-1244 (the same spheres at -z).  Returns 9.  Pure host code. */
+int kyhip_smallpt_scene_rewrite(ky_smallpt_sphere* out);
 
 /* main()'s loop nest (smallpt.cpp:91-118) with the fixed camera of 93-94.  image_rgb: width * height * 3 doubles in
-   smallpt's own order, c[(height - y - 1) * width + x], i.e. row 0 is the TOP of the picture; the image is overwritten. */
+   smallpt's own order, c[(height - y - 1) * width + x], i.e. row 0 is the TOP of the picture; the image is overwritten.
+   Variant 1: Integrater::Render (smallpt_rewrite.cpp:1287-1318) into a cleared Film, pixels_[y * width + x] with y = 0 the
+   top row (517-520).  For variant 1 the kat entry ignores (sx, sy), which must be 0. */
 int kyhip_smallpt_render(int device, const ky_smallpt_sphere* spheres, int n_spheres, const ky_smallpt_params* params,
                          double* image_rgb);
 

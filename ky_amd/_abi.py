@@ -19,6 +19,7 @@ INTEGRATOR_DIRECT_LIGHTING, INTEGRATOR_PATH_TRACING_ITERATION = 6, 11
 INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION, INTEGRATOR_PATH_TRACING_RECURSION, INTEGRATOR_PATH_TRACING_RECURSION_DEFERED = 8, 9, 10
 DIRECT_IDLE, DIRECT_BSDF, DIRECT_LIGHT, DIRECT_BSDF_MIS, DIRECT_LIGHT_MIS, DIRECT_BOTH_MIS = 0, 4, 8, 16, 32, 48
 SAMPLER_DEBUG, SAMPLER_RANDOM = 0, 1
+SP_VARIANT_SMALLPT, SP_VARIANT_REWRITE = 0, 1
 KY_OK, KY_ERR_INVALID_VALUE, KY_ERR_LIMIT, KY_ERR_DEVICE, KY_ERR_NO_DEVICE = 0, -1, -2, -3, -4
 
 # cornell_box_enum_t (ky.cpp:3121-3145)
@@ -77,7 +78,8 @@ class SmallptSphere(C.Structure):   # ky_smallpt_sphere
 
 
 class SmallptParams(C.Structure):   # ky_smallpt_params
-    _fields_ = [("width", C.c_int), ("height", C.c_int), ("samps", C.c_int), ("seed", C.c_uint32), ("max_depth", C.c_int)]
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("samps", C.c_int), ("seed", C.c_uint32), ("max_depth", C.c_int),
+                ("variant", C.c_int)]
 
 
 SP_DIFF, SP_SPEC, SP_REFR = 0, 1, 2
@@ -97,6 +99,7 @@ KYHIP_SYMBOLS = {
     "kyhip_film_add_tiles_device": (C.c_int, [C.c_int, PP, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "kyhip_kernel_ms": (C.c_float, [C.c_int]),
     "kyhip_smallpt_scene": (C.c_int, [SSP]),
+    "kyhip_smallpt_scene_rewrite": (C.c_int, [SSP]),
     "kyhip_smallpt_render": (C.c_int, [C.c_int, SSP, C.c_int, SPP, C.c_void_p]),
     "kyhip_smallpt_kat_radiance": (C.c_int, [C.c_int, SSP, C.c_int, SPP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "kyhip_kat_intersect": (C.c_int, [C.c_int, C.POINTER(Shape), C.c_void_p, C.c_int, C.c_void_p]),

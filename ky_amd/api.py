@@ -175,8 +175,16 @@ def smallpt_scene():
     return spheres
 
 
-def smallpt_params(width, height, samps, seed=1234, max_depth=10):
-    return A.SmallptParams(width, height, samps, seed, max_depth)
+def smallpt_scene_rewrite():
+    """Scene::CreateSmallptScene of smallpt2pbrt/smallpt_rewrite.cpp:1199-1244 (the same spheres at -z)."""
+    spheres = (A.SmallptSphere * 9)()
+    n = A.load_kyhip().kyhip_smallpt_scene_rewrite(spheres)
+    assert n == 9
+    return spheres
+
+
+def smallpt_params(width, height, samps, seed=1234, max_depth=10, variant=A.SP_VARIANT_SMALLPT):
+    return A.SmallptParams(width, height, samps, seed, max_depth, variant)
 
 
 def smallpt_render(spheres, params, device=0):

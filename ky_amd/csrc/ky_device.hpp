@@ -60,8 +60,14 @@ __device__ __noinline__ void ky_clk_mark(int k) {
     }
 }
 #define KY_CLK(k) ky_clk_mark(k)
+#elif defined(KY_MARKS)   // listing aid: a comment in the assembly at every phase boundary (tools/static_profile.py --marks)
+#define KY_CLK(k) asm volatile("; KYMARK " #k)
 #else
 #define KY_CLK(k) do { } while (0)
+#endif
+
+#ifndef KY_ABL
+#define KY_ABL 0
 #endif
 
 namespace kyd {
@@ -606,6 +612,26 @@ KY_DEV void concentric_disk(float u0, float u1, float& px, float& py) {
     py = origin ? 0.f : sin_rev(rev) * radius;
 }
 
+// The direction half of sample_ for the two non-delta lobes (their value and pdf are eval_ / pdf_ of that direction:
+// 2253-2254, 2526-2527), so that a caller that rarely needs the value can defer it (estimate_by_bsdf).
+KY_DEV f3 bsdf_sample_dir_nondelta(const Bsdf& B, f3 wo, float u0, float u1) {
+    if (B.lobe == LOBE_PHONG) {  // 2510-2524 + 2533-2543
+        const float ct = pow_nonneg(u1, rcp(B.m->exponent + 1.f));
+        const float st = fsqrt(1.f - ct * ct);
+        const f3 local = mk3(cos_rev(u0) * st, sin_rev(u0) * st, ct);   // phi = 2 pi u0
+        const Frame fr = make_frame(mk3(-wo.x, -wo.y, wo.z));           // frame_t(wr): wr is unit because wo is
+        f3 wi = to_world(fr, local);
+        if (wo.z < 0) wi.z = -wi.z;
+        return wi;
+    }
+    // lambert: cosine_hemisphere_sample 737-743, flipped into wo's hemisphere (2247-2249)
+    float px, py;
+    concentric_disk(u0, u1, px, py);
+    float z = fsqrt(fmaxf(0.f, 1 - px * px - py * py));
+    if (wo.z < 0) z = -z;
+    return mk3(px, py, z);
+}
+
 // bsdf sample_ x4
 KY_DEV BsdfSample bsdf_sample_local(const Bsdf& B, f3 wo, float u0, float u1) {
     BsdfSample s;
@@ -613,12 +639,8 @@ KY_DEV BsdfSample bsdf_sample_local(const Bsdf& B, f3 wo, float u0, float u1) {
     s.wi = mk3(0, 0, 0);
     s.pdf = 0.f;
     s.flags = 0;
-    if (B.lobe == LOBE_LAMBERT) {  // 2242-2257 + cosine_hemisphere_sample 737-743
-        float px, py;
-        concentric_disk(u0, u1, px, py);
-        float z = fsqrt(fmaxf(0.f, 1 - px * px - py * py));
-        if (wo.z < 0) z = -z;
-        s.wi = mk3(px, py, z);
+    if (B.lobe == LOBE_LAMBERT) {  // 2242-2257
+        s.wi = bsdf_sample_dir_nondelta(B, wo, u0, u1);
         bsdf_eval_pdf(B, wo, s.wi, s.f, s.pdf);
         s.flags = BSDF_REFLECTION | BSDF_DIFFUSE;
     } else if (B.lobe == LOBE_MIRROR) {  // 2292-2307
@@ -653,15 +675,9 @@ KY_DEV BsdfSample bsdf_sample_local(const Bsdf& B, f3 wo, float u0, float u1) {
             }
             // else total internal reflection: f = 0, pdf = 0 (2407)
         }
-    } else {  // phong, 2510-2529 + 2533-2543
-        const float ct = pow_nonneg(u1, rcp(B.m->exponent + 1.f));
-        const float st = fsqrt(1.f - ct * ct);
-        const f3 local = mk3(cos_rev(u0) * st, sin_rev(u0) * st, ct);   // phi = 2 pi u0
-        const Frame fr = make_frame(mk3(-wo.x, -wo.y, wo.z));           // frame_t(wr): wr is unit because wo is
-        f3 wi = to_world(fr, local);
-        if (wo.z < 0) wi.z = -wi.z;
-        s.wi = wi;
-        bsdf_eval_pdf(B, wo, wi, s.f, s.pdf);
+    } else {  // phong, 2510-2529
+        s.wi = bsdf_sample_dir_nondelta(B, wo, u0, u1);
+        bsdf_eval_pdf(B, wo, s.wi, s.f, s.pdf);
         s.flags = BSDF_REFLECTION | BSDF_GLOSSY;
     }
     return s;
@@ -892,26 +908,32 @@ KY_DEV f3 estimate_by_bsdf(const DScene* __restrict__ S, const LdsScene& Lds, co
     const DLight& L = S->light[li];
     f3 Ld = mk3(0, 0, 0);
     if (L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION) return Ld;  // light.is_delta(), 3894 / 3977 (wave-uniform)
+#if KY_ABL == 1 || KY_ABL == 7   // measurement builds only (tools/ablate_pmc.sh): this estimator's instructions removed
+    return Ld;
+#endif
     BsdfSample bs;
     f3 f_cos = mk3(0, 0, 0), o = mk3(0, 0, 0), Li = mk3(0, 0, 0);
     bs.wi = mk3(0, 0, 1);
     bs.pdf = 0.f;
     bool live = false;
-    if (active) {
-        bs = bsdf_sample_local(v.bsdf, vertex_wo(v), u0, u1);
-        bs.wi = to_world(vertex_frame(v), bs.wi);  // 2176
-        f_cos = bs.f * fabsf(dot(bs.wi, v.normal));
-        live = !(is_black(f_cos) || (MIS ? (bs.pdf <= 0) : (bs.pdf == 0)));
-        o = offset_ray_origin(v.position, v.normal, bs.wi);  // isect.spawn_ray, 665-668
-    }
     const bool fast = L.kind == KY_LIGHT_AREA && L.n_carriers >= 0 && S->n_gen == 0;  // wave-uniform
     if (fast) {
+        // Only the DIRECTION is sampled up front; the BSDF value and pdf (a pow for the Phong lobe) are evaluated for the few
+        // lanes whose ray reaches a carrier that emits towards it -- for all other lanes Li = 0 decides the estimate (3996-4003).
+        // (Delta lobes never get here: sample_all_light runs for non-delta vertices only, 4571.)
+        const bool act = active && !bsdf_is_delta(v.bsdf);
+        f3 wi_l = mk3(0, 0, 1);
+        if (act) {
+            wi_l = bsdf_sample_dir_nondelta(v.bsdf, vertex_wo(v), u0, u1);
+            bs.wi = to_world(vertex_frame(v), wi_l);  // 2176
+            o = offset_ray_origin(v.position, v.normal, bs.wi);  // isect.spawn_ray, 665-668
+        }
         // (a) nearest carrier surface along the ray, and what it emits towards the ray (3084, 2957-2960)
         float t_l = K_INF;
         int c = -1;
         for (int k = 0; k < L.n_carriers; ++k) {
             float t;
-            const bool ok = live & surf_hit(S->all[L.carrier[k]], S->full, o, bs.wi, t_l, t);
+            const bool ok = act & surf_hit(S->all[L.carrier[k]], S->full, o, bs.wi, t_l, t);
             t_l = ok ? t : t_l;
             c = ok ? L.carrier[k] : c;
         }
@@ -921,12 +943,20 @@ KY_DEV f3 estimate_by_bsdf(const DScene* __restrict__ S, const LdsScene& Lds, co
             Li = surface_emission(Lds, c, hit_normal(Lds.hit[c], hp, bs.wi), -bs.wi);
             pending = !is_black(Li);
         }
+        if (pending) {  // rare: now the sample's value and pdf (3979-3987)
+            bsdf_eval_pdf(v.bsdf, vertex_wo(v), wi_l, bs.f, bs.pdf);
+            f_cos = bs.f * fabsf(dot(bs.wi, v.normal));
+            live = !(is_black(f_cos) || (MIS ? (bs.pdf <= 0) : (bs.pdf == 0)));
+            pending = live;
+        }
         // (b) is any surface in front of the carrier?  (the carrier itself reproduces t_l exactly, and t < t_l is strict)
         unsigned long long queries = __ballot(pending);
         bool blocked = false;
         if (__popcll(queries) > KY_TRANSPOSE_MAX) {
             KY_PROBE(2);
-            if (pending) blocked = trace_any(S, o, bs.wi, t_l);
+            // the traversal may test the carrier with another formulation than (a) did (aar_hit vs par_hit): keep its own
+            // hit, a few ulp around t_l, out of the interval
+            if (pending) blocked = trace_any(S, o, bs.wi, t_l * (1.f - 1e-6f));
         } else {
             const int lane = (int)__lane_id();
             while (queries) {
@@ -947,16 +977,23 @@ KY_DEV f3 estimate_by_bsdf(const DScene* __restrict__ S, const LdsScene& Lds, co
             }
         }
         if (blocked) Li = mk3(0, 0, 0);
-    } else if (live) {
+    } else {
+        if (active) {
+            bs = bsdf_sample_local(v.bsdf, vertex_wo(v), u0, u1);
+            bs.wi = to_world(vertex_frame(v), bs.wi);  // 2176
+            f_cos = bs.f * fabsf(dot(bs.wi, v.normal));
+            live = !(is_black(f_cos) || (MIS ? (bs.pdf <= 0) : (bs.pdf == 0)));
+            o = offset_ray_origin(v.position, v.normal, bs.wi);  // isect.spawn_ray, 665-668
+        }
         float t = K_INF;
         KY_PROBE(2);
-        const int hs = trace_nearest(S, o, bs.wi, t);
+        const int hs = live ? trace_nearest(S, o, bs.wi, t) : -1;
         if (hs >= 0) {
             if (Lds.hit[hs].area_light == li) {  // 3912 / 3994
                 const f3 hp = o + t * bs.wi;
                 Li = surface_emission(Lds, hs, hit_normal(Lds.hit[hs], hp, bs.wi), -bs.wi);
             }
-        } else if (L.kind == KY_LIGHT_ENVIRONMENT) {
+        } else if (live && L.kind == KY_LIGHT_ENVIRONMENT) {
             Li = ld3(L.color);  // light.environmental_radiance(ray), 3918 / 4000
         }
     }
@@ -977,6 +1014,9 @@ KY_DEV f3 estimate_by_emitter(const DScene* __restrict__ S, const LdsScene& Lds,
     const DLight& L = S->light[li];
     f3 Ld = mk3(0, 0, 0);
     KY_PROBE(3);
+#if KY_ABL == 2 || KY_ABL == 7
+    return Ld;
+#endif
     const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1);
     const bool dead = is_black(ls.Li) || (MIS ? (ls.pdf <= 0) : (ls.pdf == 0));
     KY_CLK(5);
@@ -989,8 +1029,16 @@ KY_DEV f3 estimate_by_emitter(const DScene* __restrict__ S, const LdsScene& Lds,
         const float dist = d2 * inv_d;
         const f3 o = offset_ray_origin(v.position, v.normal, dir);
         KY_PROBE(4);
+#if KY_ABL == 3
+        const bool occ = o.x == 1e30f;   // never: the traversal's instructions removed, everything after it kept
+#else
         const bool occ = trace_any(S, o, dir, dist - 2e-3f);
+#endif
         KY_CLK(6);
+#if KY_ABL == 4
+        if (!occ) Ld = mk3(1e-30f, 0, 0);
+        return Ld;
+#endif
         if (!occ) {
             KY_PROBE(5);
             f3 f;
@@ -1017,17 +1065,22 @@ KY_DEV f3 sample_all_light(const DScene* __restrict__ S, const LdsScene& Lds, co
     for (int li = 0; li < nl; ++li) {
         // the reference's GCC build draws random_bsdf first, then random_light (3866-3868), for every light and strategy
         float ub0 = 0.f, ub1 = 0.f, ul0 = 0.f, ul1 = 0.f;
-        if (active) {
-            ub0 = sampler_next<DEBUG_SAMPLER>(smp); ub1 = sampler_next<DEBUG_SAMPLER>(smp);
-            ul0 = sampler_next<DEBUG_SAMPLER>(smp); ul1 = sampler_next<DEBUG_SAMPLER>(smp);
-        }
-        KY_CLK(3);
+        if (active) { ub0 = sampler_next<DEBUG_SAMPLER>(smp); ub1 = sampler_next<DEBUG_SAMPLER>(smp); }
         if (strategy == KY_DIRECT_BOTH_MIS) {  // 4076-4088
-            const f3 Lb = estimate_by_bsdf<true>(S, Lds, v, li, ub0, ub1, active);
+            KY_CLK(3);
+            const f3 Lb = estimate_by_bsdf<true>(S, Lds, v, li, ub0, ub1, active);   // draws nothing itself
             KY_CLK(4);
             f3 Ll = mk3(0, 0, 0);
-            if (active) Ll = estimate_by_emitter<true>(S, Lds, v, li, ul0, ul1);
+            if (active) {   // random_light is drawn here, after the BSDF half: same stream position, two registers fewer across it
+                ul0 = sampler_next<DEBUG_SAMPLER>(smp); ul1 = sampler_next<DEBUG_SAMPLER>(smp);
+                Ll = estimate_by_emitter<true>(S, Lds, v, li, ul0, ul1);
+            }
             Ld = Ld + (0.5f * Lb + 0.5f * Ll);
+            continue;
+        }
+        if (active) { ul0 = sampler_next<DEBUG_SAMPLER>(smp); ul1 = sampler_next<DEBUG_SAMPLER>(smp); }
+        KY_CLK(3);
+        if (strategy == KY_DIRECT_BOTH_MIS) {
         } else if (strategy == KY_DIRECT_BSDF_MIS) {
             Ld = Ld + estimate_by_bsdf<true>(S, Lds, v, li, ub0, ub1, active);
         } else if (strategy == KY_DIRECT_LIGHT_MIS) {
@@ -1125,9 +1178,36 @@ KY_DEV int path_pick_lobe(PathState& ps, int surface, const LdsScene& Lds) {
     return pick_lobe(M, lobe_u);
 }
 
+// A vertex of path_tracing_iteration_t on a delta surface (mirror / glass): it gets no direct lighting (4571), only the
+// continuation (4586-4612).  The lane engine runs it right after the traversal, so that the lane can trace again before the
+// wave enters the shading phase (whose direct-lighting part such a lane would sit out).  Same draws, same order: path 2D,
+// then the roulette number if bounces > 3.
+template <bool DEBUG_SAMPLER>
+KY_DEV bool path_delta_bounce(PathState& ps, const Vertex& v, const DMat& M, int lobe) {
+    const Frame fr = make_frame(v.normal);
+    const float u0 = sampler_next<DEBUG_SAMPLER>(ps.smp), u1 = sampler_next<DEBUG_SAMPLER>(ps.smp);
+    BsdfSample bs = bsdf_sample_local(Bsdf{lobe, &M}, to_local(fr, -ps.d), u0, u1);
+    bs.wi = to_world(fr, bs.wi);
+    if (is_black(bs.f) || bs.pdf == 0.f) return false;  // 4588 (total internal reflection in the refraction branch)
+    ps.beta = ps.beta * (bs.f * (fabsf(dot(bs.wi, v.normal)) * rcp(bs.pdf)));  // 4592
+    ps.prev_specular = (bs.flags & BSDF_SPECULAR) != 0;  // 4596: always true here
+    ps.o = offset_ray_origin(v.position, v.normal, bs.wi);  // 4597
+    ps.d = bs.wi;
+    if (ps.bounces > 3) {  // Russian roulette, 4601-4612
+        const float q = fmaxf(0.05f, 1 - max3(ps.beta));
+        const float u = sampler_next<DEBUG_SAMPLER>(ps.smp);
+        if (u < q) return false;
+        ps.beta = ps.beta * rcp(1 - q);
+    }
+    ps.bounces += 1;
+    return true;  // after a specular bounce the next traversal may still add emission at bounces == max_depth (4548)
+}
+
 // Second half: material, direct lighting, continuation.  WAVE-UNIFORM call: every lane of the wave calls it, `active`
 // says whether this lane holds a vertex.  Returns true when the (active) lane's path continues.
-template <bool DEBUG_SAMPLER>
+// NODELTA: the caller guarantees that the vertex's lobe is Lambert or Phong (delta vertices were bounced by path_delta_bounce),
+// so the mirror / glass code is not instantiated in the shading phase.
+template <bool DEBUG_SAMPLER, bool NODELTA = false>
 KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, const LdsScene& Lds, const RenderConst& rc, bool active,
                        int lobe = -1) {
     if (active) {
@@ -1161,7 +1241,7 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, c
     const bool recursion = rc.integrator == KY_INTEGRATOR_PATH_TRACING_RECURSION;
     const bool defered = rc.integrator == KY_INTEGRATOR_PATH_TRACING_RECURSION_DEFERED;
     const bool simple = rc.integrator == KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION;
-    const bool delta = bsdf_is_delta(v.bsdf);
+    const bool delta = NODELTA ? false : bsdf_is_delta(v.bsdf);
     const bool nee = active && !delta;  // 4571
     KY_PROBE(6);
     if (!simple) {  // simple_path_tracing_recursion_t samples the BSDF only
@@ -1193,7 +1273,15 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, c
     // sample BSDF to get the new path direction, 4586 / 4213 / 4383 / 4495
     const float u0 = sampler_next<DEBUG_SAMPLER>(ps.smp), u1 = sampler_next<DEBUG_SAMPLER>(ps.smp);
     KY_PROBE(7);
-    BsdfSample bs = bsdf_sample_local(v.bsdf, vertex_wo(v), u0, u1);
+    BsdfSample bs;
+    if (NODELTA) {
+        const f3 wo_l = vertex_wo(v);
+        bs.wi = bsdf_sample_dir_nondelta(v.bsdf, wo_l, u0, u1);
+        bsdf_eval_pdf(v.bsdf, wo_l, bs.wi, bs.f, bs.pdf);
+        bs.flags = BSDF_REFLECTION;   // diffuse or glossy: not specular
+    } else {
+        bs = bsdf_sample_local(v.bsdf, vertex_wo(v), u0, u1);
+    }
     bs.wi = to_world(vertex_frame(v), bs.wi);
     if (is_black(bs.f) || bs.pdf == 0.f) return false;  // 4588 / 4215 / 4385 / 4497
     if (rc.integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION) {

@@ -140,6 +140,9 @@ static ShardConst make_shard(const ky_render_params* p) {
 #ifndef KY_RETRACE_THRESHOLD
 #define KY_RETRACE_THRESHOLD 40
 #endif
+#ifndef KY_DELTA_IN_TRACE
+#define KY_DELTA_IN_TRACE 0
+#endif
 #ifndef KY_WAVES_PER_EU
 #define KY_WAVES_PER_EU 6           // the hot instantiation <false, both_mis>: 80 VGPRs
 #endif
@@ -168,6 +171,8 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? KY_WAVES_PER_EU : KY_WAVES_PER
     const int nee_weight = (rc.strategy == KY_DIRECT_IDLE || rc.integrator < KY_INTEGRATOR_DIRECT_LIGHTING ||
                             rc.integrator == KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION) ? 0 : S->n_lights;
 
+    // path_tracing_iteration_t only: delta vertices are bounced inside the trace phase (path_delta_bounce)
+    const bool delta_in_trace = rc.integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION;
     const int lane = threadIdx.x & 63;
     ItemSlot* my_ring = ring[threadIdx.x >> 6];
 
@@ -261,6 +266,7 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? KY_WAVES_PER_EU : KY_WAVES_PER
         Vertex v;
         v.in_lds = true;   // shading frame and local wo in LDS (ky_device.hpp, VertexLds)
         bool have_vertex = false;
+        int lobe = -1;
         for (int attempt = 0;; ++attempt) {
             if (!alive && !done && open) {  // next camera sample of this lane's pixel, 3712-3715
                 const int xy = c_xy[tid], s = c_s[tid];
@@ -272,17 +278,28 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? KY_WAVES_PER_EU : KY_WAVES_PER
             const bool tracing = alive && !have_vertex;
             if (!__any(tracing)) break;
             if (tracing) {
-                if (path_intersect<DEBUG_SAMPLER>(ps, v, S, Lds, rc)) {
-                    have_vertex = true;
-                } else {
+                bool ended = !path_intersect<DEBUG_SAMPLER>(ps, v, S, Lds, rc);
+                if (!ended) {
+#if KY_DELTA_IN_TRACE
+                    if (delta_in_trace) {
+                        // the material's lobe decision is made here (same stream position as in path_shade); a delta vertex
+                        // takes its continuation at once and stays in the tracing state
+                        lobe = path_pick_lobe<DEBUG_SAMPLER>(ps, v.surface, Lds);
+                        if (lobe == LOBE_MIRROR || lobe == LOBE_GLASS) ended = !path_delta_bounce<DEBUG_SAMPLER>(ps, v, Lds.mat[Lds.hit[v.surface].material], lobe);
+                        else have_vertex = true;
+                    } else
+#endif
+                        have_vertex = true;
+                }
+                if (ended) {
                     c_lsum[0][tid] += ps.Lo.x * rc.inv_spp; c_lsum[1][tid] += ps.Lo.y * rc.inv_spp; c_lsum[2][tid] += ps.Lo.z * rc.inv_spp;
                     alive = false;
                 }
             }
             if (attempt >= KY_MAX_RETRACE) break;
-            // lanes that could start another path right now; worth one more traversal if they would otherwise idle
-            // through (2 traversals x lights + shading) that is worth more than the extra traversal
-            const int idle = __popcll(__ballot(!alive && !done && open));
+            // lanes that could trace right now (a new path, or the ray leaving a delta vertex); worth one more traversal if they
+            // would otherwise idle through (2 traversals x lights + shading) that is worth more than the extra traversal
+            const int idle = __popcll(__ballot((!alive && !done && open) || (alive && !have_vertex)));
             if (idle * (2 * nee_weight + 1) < KY_RETRACE_THRESHOLD) break;
         }
         KY_CLK(1);
@@ -292,7 +309,8 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? KY_WAVES_PER_EU : KY_WAVES_PER
         }
         // ---- (3) shade the vertex: direct lighting, continuation ----
         {
-            const bool cont = path_shade<DEBUG_SAMPLER>(ps, v, S, Lds, rc, have_vertex);  // wave-uniform call
+            // wave-uniform call; in the hot instantiation every vertex that gets here is Lambert or Phong
+            const bool cont = path_shade<DEBUG_SAMPLER, (STRATEGY >= 0) && KY_DELTA_IN_TRACE>(ps, v, S, Lds, rc, have_vertex, lobe);
             if (have_vertex && !cont) {
                 c_lsum[0][tid] += ps.Lo.x * rc.inv_spp; c_lsum[1][tid] += ps.Lo.y * rc.inv_spp; c_lsum[2][tid] += ps.Lo.z * rc.inv_spp;
                 alive = false;
@@ -1049,8 +1067,17 @@ int kyhip_smallpt_scene(ky_smallpt_sphere* out) {
     return 9;
 }
 
+int kyhip_smallpt_scene_rewrite(ky_smallpt_sphere* out) {   // smallpt_rewrite.cpp:1201-1211, 1225-1242: z -> -z
+    const int n = kyhip_smallpt_scene(out);
+    if (n < 0) return n;
+    static const double z[9] = {-81.6, -81.6, -1e5, 1e5 - 170, -81.6, -81.6, -47, -78, -81.6};
+    for (int i = 0; i < n; ++i) out[i].p[2] = z[i];
+    return n;
+}
+
 static int smallpt_check(const ky_smallpt_sphere* spheres, int n, const ky_smallpt_params* p) {
     if (!spheres || !p) return fail(KY_ERR_INVALID_VALUE, "null argument");
+    if (p->variant != KY_SP_VARIANT_SMALLPT && p->variant != KY_SP_VARIANT_REWRITE) return fail(KY_ERR_INVALID_VALUE, "unknown smallpt variant %d", p->variant);
     if (n <= 0 || n > kysp::SP_MAX_SPHERES) return fail(KY_ERR_INVALID_VALUE, "1..%d spheres", kysp::SP_MAX_SPHERES);
     if (p->width <= 0 || p->height <= 0 || p->width > 16384 || p->height > 16384 || p->samps <= 0 || p->max_depth < 0)
         return fail(KY_ERR_INVALID_VALUE, "invalid smallpt params");
@@ -1083,7 +1110,7 @@ int kyhip_smallpt_render(int device, const ky_smallpt_sphere* spheres, int n, co
     hipLaunchKernelGGL(kysp::smallpt_kernel, dim3(blocks), dim3(256), 0, 0, d_sph, k, d_sub);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, 0));
-    hipLaunchKernelGGL(kysp::smallpt_resolve_kernel, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, 0, d_sub, d_img, p->width, p->height);
+    hipLaunchKernelGGL(kysp::smallpt_resolve_kernel, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, 0, d_sub, d_img, p->width, p->height, p->variant);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(image_rgb, d_img, n_px * 3 * sizeof(double), hipMemcpyDeviceToHost));
     HIP_TRY(hipFree(d_sph)); HIP_TRY(hipFree(d_sub)); HIP_TRY(hipFree(d_img));
@@ -1096,6 +1123,7 @@ int kyhip_smallpt_kat_radiance(int device, const ky_smallpt_sphere* spheres, int
     if (rcode != KY_OK) return rcode;
     if (!out3 || n <= 0 || s0 < 0 || x < 0 || y < 0 || x >= p->width || y >= p->height || (sx | sy) < 0 || sx > 1 || sy > 1)
         return fail(KY_ERR_INVALID_VALUE, "bad KAT arguments");
+    if (p->variant == KY_SP_VARIANT_REWRITE && (sx | sy) != 0) return fail(KY_ERR_INVALID_VALUE, "variant 1 has no subpixels: sx = sy = 0");
     std::lock_guard<std::mutex> lock(g_mutex);
     DeviceCtx* c = nullptr;
     rcode = get_ctx(device, &c);

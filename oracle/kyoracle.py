@@ -43,6 +43,9 @@ def load():
         _lib.kyo_smallpt_render.argtypes = [A.SSP, C.c_int, A.SPP, C.c_int, C.c_void_p]
         _lib.kyo_smallpt_radiance.argtypes = [A.SSP, C.c_int, A.SPP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         _lib.kyo_smallpt_scene.argtypes = [A.SSP]
+        _lib.kyo_sprw_render.argtypes = [A.SSP, C.c_int, A.SPP, C.c_int, C.c_void_p]
+        _lib.kyo_sprw_radiance.argtypes = [A.SSP, C.c_int, A.SPP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _lib.kyo_sprw_scene.argtypes = [A.SSP]
     return _lib
 
 
@@ -159,4 +162,40 @@ def smallpt_radiance(spheres, params, x, y, sx, sy, s0, n):
     rc = load().kyo_smallpt_radiance(spheres, len(spheres), C.byref(params), x, y, sx, sy, s0, n, out.ctypes.data_as(C.c_void_p))
     if rc != 0:
         raise ValueError(f"kyo_smallpt_radiance returned {rc}")
+    return out
+
+
+# ---- smallpt_rewrite_oracle.cpp: smallpt2pbrt/smallpt_rewrite.cpp restated (double precision) ----
+
+def sprw_scene():
+    spheres = (A.SmallptSphere * 9)()
+    assert load().kyo_sprw_scene(spheres) == 9
+    return spheres
+
+
+def sprw_render(spheres, params, rng_mode=0):
+    """Integrater::Render into a cleared film: float64 [H, W, 3], row 0 = top.  rng_mode 1: the reference's own
+    std::mt19937_64 per image row (byte-exact with oracle/_ref/smallpt_rewrite); 0: the HIP path's per-sample streams."""
+    film = np.zeros((params.height, params.width, 3), np.float64)
+    rc = load().kyo_sprw_render(spheres, len(spheres), C.byref(params), rng_mode, film.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise ValueError(f"kyo_sprw_render returned {rc}")
+    return film
+
+
+def sprw_radiance(spheres, params, x, y, s0, n):
+    out = np.zeros((n, 3), np.float64)
+    rc = load().kyo_sprw_radiance(spheres, len(spheres), C.byref(params), x, y, s0, n, out.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise ValueError(f"kyo_sprw_radiance returned {rc}")
+    return out
+
+
+def sprw_gamma_bytes(film):
+    """GammaEncoding (smallpt_rewrite.cpp:494) with the C library's pow, like the reference binary."""
+    film = np.ascontiguousarray(film, np.float64)
+    out = np.zeros(film.shape, np.uint8)
+    lib = load()
+    lib.kyo_sprw_gamma_bytes.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    assert lib.kyo_sprw_gamma_bytes(film.ctypes.data_as(C.c_void_p), film.size, out.ctypes.data_as(C.c_void_p)) == 0
     return out

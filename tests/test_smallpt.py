@@ -24,7 +24,7 @@ def test_scene_tables_agree(A, O):
         assert list(a.p) == list(b.p) and list(a.e) == list(b.e) and list(a.c) == list(b.c)
     assert [s.refl for s in mine] == [0, 0, 0, 0, 0, 0, 1, 2, 0]
     assert mine[8].rad == 600 and list(mine[8].e) == [12, 12, 12] and mine[8].p[1] == 681.6 - .27
-    assert C.sizeof(A.SmallptSphere) == 88 and C.sizeof(A.SmallptParams) == 20
+    assert C.sizeof(A.SmallptSphere) == 88 and C.sizeof(A.SmallptParams) == 24
 
 
 def test_oracle_facts(A, O):

@@ -1,0 +1,9 @@
+#!/bin/bash
+# tools/mkvariant.sh <name> [extra hipcc flags...]  -> build_variants/<name>.so + build_variants/<name>.txt (resource usage of the render kernels)
+NAME=$1; shift
+BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical -no-hip-rt -fno-slp-vectorize -fno-hip-fp32-correctly-rounded-divide-sqrt -DKY_WAVES_PER_EU=6"
+SRC=${KY_SRC:-ky_amd/csrc/kyhip.hip}
+hipcc $BASE "$@" -Rpass-analysis=kernel-resource-usage -shared -o build_variants/$NAME.so $SRC 2> /tmp/bv/$NAME.log
+grep -A9 "Function Name: _Z13render_kernel" /tmp/bv/$NAME.log | grep -E "Function Name|VGPRs:|Spill|Occupancy|TotalSGPRs|ScratchSize" | sed 's/.*usage\]//; s/remark: [^ ]* //; s/\[-Rpass.*//' > build_variants/$NAME.txt
+grep -E "error" /tmp/bv/$NAME.log | head -5
+echo "== $NAME: $*"; cat build_variants/$NAME.txt | tr '\n' ' ' | sed 's/Function Name/\n  FN/g'; echo

@@ -52,6 +52,6 @@ void run(const char* name, int blocks_per_cu) {
     hipFree(d);
 }
 int main() {
-    for (int b : {1, 2, 4}) { run<0>("v_fma_f32", b); run<1>("v_mul/add/sub_f32", b); run<2>("v_rcp_f32", b); run<3>("cndmask/cmp/xor/mul_lo", b); run<4>("v_pk_fma_f32", b); run<5>("v_pk_mul/add_f32", b); }
+    for (int b : {1, 2, 4, 8}) { run<0>("v_fma_f32", b); run<1>("v_mul/add/sub_f32", b); run<2>("v_rcp_f32", b); run<3>("cndmask/cmp/xor/mul_lo", b); run<4>("v_pk_fma_f32", b); run<5>("v_pk_mul/add_f32", b); }
     return 0;
 }

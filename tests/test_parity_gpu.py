@@ -466,7 +466,9 @@ def test_engines_agree(A, api):
             # (a point light under the plain bsdf strategy is black by construction: delta lights are skipped, 3894)
             assert a.max() > 0 or p.direct_sample == A.DIRECT_BSDF, (p.samples_per_pixel, p.direct_sample)
             assert np.array_equal(b, b2)                       # scheduling does not show in the image
-            assert np.abs(a - b).max() <= 2e-6, (p.samples_per_pixel, p.direct_sample, float(np.abs(a - b).max()))
+            # same arithmetic per sample, but the two kernels inline it into different surroundings (fp contraction can differ
+            # by an ulp per term) and sum a pixel's samples (unclamped, up to the light's radiance) in different orders: ~1e-5 on the clamped mean
+            assert np.abs(a - b).max() <= 2e-5, (p.samples_per_pixel, p.direct_sample, float(np.abs(a - b).max()))
             if p.integrator != A.INTEGRATOR_PATH_TRACING_ITERATION:
                 assert np.array_equal(a, b)
     finally:

@@ -140,8 +140,14 @@ def test_gpu_film_matches_reference_image_statistically(A, api, O):
     film = api.smallpt_render(sp, p)
     img = O.sprw_gamma_bytes(film).astype(np.float64)
     means = img.reshape(48, 16, 64, 16, 3).mean(axis=(1, 3))
-    d = np.abs(means - g["means64"])
-    # two independent 256-spp renders: block-mean noise of the 8-bit values is ~0.3; any systematic difference (camera, a
-    # material, the roulette rule) shows up as whole levels
-    assert d.mean() < 0.35 and d.max() < 3.0, (d.mean(), d.max())
-    assert abs(means.mean() - g["means64"].mean()) < 0.08
+    # The reference re-seeds its generator for every image row (Sampler::Clone, 1300): all rows of its picture replay ONE
+    # random stream, so its noise does not average out down a block's rows -- a 16 x 16 block mean of its 256-spp picture
+    # is as noisy as a 16-pixel row segment (about 2.5 of 255 levels).  Compare 192 x 256 regions instead (noise ~0.6 level);
+    # a systematic difference (camera, a material, the roulette rule) shifts whole regions by several levels.
+    big = lambda m: m.reshape(4, 12, 4, 16, 3).mean(axis=(1, 3))
+    d = np.abs(big(means) - big(g["means64"].astype(np.float64)))
+    assert d.mean() < 1.0 and d.max() < 3.0, (d.mean(), d.max())
+    assert abs(means.mean() - g["means64"].mean()) < 0.6
+    # and block by block the difference stays at the reference's own (row-correlated) noise level
+    d16 = np.abs(means - g["means64"])
+    assert d16.mean() < 4.0, d16.mean()

@@ -1,6 +1,6 @@
 /*
  * ky_drivers.cpp -- the reference's experiment drivers (ky.cpp:4675-4949) written against ky_amd/host/ky.hpp,
- * i.e. the same call shape `integrator->render(&scene, sampler.get(), &film); film.next_subfilm();` with the
+ * i.e. the same call shape `use_devices(*integrator); integrator->render(&scene, sampler.get(), &film); film.next_subfilm();` with the
  * rendering done by the MI355X library.  Workload definitions only: spp, grids and scene flags are the reference's.
  *
  *   ky_drivers single [spp4]     render_single_scene       (4675): 1024x1024 Cornell + environment light
@@ -9,7 +9,13 @@
  *   ky_drivers direct_sample     render_direct_sample_enum (4779): 4 Cornell lights x 5 strategies, 4x5 grid
  *   ky_drivers multiple_scene    render_multiple_scene     (4819): 3 strategies x 4 Cornell lights, 3x4 grid
  *   ky_drivers mis               render_mis_scene          (4878): Veach x 6 strategies, 2x3 grid
+ *   ky_drivers batch [spp] [res] BASELINE.json configs[3]: render_multiple_scene scaled up -- the four Cornell light variants
+ *                                (both_mis), Veach (both_mis) and a first-hit AOV pass, each res x res (1024) at spp (2048),
+ *                                into a film_grid_t(2, 3, res, res); writes batch.bmp
+ *   ky_drivers stress [spp] [res] BASELINE.json configs[4]: Cornell res x res (4096), spp (16384), max depth 16; writes stress.bmp
  * An optional last argument multiplies every spp (the reference's values are tiny because its CPU path is slow).
+ * KY_DEVICES=all (or a count n: devices 0 .. n-1) makes every integrator spread its tiles over that many GPUs of the node
+ * (integrator_t::set_devices); the images do not depend on it.
  */
 #include <chrono>
 #include <cstdio>
@@ -23,6 +29,20 @@
 using namespace ky;
 
 static int g_spp_scale = 1;
+
+// KY_DEVICES: the GPUs every integrator of this process renders on
+static void use_devices(integrator_t& integrator) {
+    const char* e = std::getenv("KY_DEVICES");
+    if (!e || !*e) return;
+    std::vector<int> all = integrator_t::all_devices();
+    if (std::strcmp(e, "all") != 0) {
+        const int n = std::atoi(e);
+        if (n < 1) return;
+        all.resize((size_t)n);
+        for (int i = 0; i < n; ++i) all[(size_t)i] = i;
+    }
+    integrator.set_devices(all);
+}
 
 template <typename F>
 static double timing_seconds(F f) {  // wall clock (the reference's clock() counts CPU time on Linux, ky.cpp:156-163)
@@ -38,6 +58,7 @@ static void render_single_scene(int spp4) {
     const int samples_per_pixel = (spp4 > 0 ? spp4 / 4 : 16) * g_spp_scale;
     std::unique_ptr<sampler_t> sampler = std::make_unique<random_sampler_t>(samples_per_pixel);
     auto integrator = create_integrator(integrator_enum_t::path_tracing_iteration, 5, direct_sample_enum_t::both_mis);
+    use_devices(*integrator);
     const double seconds = timing_seconds([&] { integrator->render(&scene, sampler.get(), &film); });
     std::printf("%d spp, %.3f seconds (kernel %.3f ms), %.1f Msamples/s\n", samples_per_pixel, seconds, integrator->last_kernel_ms(),
                 (double)width * height * samples_per_pixel / seconds / 1e6);
@@ -50,7 +71,7 @@ static void render_debug() {
     scene_t scene = scene_t::create_mis_scene(film.get_resolution());
     for (auto e : {integrator_enum_t::position, integrator_enum_t::normal, integrator_enum_t::basecolor}) {
         std::unique_ptr<integrator_t> integrator = std::make_unique<debug_integrator_t>(e);
-        integrator->render(&scene, sampler.get(), &film);
+        use_devices(*integrator); integrator->render(&scene, sampler.get(), &film);
         film.next_subfilm();
     }
     film.store_image("render_debug");
@@ -74,7 +95,7 @@ static void render_multiple_integrator() {
         std::unique_ptr<sampler_t> sampler = std::make_unique<random_sampler_t>(spp * g_spp_scale);
         for (auto integrator_enum : integrator_enums) {
             auto integrator = create_integrator(integrator_enum, 5, direct_sample_enum_t::both_mis);
-            integrator->render(&scene, sampler.get(), &film);
+            use_devices(*integrator); integrator->render(&scene, sampler.get(), &film);
             film.next_subfilm();
         }
     }
@@ -90,7 +111,7 @@ static void render_direct_sample_enum() {
         scene_t scene = scene_t::create_cornell_box_scene(cornell_box_enum_t::both_small_spheres | scene_enum, film.get_resolution());
         for (auto sample_enum : sample_enums) {
             std::unique_ptr<integrator_t> integrator = std::make_unique<path_tracing_iteration_t>(5, sample_enum);
-            integrator->render(&scene, sampler.get(), &film);
+            use_devices(*integrator); integrator->render(&scene, sampler.get(), &film);
             film.next_subfilm();
         }
     }
@@ -105,7 +126,7 @@ static void render_multiple_scene() {
         for (auto [scene_enum, spp] : scene_params(true)) {
             std::unique_ptr<sampler_t> sampler = std::make_unique<random_sampler_t>(spp * g_spp_scale);
             scene_t scene = scene_t::create_cornell_box_scene(cornell_box_enum_t::both_small_spheres | scene_enum, film.get_resolution());
-            integrator->render(&scene, sampler.get(), &film);
+            use_devices(*integrator); integrator->render(&scene, sampler.get(), &film);
             film.next_subfilm();
         }
     }
@@ -119,10 +140,52 @@ static void render_mis_scene() {
     for (auto sample_enum : {direct_sample_enum_t::bsdf, direct_sample_enum_t::light, direct_sample_enum_t::idle, direct_sample_enum_t::bsdf_mis,
                              direct_sample_enum_t::light_mis, direct_sample_enum_t::both_mis}) {
         std::unique_ptr<integrator_t> integrator = std::make_unique<path_tracing_iteration_t>(5, sample_enum);
-        integrator->render(&scene, sampler.get(), &film);
+        use_devices(*integrator); integrator->render(&scene, sampler.get(), &film);
         film.next_subfilm();
     }
     film.store_image("veach_mis");
+}
+
+// BASELINE.json configs[3]: the batch of render_multiple_scene (4819-4876) at production size -- one film_grid_t, one
+// integrator->render() per cell, every frame's tiles interleaved over the GPUs of KY_DEVICES
+static void render_batch(int spp, int res) {
+    film_grid_t film(2, 3, res, res);
+    double samples = 0;
+    const double seconds = timing_seconds([&] {
+        std::unique_ptr<sampler_t> sampler = std::make_unique<random_sampler_t>(spp);
+        for (auto light : {cornell_box_enum_t::light_point, cornell_box_enum_t::light_direction, cornell_box_enum_t::light_area, cornell_box_enum_t::light_environment}) {
+            scene_t scene = scene_t::create_cornell_box_scene(cornell_box_enum_t::both_small_spheres | light, film.get_resolution());
+            std::unique_ptr<integrator_t> integrator = std::make_unique<path_tracing_iteration_t>(5, direct_sample_enum_t::both_mis);
+            use_devices(*integrator); integrator->render(&scene, sampler.get(), &film);
+            film.next_subfilm();
+            samples += (double)res * res * spp;
+        }
+        {
+            scene_t scene = scene_t::create_mis_scene(film.get_resolution());
+            std::unique_ptr<integrator_t> integrator = std::make_unique<path_tracing_iteration_t>(5, direct_sample_enum_t::both_mis);
+            use_devices(*integrator); integrator->render(&scene, sampler.get(), &film);
+            film.next_subfilm();
+            samples += (double)res * res * spp;
+            std::unique_ptr<integrator_t> aov = std::make_unique<debug_integrator_t>(integrator_enum_t::normal);   // the "debug" member of the batch
+            std::unique_ptr<sampler_t> one = std::make_unique<debug_sampler_t>(1);
+            use_devices(*aov); aov->render(&scene, one.get(), &film);
+            samples += (double)res * res;
+        }
+    });
+    std::printf("batch: 6 frames %dx%d, %d spp: %.3f seconds, %.1f Msamples/s\n", res, res, spp, seconds, samples / seconds / 1e6);
+    film.store_image("batch");
+}
+
+// BASELINE.json configs[4]: the stress frame
+static void render_stress(int spp, int res) {
+    film_t film(res, res);
+    scene_t scene = scene_t::create_cornell_box_scene(cornell_box_enum_t::both_small_spheres | cornell_box_enum_t::light_area, film.get_resolution());
+    std::unique_ptr<sampler_t> sampler = std::make_unique<random_sampler_t>(spp);
+    auto integrator = create_integrator(integrator_enum_t::path_tracing_iteration, 16, direct_sample_enum_t::both_mis);
+    use_devices(*integrator);
+    const double seconds = timing_seconds([&] { integrator->render(&scene, sampler.get(), &film); });
+    std::printf("stress: %dx%d, %d spp, depth 16: %.3f seconds, %.1f Msamples/s\n", res, res, spp, seconds, (double)res * res * spp / seconds / 1e6);
+    film.store_image("stress");
 }
 
 int main(int argc, char* argv[]) {
@@ -131,6 +194,10 @@ int main(int argc, char* argv[]) {
         if (!std::strcmp(which, "single")) {
             if (argc > 3) g_spp_scale = std::atoi(argv[3]);
             render_single_scene(argc > 2 ? std::atoi(argv[2]) : 0);
+        } else if (!std::strcmp(which, "batch")) {
+            render_batch(argc > 2 ? std::atoi(argv[2]) : 2048, argc > 3 ? std::atoi(argv[3]) : 1024);
+        } else if (!std::strcmp(which, "stress")) {
+            render_stress(argc > 2 ? std::atoi(argv[2]) : 16384, argc > 3 ? std::atoi(argv[3]) : 4096);
         } else {
             if (argc > 2) g_spp_scale = std::atoi(argv[2]);
             if (g_spp_scale < 1) g_spp_scale = 1;

@@ -173,7 +173,8 @@ typedef enum ky_status {
     KY_OK                = 0,
     KY_ERR_INVALID_VALUE = -1,  /* bad argument, unknown enum (create_integrator returns nullptr, 4638;
                                    sample_all_light leaves the std::function empty, 3860) */
-    KY_ERR_LIMIT         = -2,  /* scene larger than the KYHIP_MAX_* limits */
+    KY_ERR_LIMIT         = -2,  /* scene larger than the KYHIP_MAX_* limits, or a frame whose work items / pixels do not fit
+                                   the device code's 32-bit indices (e.g. 4096 x 4096 at more than ~1.8e6 spp) */
     KY_ERR_DEVICE        = -3,  /* HIP runtime error (message has the hipError string) */
     KY_ERR_NO_DEVICE     = -4   /* no gfx950 device visible: the product has no CPU fallback */
 } ky_status;
@@ -219,12 +220,37 @@ int kyhip_render(int device, const ky_scene* scene, const ky_render_params* para
  *
  * kyhip_film_add_tiles_device: the de-interleave step after the gather: adds the compact tiles of
  *   shard (tile_first, tile_step) into a DEVICE film (same layout as kyhip_render's film_rgb).
+ *
+ * Streams: the calls on one device share the library's per-device render state (scene copy, work counter, cached
+ *   workspace, timing events).  A call on another stream than the previous call's first waits ON THE DEVICE for that
+ *   previous call's kernels (an event), so calls for one device execute one after the other whatever streams they use;
+ *   calls for different devices are independent (one lock and one state per device).
+ *
+ * kyhip_film_add_gathered_device: the same de-interleave for ALL shards of a frame in one kernel.  The frame described
+ *   by params (tile_first, tile_step) was rendered as `world` shards -- shard r = (tile_first + r * tile_step,
+ *   tile_step * world) -- whose compact tile buffers lie at d_gathered + r * rank_stride_floats (the layout a gather
+ *   collective leaves on the root); rank_stride_floats >= kyhip_shard_float_count() of shard 0.
  */
 size_t kyhip_workspace_bytes(const ky_render_params* params);
 int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render_params* params,
                               float* d_tiles, void* d_workspace, size_t workspace_bytes, void* stream);
 int kyhip_film_add_tiles_device(int device, const ky_render_params* params, const float* d_tiles,
                                 float* d_film_rgb, size_t film_row_stride_px, void* stream);
+int kyhip_film_add_gathered_device(int device, const ky_render_params* params, int world, const float* d_gathered,
+                                   size_t rank_stride_floats, float* d_film_rgb, size_t film_row_stride_px, void* stream);
+
+/*
+ * kyhip_render_multi -- integrator_t::render(scene, sampler, film) on a LIST of devices of one node.  The reference
+ * spreads render()'s pixel loop over all cores itself (`#pragma omp parallel for schedule(dynamic, 1)`, ky.cpp:3696-3699);
+ * here the frame's tiles are interleaved over the listed GPUs: shard i = (tile_first + i * tile_step, tile_step * n_devices)
+ * renders on devices[i] on that device's own stream, all shards concurrently and without communication; the tile buffers
+ * are then gathered on devices[0] (one peer copy per remote shard over xGMI), de-interleaved by one kernel and ADDED into
+ * the caller's host film exactly like kyhip_render.  A device may be listed more than once (its shards then run one after
+ * the other).  The image does not depend on the device list: it is bit-identical to kyhip_render's.  Blocking.
+ * kyhip_render(device, ...) is kyhip_render_multi(&device, 1, ...).
+ */
+int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene, const ky_render_params* params,
+                       float* film_rgb, size_t film_row_stride_px);
 
 /*
  * Duration in milliseconds of the integrator kernel (render_kernel) of the most recent

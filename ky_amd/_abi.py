@@ -97,6 +97,8 @@ KYHIP_SYMBOLS = {
     "kyhip_workspace_bytes": (C.c_size_t, [PP]),
     "kyhip_render_tiles_device": (C.c_int, [C.c_int, SP, PP, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "kyhip_film_add_tiles_device": (C.c_int, [C.c_int, PP, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "kyhip_film_add_gathered_device": (C.c_int, [C.c_int, PP, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "kyhip_render_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, SP, PP, C.c_void_p, C.c_size_t]),
     "kyhip_kernel_ms": (C.c_float, [C.c_int]),
     "kyhip_smallpt_scene": (C.c_int, [SSP]),
     "kyhip_smallpt_scene_rewrite": (C.c_int, [SSP]),

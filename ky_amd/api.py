@@ -87,6 +87,18 @@ def render(scene, params, film=None, device=0, row_stride_px=None, origin_px=(0,
     return film
 
 
+def render_multi(scene, params, devices, film=None, row_stride_px=None, origin_px=(0, 0)):
+    """kyhip_render_multi: integrator_t::render with the frame's tiles spread over the listed GPUs (a device may repeat)."""
+    lib = A.load_kyhip()
+    if film is None:
+        film = np.zeros((params.height, params.width, 3), np.float32)
+    stride = film.shape[1] if row_stride_px is None else row_stride_px
+    base = film.ctypes.data + (origin_px[1] * stride + origin_px[0]) * 12
+    devs = (C.c_int * len(devices))(*devices)
+    _check(lib.kyhip_render_multi(devs, len(devices), _scene_ptr(scene), C.byref(params), C.c_void_p(base), stride))
+    return film
+
+
 def render_host_api(scene, integrator_enum, depth, direct_sample, sampler, spp, width, height, seed=1234,
                     grid=None, cell=0, film=None, device=0):
     """Drive the C++ host classes exactly like a reference driver: create_integrator(...)->render(&scene, sampler, &film)."""

@@ -1178,36 +1178,9 @@ KY_DEV int path_pick_lobe(PathState& ps, int surface, const LdsScene& Lds) {
     return pick_lobe(M, lobe_u);
 }
 
-// A vertex of path_tracing_iteration_t on a delta surface (mirror / glass): it gets no direct lighting (4571), only the
-// continuation (4586-4612).  The lane engine runs it right after the traversal, so that the lane can trace again before the
-// wave enters the shading phase (whose direct-lighting part such a lane would sit out).  Same draws, same order: path 2D,
-// then the roulette number if bounces > 3.
-template <bool DEBUG_SAMPLER>
-KY_DEV bool path_delta_bounce(PathState& ps, const Vertex& v, const DMat& M, int lobe) {
-    const Frame fr = make_frame(v.normal);
-    const float u0 = sampler_next<DEBUG_SAMPLER>(ps.smp), u1 = sampler_next<DEBUG_SAMPLER>(ps.smp);
-    BsdfSample bs = bsdf_sample_local(Bsdf{lobe, &M}, to_local(fr, -ps.d), u0, u1);
-    bs.wi = to_world(fr, bs.wi);
-    if (is_black(bs.f) || bs.pdf == 0.f) return false;  // 4588 (total internal reflection in the refraction branch)
-    ps.beta = ps.beta * (bs.f * (fabsf(dot(bs.wi, v.normal)) * rcp(bs.pdf)));  // 4592
-    ps.prev_specular = (bs.flags & BSDF_SPECULAR) != 0;  // 4596: always true here
-    ps.o = offset_ray_origin(v.position, v.normal, bs.wi);  // 4597
-    ps.d = bs.wi;
-    if (ps.bounces > 3) {  // Russian roulette, 4601-4612
-        const float q = fmaxf(0.05f, 1 - max3(ps.beta));
-        const float u = sampler_next<DEBUG_SAMPLER>(ps.smp);
-        if (u < q) return false;
-        ps.beta = ps.beta * rcp(1 - q);
-    }
-    ps.bounces += 1;
-    return true;  // after a specular bounce the next traversal may still add emission at bounces == max_depth (4548)
-}
-
 // Second half: material, direct lighting, continuation.  WAVE-UNIFORM call: every lane of the wave calls it, `active`
 // says whether this lane holds a vertex.  Returns true when the (active) lane's path continues.
-// NODELTA: the caller guarantees that the vertex's lobe is Lambert or Phong (delta vertices were bounced by path_delta_bounce),
-// so the mirror / glass code is not instantiated in the shading phase.
-template <bool DEBUG_SAMPLER, bool NODELTA = false>
+template <bool DEBUG_SAMPLER>
 KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, const LdsScene& Lds, const RenderConst& rc, bool active,
                        int lobe = -1) {
     if (active) {
@@ -1241,7 +1214,7 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, c
     const bool recursion = rc.integrator == KY_INTEGRATOR_PATH_TRACING_RECURSION;
     const bool defered = rc.integrator == KY_INTEGRATOR_PATH_TRACING_RECURSION_DEFERED;
     const bool simple = rc.integrator == KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION;
-    const bool delta = NODELTA ? false : bsdf_is_delta(v.bsdf);
+    const bool delta = bsdf_is_delta(v.bsdf);
     const bool nee = active && !delta;  // 4571
     KY_PROBE(6);
     if (!simple) {  // simple_path_tracing_recursion_t samples the BSDF only
@@ -1273,15 +1246,7 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, c
     // sample BSDF to get the new path direction, 4586 / 4213 / 4383 / 4495
     const float u0 = sampler_next<DEBUG_SAMPLER>(ps.smp), u1 = sampler_next<DEBUG_SAMPLER>(ps.smp);
     KY_PROBE(7);
-    BsdfSample bs;
-    if (NODELTA) {
-        const f3 wo_l = vertex_wo(v);
-        bs.wi = bsdf_sample_dir_nondelta(v.bsdf, wo_l, u0, u1);
-        bsdf_eval_pdf(v.bsdf, wo_l, bs.wi, bs.f, bs.pdf);
-        bs.flags = BSDF_REFLECTION;   // diffuse or glossy: not specular
-    } else {
-        bs = bsdf_sample_local(v.bsdf, vertex_wo(v), u0, u1);
-    }
+    BsdfSample bs = bsdf_sample_local(v.bsdf, vertex_wo(v), u0, u1);
     bs.wi = to_world(vertex_frame(v), bs.wi);
     if (is_black(bs.f) || bs.pdf == 0.f) return false;  // 4588 / 4215 / 4385 / 4497
     if (rc.integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION) {

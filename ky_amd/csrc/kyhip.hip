@@ -27,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -111,6 +112,19 @@ static bool valid_params(const ky_render_params* p) {
     return true;
 }
 
+// Index ranges of the device code: work items are counted in 32 bits, accumulator and tile indices are ints.
+static bool shard_in_range(const ky_render_params* p) {
+    const long long tiles_x = (p->width + p->tile_w - 1) / p->tile_w, tiles_y = (p->height + p->tile_h - 1) / p->tile_h;
+    const long long total = tiles_x * tiles_y;
+    const long long n_tiles = p->tile_first >= total ? 0 : (total - p->tile_first + p->tile_step - 1) / p->tile_step;
+    const long long n_pix = n_tiles * p->tile_w * p->tile_h;
+    const long long n_blocks = n_tiles * (p->tile_w / 8) * (p->tile_h / 8);
+    const long long spp = p->samples_per_pixel, tail = spp < KY_TAIL ? spp : KY_TAIL;
+    const long long head = ((spp - tail) / KY_CHUNK) * KY_CHUNK;
+    const long long n_chunks = head / KY_CHUNK + (spp - head + KY_CHUNK_SMALL - 1) / KY_CHUNK_SMALL;
+    return n_pix * 3 <= 0x7fffffffLL && n_blocks * n_chunks < 0xffffffffLL && total <= 0x7fffffffLL;
+}
+
 static ShardConst make_shard(const ky_render_params* p) {
     ShardConst s{};
     s.tile_w = p->tile_w; s.tile_h = p->tile_h; s.tile_first = p->tile_first; s.tile_step = p->tile_step;
@@ -140,9 +154,6 @@ static ShardConst make_shard(const ky_render_params* p) {
 #ifndef KY_RETRACE_THRESHOLD
 #define KY_RETRACE_THRESHOLD 40
 #endif
-#ifndef KY_DELTA_IN_TRACE
-#define KY_DELTA_IN_TRACE 0
-#endif
 #ifndef KY_WAVES_PER_EU
 #define KY_WAVES_PER_EU 6           // the hot instantiation <false, both_mis>: 80 VGPRs
 #endif
@@ -171,8 +182,6 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? KY_WAVES_PER_EU : KY_WAVES_PER
     const int nee_weight = (rc.strategy == KY_DIRECT_IDLE || rc.integrator < KY_INTEGRATOR_DIRECT_LIGHTING ||
                             rc.integrator == KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION) ? 0 : S->n_lights;
 
-    // path_tracing_iteration_t only: delta vertices are bounced inside the trace phase (path_delta_bounce)
-    const bool delta_in_trace = rc.integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION;
     const int lane = threadIdx.x & 63;
     ItemSlot* my_ring = ring[threadIdx.x >> 6];
 
@@ -266,7 +275,6 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? KY_WAVES_PER_EU : KY_WAVES_PER
         Vertex v;
         v.in_lds = true;   // shading frame and local wo in LDS (ky_device.hpp, VertexLds)
         bool have_vertex = false;
-        int lobe = -1;
         for (int attempt = 0;; ++attempt) {
             if (!alive && !done && open) {  // next camera sample of this lane's pixel, 3712-3715
                 const int xy = c_xy[tid], s = c_s[tid];
@@ -278,28 +286,17 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? KY_WAVES_PER_EU : KY_WAVES_PER
             const bool tracing = alive && !have_vertex;
             if (!__any(tracing)) break;
             if (tracing) {
-                bool ended = !path_intersect<DEBUG_SAMPLER>(ps, v, S, Lds, rc);
-                if (!ended) {
-#if KY_DELTA_IN_TRACE
-                    if (delta_in_trace) {
-                        // the material's lobe decision is made here (same stream position as in path_shade); a delta vertex
-                        // takes its continuation at once and stays in the tracing state
-                        lobe = path_pick_lobe<DEBUG_SAMPLER>(ps, v.surface, Lds);
-                        if (lobe == LOBE_MIRROR || lobe == LOBE_GLASS) ended = !path_delta_bounce<DEBUG_SAMPLER>(ps, v, Lds.mat[Lds.hit[v.surface].material], lobe);
-                        else have_vertex = true;
-                    } else
-#endif
-                        have_vertex = true;
-                }
+                const bool ended = !path_intersect<DEBUG_SAMPLER>(ps, v, S, Lds, rc);
+                if (!ended) have_vertex = true;
                 if (ended) {
                     c_lsum[0][tid] += ps.Lo.x * rc.inv_spp; c_lsum[1][tid] += ps.Lo.y * rc.inv_spp; c_lsum[2][tid] += ps.Lo.z * rc.inv_spp;
                     alive = false;
                 }
             }
             if (attempt >= KY_MAX_RETRACE) break;
-            // lanes that could trace right now (a new path, or the ray leaving a delta vertex); worth one more traversal if they
-            // would otherwise idle through (2 traversals x lights + shading) that is worth more than the extra traversal
-            const int idle = __popcll(__ballot((!alive && !done && open) || (alive && !have_vertex)));
+            // lanes that could start another path right now; worth one more traversal if they would otherwise idle
+            // through (2 traversals x lights + shading) that is worth more than the extra traversal
+            const int idle = __popcll(__ballot(!alive && !done && open));
             if (idle * (2 * nee_weight + 1) < KY_RETRACE_THRESHOLD) break;
         }
         KY_CLK(1);
@@ -309,8 +306,7 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? KY_WAVES_PER_EU : KY_WAVES_PER
         }
         // ---- (3) shade the vertex: direct lighting, continuation ----
         {
-            // wave-uniform call; in the hot instantiation every vertex that gets here is Lambert or Phong
-            const bool cont = path_shade<DEBUG_SAMPLER, (STRATEGY >= 0) && KY_DELTA_IN_TRACE>(ps, v, S, Lds, rc, have_vertex, lobe);
+            const bool cont = path_shade<DEBUG_SAMPLER>(ps, v, S, Lds, rc, have_vertex);  // wave-uniform call
             if (have_vertex && !cont) {
                 c_lsum[0][tid] += ps.Lo.x * rc.inv_spp; c_lsum[1][tid] += ps.Lo.y * rc.inv_spp; c_lsum[2][tid] += ps.Lo.z * rc.inv_spp;
                 alive = false;
@@ -348,6 +344,23 @@ __global__ void film_add_kernel(const float* __restrict__ tiles, float* __restri
     if (x >= width || y >= height) return;
     float* px = film + ((size_t)y * stride_px + x) * 3;
     px[0] += tiles[3 * (size_t)i]; px[1] += tiles[3 * (size_t)i + 1]; px[2] += tiles[3 * (size_t)i + 2];
+}
+
+// film_t::add_color for ALL shards of a frame at once: `gathered` holds the compact tile buffers of the `world` shards
+// (tile_first + r * tile_step, tile_step * world), r = 0 .. world - 1, shard r at gathered + r * rank_stride floats.
+__global__ void film_add_gathered_kernel(const float* __restrict__ gathered, size_t rank_stride, int world, float* __restrict__ film, size_t stride_px,
+                                         int tile_w, int tile_h, int tile_first, int tile_step, int tiles_x, int width, int height) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= width * height) return;
+    const int x = i % width, y = i / width;
+    const int tcol = x / tile_w, trow = y / tile_h;
+    const int tile = trow * tiles_x + ((tcol - trow % tiles_x) + tiles_x) % tiles_x;   // inverse of the row rotation (kyhip.h)
+    const int rel = tile - tile_first;
+    if (rel < 0 || rel % tile_step != 0) return;          // the tile does not belong to this frame's shard set
+    const int j = rel / tile_step, r = j % world, k = j / world;
+    const float* src = gathered + (size_t)r * rank_stride + (((size_t)k * tile_h + (y % tile_h)) * tile_w + (x % tile_w)) * 3;
+    float* px = film + ((size_t)y * stride_px + x) * 3;
+    px[0] += src[0]; px[1] += src[1]; px[2] += src[2];
 }
 
 // ---- KAT kernels ----
@@ -688,48 +701,95 @@ static int current_engine() {
     return g_engine;
 }
 
+// device memory that is released on every way out of an entry point
+struct DevBuf {
+    void* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes < 16 ? 16 : bytes); }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+// One context per device, created on first use.  Every entry point holds the context's own mutex while it enqueues, so
+// calls for different devices never wait for each other.  The render state that is shared by the calls on one device
+// (scene copy, work counter, cached workspace, timing events) is handed from stream to stream with `busy`: a call on
+// another stream first waits (on the device) for the previous call's last kernel.
 struct DeviceCtx {
-    bool init = false;
+    std::mutex m;
+    int device = 0;
     int cus = 0;
     DScene* d_scene = nullptr;
     DScene* h_scene = nullptr;   // pinned staging
     unsigned* d_counter = nullptr;
     void* ws = nullptr;
     size_t ws_bytes = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, busy = nullptr;
+    bool busy_valid = false, timing_valid = false;
+    hipStream_t last_stream = nullptr;
+    hipStream_t stream = nullptr;   // the library's own stream on this device (kyhip_render_multi)
     int blocks_per_cu[3] = {0, 0, 0};
     int q_blocks_per_cu[3] = {0, 0, 0};
     bool scene_valid = false;
 };
-static std::mutex g_mutex;
-static DeviceCtx g_ctx[16];
+static std::mutex g_ctx_mutex;                          // guards g_ctx itself (creation), never held while enqueueing
+static std::vector<std::unique_ptr<DeviceCtx>> g_ctx;   // index = HIP device ordinal
 
+static int create_ctx(int device, DeviceCtx& c) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(KY_ERR_NO_DEVICE, "device %d is %s; libkyhip is built for gfx950 only", device, prop.gcnArchName);
+    c.device = device;
+    c.cus = prop.multiProcessorCount;
+    HIP_TRY(hipMalloc(&c.d_scene, sizeof(DScene)));
+    HIP_TRY(hipHostMalloc(&c.h_scene, sizeof(DScene)));
+    HIP_TRY(hipMalloc(&c.d_counter, 256));
+    HIP_TRY(hipEventCreate(&c.ev0));
+    HIP_TRY(hipEventCreate(&c.ev1));
+    HIP_TRY(hipEventCreateWithFlags(&c.busy, hipEventDisableTiming));
+    HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[0], render_kernel<false, KY_DIRECT_BOTH_MIS>, 256, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[1], render_kernel<false, -1>, 256, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[2], render_kernel<true, -1>, 256, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.q_blocks_per_cu[0], render_kernel_q<false, KY_DIRECT_BOTH_MIS>, QE_THREADS, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.q_blocks_per_cu[1], render_kernel_q<false, -1>, QE_THREADS, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.q_blocks_per_cu[2], render_kernel_q<true, -1>, QE_THREADS, 0));
+    return KY_OK;
+}
+
+// Looks the context of `device` up (creating it on first use) and makes the device current for the calling thread.
 static int get_ctx(int device, DeviceCtx** out) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(KY_ERR_NO_DEVICE, "no HIP device visible (libkyhip has no CPU fallback)");
-    if (device < 0 || device >= n || device >= 16) return fail(KY_ERR_INVALID_VALUE, "device %d out of range (%d visible)", device, n);
+    if (device < 0 || device >= n) return fail(KY_ERR_INVALID_VALUE, "device %d out of range (%d visible)", device, n);
     HIP_TRY(hipSetDevice(device));
-    DeviceCtx& c = g_ctx[device];
-    if (!c.init) {
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, device));
-        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-            return fail(KY_ERR_NO_DEVICE, "device %d is %s; libkyhip is built for gfx950 only", device, prop.gcnArchName);
-        c.cus = prop.multiProcessorCount;
-        HIP_TRY(hipMalloc(&c.d_scene, sizeof(DScene)));
-        HIP_TRY(hipHostMalloc(&c.h_scene, sizeof(DScene)));
-        HIP_TRY(hipMalloc(&c.d_counter, 256));
-        HIP_TRY(hipEventCreate(&c.ev0));
-        HIP_TRY(hipEventCreate(&c.ev1));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[0], render_kernel<false, KY_DIRECT_BOTH_MIS>, 256, 0));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[1], render_kernel<false, -1>, 256, 0));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[2], render_kernel<true, -1>, 256, 0));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.q_blocks_per_cu[0], render_kernel_q<false, KY_DIRECT_BOTH_MIS>, QE_THREADS, 0));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.q_blocks_per_cu[1], render_kernel_q<false, -1>, QE_THREADS, 0));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.q_blocks_per_cu[2], render_kernel_q<true, -1>, QE_THREADS, 0));
-        c.init = true;
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    if ((int)g_ctx.size() < n) g_ctx.resize(n);
+    if (!g_ctx[device]) {
+        auto c = std::make_unique<DeviceCtx>();
+        const int rc = create_ctx(device, *c);
+        if (rc != KY_OK) return rc;   // a half-built context is dropped; its few allocations are reclaimed at process exit
+        g_ctx[device] = std::move(c);
     }
-    *out = &c;
+    *out = g_ctx[device].get();
+    return KY_OK;
+}
+static DeviceCtx* find_ctx(int device) {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    return (device >= 0 && device < (int)g_ctx.size()) ? g_ctx[device].get() : nullptr;
+}
+
+// Hands the per-device render state over to `stream`: device-side wait for the previous call's last kernel.
+static int acquire_state(DeviceCtx* c, hipStream_t stream) {
+    if (c->busy_valid && stream != c->last_stream) HIP_TRY(hipStreamWaitEvent(stream, c->busy, 0));
+    return KY_OK;
+}
+static int release_state(DeviceCtx* c, hipStream_t stream) {
+    HIP_TRY(hipEventRecord(c->busy, stream));
+    c->busy_valid = true;
+    c->last_stream = stream;
     return KY_OK;
 }
 
@@ -740,7 +800,7 @@ static int upload_scene(DeviceCtx* c, const ky_scene* scene, hipStream_t stream)
     const int rc = pack_scene(scene, &scratch);
     if (rc != KY_OK) return rc;
     if (c->scene_valid && std::memcmp(&scratch, c->h_scene, sizeof(DScene)) == 0) return KY_OK;
-    // the pinned staging copy must not be overwritten while a previous async copy may still read it
+    // the pinned staging copy and the device copy must not change under a kernel or copy that is still in flight
     HIP_TRY(hipDeviceSynchronize());
     std::memcpy(c->h_scene, &scratch, sizeof(DScene));
     HIP_TRY(hipMemcpyAsync(c->d_scene, c->h_scene, sizeof(DScene), hipMemcpyHostToDevice, stream));
@@ -761,25 +821,22 @@ static RenderConst make_rc(const ky_render_params* p) {
 // shared driver of the KAT entry points
 template <typename F>
 static int kat_run(int device, const void* in, size_t in_bytes, void* out, size_t out_bytes, F launch) {
-    std::lock_guard<std::mutex> lock(g_mutex);
     DeviceCtx* c;
     int rcode = get_ctx(device, &c);
     if (rcode != KY_OK) return rcode;
-    void *d_in = nullptr, *d_out = nullptr;
-    HIP_TRY(hipMalloc(&d_in, std::max<size_t>(in_bytes, 16)));
-    HIP_TRY(hipMalloc(&d_out, std::max<size_t>(out_bytes, 16)));
-    HIP_TRY(hipMemcpy(d_in, in, in_bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(d_out, 0, out_bytes));
-    rcode = launch(c, (const float*)d_in, (float*)d_out);
-    if (rcode == KY_OK) {
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-        if (e == hipSuccess) e = hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rcode = fail(KY_ERR_DEVICE, "KAT kernel failed: %s", hipGetErrorString(e));
-    }
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
-    return rcode;
+    std::lock_guard<std::mutex> lock(c->m);
+    DevBuf d_in, d_out;
+    HIP_TRY(d_in.alloc(in_bytes));
+    HIP_TRY(d_out.alloc(out_bytes));
+    HIP_TRY(hipDeviceSynchronize());   // KAT entries use the default stream and may replace the device's scene copy
+    HIP_TRY(hipMemcpy(d_in.p, in, in_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d_out.p, 0, out_bytes));
+    rcode = launch(c, d_in.as<const float>(), d_out.as<float>());
+    if (rcode != KY_OK) return rcode;
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, d_out.p, out_bytes, hipMemcpyDeviceToHost));
+    return KY_OK;
 }
 
 
@@ -842,11 +899,12 @@ size_t kyhip_workspace_bytes(const ky_render_params* p) {
 int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render_params* p, float* d_tiles, void* d_workspace,
                               size_t workspace_bytes, void* stream_) {
     if (!valid_params(p)) return fail(KY_ERR_INVALID_VALUE, "invalid render params (integrator %d, direct_sample %d)", p ? p->integrator : -1, p ? p->direct_sample : -1);
+    if (!shard_in_range(p)) return fail(KY_ERR_LIMIT, "frame too large for the device's 32-bit work-item and pixel indices (%d x %d, %d spp)", p->width, p->height, p->samples_per_pixel);
     if (!d_tiles) return fail(KY_ERR_INVALID_VALUE, "d_tiles is NULL");
-    std::lock_guard<std::mutex> lock(g_mutex);
     DeviceCtx* c;
     int rcode = get_ctx(device, &c);
     if (rcode != KY_OK) return rcode;
+    std::lock_guard<std::mutex> lock(c->m);
     hipStream_t stream = (hipStream_t)stream_;
     rcode = upload_scene(c, scene, stream);
     if (rcode != KY_OK) return rcode;
@@ -860,7 +918,7 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
     void* ws = d_workspace;
     if (!(d_workspace && workspace_bytes >= need)) {
         if (c->ws_bytes < need) {
-            HIP_TRY(hipStreamSynchronize(stream));
+            if (c->busy_valid) HIP_TRY(hipEventSynchronize(c->busy));   // the previous call's kernels still use the old block
             if (c->ws) HIP_TRY(hipFree(c->ws));
             c->ws = nullptr; c->ws_bytes = 0;
             HIP_TRY(hipMalloc(&c->ws, need));
@@ -868,6 +926,8 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
         }
         ws = c->ws;
     }
+    rcode = acquire_state(c, stream);   // counter, cached workspace and timing events are shared by the calls on this device
+    if (rcode != KY_OK) return rcode;
     unsigned long long* accum = (unsigned long long*)ws;
     unsigned* flags = (unsigned*)(accum + (size_t)sh.n_pix * 3);
     HIP_TRY(hipMemsetAsync(ws, 0, need, stream));
@@ -879,7 +939,7 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
     if (current_engine() == KY_ENGINE_QUEUE && p->integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION) {
         const int per_cu = c->q_blocks_per_cu[variant] > 0 ? c->q_blocks_per_cu[variant] : 1;
         unsigned grid = (unsigned)(c->cus * per_cu);
-        const unsigned need_blocks = (sh.n_items * 64u + QE_SLOTS - 1) / QE_SLOTS;
+        const unsigned need_blocks = (unsigned)(((unsigned long long)sh.n_items * 64u + QE_SLOTS - 1) / QE_SLOTS);
         if (grid > need_blocks) grid = need_blocks;
         if (grid < 1) grid = 1;
         if (variant == 0) hipLaunchKernelGGL((render_kernel_q<false, KY_DIRECT_BOTH_MIS>), dim3(grid), dim3(QE_THREADS), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags);
@@ -888,7 +948,7 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
     } else {
         const int per_cu = c->blocks_per_cu[variant] > 0 ? c->blocks_per_cu[variant] : 1;
         unsigned grid = (unsigned)(c->cus * per_cu);
-        const unsigned need_blocks = (sh.n_items + 3) / 4;
+        const unsigned need_blocks = sh.n_items / 4 + 1;
         if (grid > need_blocks) grid = need_blocks;
         if (grid < 1) grid = 1;
         if (variant == 0) hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_BOTH_MIS>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags);
@@ -897,27 +957,31 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, stream));
+    c->timing_valid = true;
     const int nf = sh.n_pix * 3;
     hipLaunchKernelGGL(resolve_kernel, dim3((nf + 255) / 256), dim3(256), 0, stream, accum, flags, d_tiles, nf);
     HIP_TRY(hipGetLastError());
-    return KY_OK;
+    return release_state(c, stream);
 }
 
 // resolves the event pair of the last launch on `device`; the stream must have been synchronised
 float kyhip_kernel_ms(int device) {
-    if (device < 0 || device >= 16 || !g_ctx[device].init) return -1.f;
+    DeviceCtx* c = find_ctx(device);
+    if (!c) return -1.f;
+    std::lock_guard<std::mutex> lock(c->m);
+    if (!c->timing_valid) return -1.f;
     float ms = -1.f;
-    if (hipEventElapsedTime(&ms, g_ctx[device].ev0, g_ctx[device].ev1) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.f;
     return ms;
 }
 
 int kyhip_film_add_tiles_device(int device, const ky_render_params* p, const float* d_tiles, float* d_film, size_t stride_px, void* stream_) {
-    if (!valid_params(p)) return fail(KY_ERR_INVALID_VALUE, "invalid render params");
+    if (!valid_params(p) || !shard_in_range(p)) return fail(KY_ERR_INVALID_VALUE, "invalid render params");
     if (!d_tiles || !d_film || stride_px < (size_t)p->width) return fail(KY_ERR_INVALID_VALUE, "bad film arguments");
-    std::lock_guard<std::mutex> lock(g_mutex);
     DeviceCtx* c;
     int rcode = get_ctx(device, &c);
     if (rcode != KY_OK) return rcode;
+    std::lock_guard<std::mutex> lock(c->m);
     const ShardConst sh = make_shard(p);
     if (sh.n_pix == 0) return KY_OK;
     hipLaunchKernelGGL(film_add_kernel, dim3((sh.n_pix + 255) / 256), dim3(256), 0, (hipStream_t)stream_, d_tiles, d_film, stride_px, sh, p->width, p->height);
@@ -925,38 +989,119 @@ int kyhip_film_add_tiles_device(int device, const ky_render_params* p, const flo
     return KY_OK;
 }
 
-int kyhip_render(int device, const ky_scene* scene, const ky_render_params* p, float* film_rgb, size_t stride_px) {
-    if (!valid_params(p)) return fail(KY_ERR_INVALID_VALUE, "invalid render params (integrator %d, direct_sample %d)", p ? p->integrator : -1, p ? p->direct_sample : -1);
-    if (!film_rgb || stride_px < (size_t)p->width) return fail(KY_ERR_INVALID_VALUE, "bad film arguments");
-    const ShardConst sh = make_shard(p);
-    float *d_tiles = nullptr, *d_film = nullptr;
-    const size_t film_floats = (size_t)p->width * p->height * 3;
-    {
-        std::lock_guard<std::mutex> lock(g_mutex);
-        DeviceCtx* c;
-        int rcode = get_ctx(device, &c);
-        if (rcode != KY_OK) return rcode;
-        HIP_TRY(hipMalloc(&d_tiles, std::max<size_t>((size_t)sh.n_pix * 3 * sizeof(float), 16)));
-        HIP_TRY(hipMalloc(&d_film, film_floats * sizeof(float)));
-        HIP_TRY(hipMemsetAsync(d_film, 0, film_floats * sizeof(float), 0));
-    }
-    int rcode = kyhip_render_tiles_device(device, scene, p, d_tiles, nullptr, 0, nullptr);
-    if (rcode == KY_OK) rcode = kyhip_film_add_tiles_device(device, p, d_tiles, d_film, (size_t)p->width, nullptr);
-    std::vector<float> host(film_floats);
-    if (rcode == KY_OK) {
-        hipError_t e = hipMemcpy(host.data(), d_film, film_floats * sizeof(float), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rcode = fail(KY_ERR_DEVICE, "hipMemcpy failed: %s", hipGetErrorString(e));
-    }
-    (void)hipFree(d_tiles);
-    (void)hipFree(d_film);
+int kyhip_film_add_gathered_device(int device, const ky_render_params* p, int world, const float* d_gathered, size_t rank_stride_floats,
+                                   float* d_film, size_t stride_px, void* stream_) {
+    if (!valid_params(p) || !shard_in_range(p)) return fail(KY_ERR_INVALID_VALUE, "invalid render params");
+    if (world < 1 || (long long)p->tile_step * world > 0x7fffffffLL) return fail(KY_ERR_INVALID_VALUE, "bad shard count %d", world);
+    if (!d_gathered || !d_film || stride_px < (size_t)p->width) return fail(KY_ERR_INVALID_VALUE, "bad film arguments");
+    ky_render_params q = *p;   // the largest shard is shard 0: its buffer must fit the stride
+    q.tile_step = p->tile_step * world;
+    if (rank_stride_floats < (size_t)make_shard(&q).n_pix * 3) return fail(KY_ERR_INVALID_VALUE, "rank_stride_floats is smaller than a shard's tile buffer");
+    DeviceCtx* c;
+    int rcode = get_ctx(device, &c);
     if (rcode != KY_OK) return rcode;
-    kyhip_kernel_ms(device);
+    std::lock_guard<std::mutex> lock(c->m);
+    const int n = p->width * p->height, tiles_x = (p->width + p->tile_w - 1) / p->tile_w;
+    hipLaunchKernelGGL(film_add_gathered_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream_, d_gathered, rank_stride_floats, world, d_film, stride_px,
+                       p->tile_w, p->tile_h, p->tile_first, p->tile_step, tiles_x, p->width, p->height);
+    HIP_TRY(hipGetLastError());
+    return KY_OK;
+}
+
+// integrator_t::render on a LIST of devices (the reference spreads the pixel loop over all cores inside render(),
+// ky.cpp:3696-3699).  Shard i of the frame goes to devices[i] on that device's own stream; the tile buffers are gathered on
+// devices[0] (peer copies over xGMI), de-interleaved by one kernel and added into the caller's film.
+int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene, const ky_render_params* p, float* film_rgb, size_t stride_px) {
+    if (!valid_params(p)) return fail(KY_ERR_INVALID_VALUE, "invalid render params (integrator %d, direct_sample %d)", p ? p->integrator : -1, p ? p->direct_sample : -1);
+    if (!shard_in_range(p)) return fail(KY_ERR_LIMIT, "frame too large for the device's 32-bit work-item and pixel indices (%d x %d, %d spp)", p->width, p->height, p->samples_per_pixel);
+    if (!devices || n_devices < 1 || n_devices > 64) return fail(KY_ERR_INVALID_VALUE, "bad device list");
+    if ((long long)p->tile_step * n_devices > 0x7fffffffLL) return fail(KY_ERR_INVALID_VALUE, "tile_step x devices overflows");
+    if (!film_rgb || stride_px < (size_t)p->width) return fail(KY_ERR_INVALID_VALUE, "bad film arguments");
+    const int root = devices[0];
+    std::vector<ky_render_params> shard(n_devices, *p);
+    std::vector<DeviceCtx*> ctx(n_devices, nullptr);
+    for (int i = 0; i < n_devices; ++i) {
+        shard[i].tile_first = p->tile_first + i * p->tile_step;
+        shard[i].tile_step = p->tile_step * n_devices;
+        const int rc = get_ctx(devices[i], &ctx[i]);
+        if (rc != KY_OK) return rc;
+    }
+    const size_t rank_stride = (size_t)make_shard(&shard[0]).n_pix * 3;   // shard 0 owns the most tiles
+    const size_t film_floats = (size_t)p->width * p->height * 3;
+
+    // buffers: one gather block and the film on the root; a tile buffer on every other device
+    HIP_TRY(hipSetDevice(root));
+    DevBuf d_gather, d_film;
+    HIP_TRY(d_gather.alloc(rank_stride * n_devices * sizeof(float)));
+    HIP_TRY(d_film.alloc(film_floats * sizeof(float)));
+    hipStream_t root_stream = ctx[0]->stream;
+    HIP_TRY(hipMemsetAsync(d_film.p, 0, film_floats * sizeof(float), root_stream));
+    std::vector<DevBuf> remote(n_devices);
+    std::vector<hipEvent_t> done(n_devices, nullptr);
+    struct EventGuard {
+        std::vector<hipEvent_t>& ev;
+        ~EventGuard() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); }
+    } event_guard{done};
+
+    // 1. every shard is enqueued before anything is waited for: the devices render concurrently
+    int rcode = KY_OK;
+    for (int i = 0; i < n_devices && rcode == KY_OK; ++i) {
+        float* dst = d_gather.as<float>() + rank_stride * i;
+        if (devices[i] != root) {
+            HIP_TRY(hipSetDevice(devices[i]));
+            HIP_TRY(remote[i].alloc(rank_stride * sizeof(float)));
+            dst = remote[i].as<float>();
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, root, devices[i]) == hipSuccess && can) {   // direct xGMI copies; staged otherwise
+                HIP_TRY(hipSetDevice(root));
+                (void)hipDeviceEnablePeerAccess(devices[i], 0);
+                (void)hipGetLastError();   // "already enabled" is not an error here
+            }
+        }
+        rcode = kyhip_render_tiles_device(devices[i], scene, &shard[i], dst, nullptr, 0, ctx[i]->stream);
+        if (rcode != KY_OK) break;
+        if (devices[i] != root) {
+            HIP_TRY(hipSetDevice(devices[i]));
+            HIP_TRY(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(done[i], ctx[i]->stream));
+        }
+    }
+    // 2. the gather: one peer copy per remote shard, ordered behind that shard's kernels; then one add into the film
+    if (rcode == KY_OK) {
+        HIP_TRY(hipSetDevice(root));
+        for (int i = 0; i < n_devices; ++i) {
+            if (devices[i] == root) continue;
+            HIP_TRY(hipStreamWaitEvent(root_stream, done[i], 0));
+            const size_t bytes = (size_t)make_shard(&shard[i]).n_pix * 3 * sizeof(float);
+            if (bytes) HIP_TRY(hipMemcpyPeerAsync(d_gather.as<float>() + rank_stride * i, root, remote[i].p, devices[i], bytes, root_stream));
+        }
+        rcode = kyhip_film_add_gathered_device(root, p, n_devices, d_gather.as<float>(), rank_stride, d_film.as<float>(), (size_t)p->width, root_stream);
+    }
+    std::vector<float> host;
+    if (rcode == KY_OK) {
+        host.resize(film_floats);
+        HIP_TRY(hipMemcpyAsync(host.data(), d_film.p, film_floats * sizeof(float), hipMemcpyDeviceToHost, root_stream));
+    }
+    // every stream that may still use a buffer of this call is drained before the buffers go away (also on errors)
+    hipError_t sync_err = hipSuccess;
+    for (int i = 0; i < n_devices; ++i) {
+        if (hipSetDevice(devices[i]) != hipSuccess) continue;
+        const hipError_t e = hipStreamSynchronize(ctx[i]->stream);
+        if (e != hipSuccess) sync_err = e;
+    }
+    (void)hipSetDevice(root);
+    if (rcode != KY_OK) return rcode;
+    if (sync_err != hipSuccess) return fail(KY_ERR_DEVICE, "render failed: %s", hipGetErrorString(sync_err));
     for (int y = 0; y < p->height; ++y) {  // film_t::add_color, 1586-1590
         float* dst = film_rgb + (size_t)y * stride_px * 3;
         const float* src = host.data() + (size_t)y * p->width * 3;
         for (int i = 0; i < p->width * 3; ++i) dst[i] += src[i];
     }
     return KY_OK;
+}
+
+int kyhip_render(int device, const ky_scene* scene, const ky_render_params* p, float* film_rgb, size_t stride_px) {
+    return kyhip_render_multi(&device, 1, scene, p, film_rgb, stride_px);
 }
 
 // ---- KAT entry points ----
@@ -1090,30 +1235,29 @@ int kyhip_smallpt_render(int device, const ky_smallpt_sphere* spheres, int n, co
     int rcode = smallpt_check(spheres, n, p);
     if (rcode != KY_OK) return rcode;
     if (!image_rgb) return fail(KY_ERR_INVALID_VALUE, "null image");
-    std::lock_guard<std::mutex> lock(g_mutex);
     DeviceCtx* c = nullptr;
     rcode = get_ctx(device, &c);
     if (rcode != KY_OK) return rcode;
+    std::lock_guard<std::mutex> lock(c->m);
     kysp::SpSphere packed[kysp::SP_MAX_SPHERES];
     kysp::sp_pack(spheres, n, packed);
     kysp::SpConst k;
     kysp::sp_make_const(p, n, k);
     const size_t n_px = (size_t)p->width * p->height;
-    kysp::SpSphere* d_sph = nullptr;
-    double *d_sub = nullptr, *d_img = nullptr;
-    HIP_TRY(hipMalloc(&d_sph, sizeof(packed)));
-    HIP_TRY(hipMalloc(&d_sub, n_px * 12 * sizeof(double)));
-    HIP_TRY(hipMalloc(&d_img, n_px * 3 * sizeof(double)));
-    HIP_TRY(hipMemcpy(d_sph, packed, sizeof(packed), hipMemcpyHostToDevice));
+    DevBuf d_sph, d_sub, d_img;
+    HIP_TRY(d_sph.alloc(sizeof(packed)));
+    HIP_TRY(d_sub.alloc(n_px * 12 * sizeof(double)));
+    HIP_TRY(d_img.alloc(n_px * 3 * sizeof(double)));
+    HIP_TRY(hipMemcpy(d_sph.p, packed, sizeof(packed), hipMemcpyHostToDevice));
     const int blocks = ((p->width + 7) / 8) * ((p->height + 7) / 8);
     HIP_TRY(hipEventRecord(c->ev0, 0));
-    hipLaunchKernelGGL(kysp::smallpt_kernel, dim3(blocks), dim3(256), 0, 0, d_sph, k, d_sub);
+    hipLaunchKernelGGL(kysp::smallpt_kernel, dim3(blocks), dim3(256), 0, 0, d_sph.as<kysp::SpSphere>(), k, d_sub.as<double>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, 0));
-    hipLaunchKernelGGL(kysp::smallpt_resolve_kernel, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, 0, d_sub, d_img, p->width, p->height, p->variant);
+    c->timing_valid = true;
+    hipLaunchKernelGGL(kysp::smallpt_resolve_kernel, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, 0, d_sub.as<double>(), d_img.as<double>(), p->width, p->height, p->variant);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(image_rgb, d_img, n_px * 3 * sizeof(double), hipMemcpyDeviceToHost));
-    HIP_TRY(hipFree(d_sph)); HIP_TRY(hipFree(d_sub)); HIP_TRY(hipFree(d_img));
+    HIP_TRY(hipMemcpy(image_rgb, d_img.p, n_px * 3 * sizeof(double), hipMemcpyDeviceToHost));
     return KY_OK;
 }
 
@@ -1124,23 +1268,21 @@ int kyhip_smallpt_kat_radiance(int device, const ky_smallpt_sphere* spheres, int
     if (!out3 || n <= 0 || s0 < 0 || x < 0 || y < 0 || x >= p->width || y >= p->height || (sx | sy) < 0 || sx > 1 || sy > 1)
         return fail(KY_ERR_INVALID_VALUE, "bad KAT arguments");
     if (p->variant == KY_SP_VARIANT_REWRITE && (sx | sy) != 0) return fail(KY_ERR_INVALID_VALUE, "variant 1 has no subpixels: sx = sy = 0");
-    std::lock_guard<std::mutex> lock(g_mutex);
     DeviceCtx* c = nullptr;
     rcode = get_ctx(device, &c);
     if (rcode != KY_OK) return rcode;
+    std::lock_guard<std::mutex> lock(c->m);
     kysp::SpSphere packed[kysp::SP_MAX_SPHERES];
     kysp::sp_pack(spheres, n_spheres, packed);
     kysp::SpConst k;
     kysp::sp_make_const(p, n_spheres, k);
-    kysp::SpSphere* d_sph = nullptr;
-    double* d_out = nullptr;
-    HIP_TRY(hipMalloc(&d_sph, sizeof(packed)));
-    HIP_TRY(hipMalloc(&d_out, (size_t)n * 3 * sizeof(double)));
-    HIP_TRY(hipMemcpy(d_sph, packed, sizeof(packed), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(kysp::smallpt_kat_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d_sph, k, x, y, sx, sy, s0, n, d_out);
+    DevBuf d_sph, d_out;
+    HIP_TRY(d_sph.alloc(sizeof(packed)));
+    HIP_TRY(d_out.alloc((size_t)n * 3 * sizeof(double)));
+    HIP_TRY(hipMemcpy(d_sph.p, packed, sizeof(packed), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kysp::smallpt_kat_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d_sph.as<kysp::SpSphere>(), k, x, y, sx, sy, s0, n, d_out.as<double>());
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out3, d_out, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
-    HIP_TRY(hipFree(d_sph)); HIP_TRY(hipFree(d_out));
+    HIP_TRY(hipMemcpy(out3, d_out.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
     return KY_OK;
 }
 

@@ -44,14 +44,43 @@ def shard_tile_count(params, rank, world):
     return 0 if rank >= total else (total - rank + world - 1) // world
 
 
-def render_shard(scene, params, rank, world, device_index=0):
-    """Render this rank's tiles on its GPU.  Returns a CUDA tensor [max_tiles_per_rank, tile_h, tile_w, 3]
-    (ranks that own one tile fewer leave the last slot zero) -- equal sizes keep the gather a single call."""
+class FrameBuffers:
+    """Device buffers of a frame, allocated ONCE and reused for every frame of the same geometry: this rank's compact tile
+    buffer [max_tiles_per_rank, tile_h, tile_w, 3] (ranks that own one tile fewer never write the last slot, which stays
+    zero) and, on rank 0, the gather target [world, max_tiles_per_rank, tile_h, tile_w, 3] the collective writes into
+    directly.  Nothing is allocated, stacked or copied per frame."""
+
+    def __init__(self, params, rank, world, device):
+        self.key = (params.width, params.height, params.tile_w, params.tile_h, rank, world, str(device))
+        self.max_tiles = shard_tile_count(params, 0, world)
+        shape = (self.max_tiles, params.tile_h, params.tile_w, 3)
+        self.tiles = torch.zeros(shape, dtype=torch.float32, device=device)
+        self.gathered = None
+        if rank == 0:
+            self.gathered = self.tiles.unsqueeze(0) if world == 1 else torch.zeros((world,) + shape, dtype=torch.float32, device=device)
+            self.gather_list = None if world == 1 else list(self.gathered.unbind(0))
+
+
+_buffers = {}
+
+
+def frame_buffers(params, rank, world, device):
+    key = (params.width, params.height, params.tile_w, params.tile_h, rank, world, str(device))
+    fb = _buffers.get(key)
+    if fb is None:
+        fb = _buffers[key] = FrameBuffers(params, rank, world, device)
+    return fb
+
+
+def render_shard(scene, params, rank, world, device_index=0, out=None):
+    """Render this rank's tiles on its GPU into `out` (default: a fresh zeroed tensor) [max_tiles_per_rank, tile_h, tile_w, 3]
+    -- equal sizes on every rank keep the gather a single call."""
     lib = A.load_kyhip()
     p = shard_params(params, rank, world)
-    max_tiles = shard_tile_count(params, 0, world)
     dev = torch.device("cuda", device_index)
-    tiles = torch.zeros((max_tiles, params.tile_h, params.tile_w, 3), dtype=torch.float32, device=dev)
+    tiles = out
+    if tiles is None:
+        tiles = torch.zeros((shard_tile_count(params, 0, world), params.tile_h, params.tile_w, 3), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     rc = lib.kyhip_render_tiles_device(device_index, api._scene_ptr(scene), C.byref(p), C.c_void_p(tiles.data_ptr()), None, 0,
                                        C.c_void_p(stream))
@@ -59,20 +88,29 @@ def render_shard(scene, params, rank, world, device_index=0):
     return tiles
 
 
-def gather_tiles(tiles, rank, world, group=None):
-    """The one collective of a frame: gather every rank's tile buffer to rank 0.  Returns [world, ...] on rank 0."""
+def gather_tiles(tiles, rank, world, group=None, out=None, out_list=None):
+    """The one collective of a frame: gather every rank's tile buffer to rank 0.  Returns [world, ...] on rank 0.
+    With `out` ([world, ...]) / `out_list` (its slices) the collective writes straight into that tensor."""
     if world == 1:
         return tiles.unsqueeze(0)
     import torch.distributed as dist
-    out = [torch.empty_like(tiles) for _ in range(world)] if rank == 0 else None
-    dist.gather(tiles, out, dst=0, group=group)
-    return torch.stack(out, 0) if rank == 0 else None
+    if rank != 0:
+        dist.gather(tiles, None, dst=0, group=group)
+        return None
+    if out is None:
+        out = torch.empty((world,) + tuple(tiles.shape), dtype=tiles.dtype, device=tiles.device)
+        out_list = None
+    if out_list is None:
+        out_list = list(out.unbind(0))
+    dist.gather(tiles, out_list, dst=0, group=group)
+    return out
 
 
 def add_tiles_to_film(film, gathered, params, world, device_index=0):
     """De-interleave gathered[r, k] (tile r + k*world) and ADD into film [H, W, 3] (rank 0 only).
 
-    CUDA tensors go through kyhip_film_add_tiles_device; CPU tensors (the gloo tests) use index arithmetic.
+    CUDA tensors go through kyhip_film_add_gathered_device (one kernel for all shards); CPU tensors (the gloo tests) use
+    index arithmetic.
     """
     H, W = params.height, params.width
     tw, th = params.tile_w, params.tile_h
@@ -80,11 +118,11 @@ def add_tiles_to_film(film, gathered, params, world, device_index=0):
     if film.is_cuda:
         lib = A.load_kyhip()
         stream = torch.cuda.current_stream(film.device).cuda_stream
-        for r in range(world):
-            p = shard_params(params, r, world)
-            rc = lib.kyhip_film_add_tiles_device(device_index, C.byref(p), C.c_void_p(gathered[r].data_ptr()),
-                                                 C.c_void_p(film.data_ptr()), film.shape[1], C.c_void_p(stream))
-            api._check(rc, lib)
+        assert gathered.is_contiguous() and gathered.shape[0] == world
+        rank_stride = gathered[0].numel()
+        rc = lib.kyhip_film_add_gathered_device(device_index, C.byref(params), world, C.c_void_p(gathered.data_ptr()), rank_stride,
+                                                C.c_void_p(film.data_ptr()), film.shape[1], C.c_void_p(stream))
+        api._check(rc, lib)
         return film
     for r in range(world):
         for k in range(shard_tile_count(params, r, world)):
@@ -97,11 +135,13 @@ def add_tiles_to_film(film, gathered, params, world, device_index=0):
 
 
 def render_distributed(scene, params, rank, world, device_index=0, film=None, group=None):
-    """integrator_t::render over `world` GPUs.  Returns the film (a CUDA tensor) on rank 0, None elsewhere."""
-    tiles = render_shard(scene, params, rank, world, device_index)
-    gathered = gather_tiles(tiles, rank, world, group)
+    """integrator_t::render over `world` GPUs.  Returns the film (a CUDA tensor) on rank 0, None elsewhere.
+    Per frame: one render launch per rank, ONE gather, one add kernel on rank 0; the buffers are cached (FrameBuffers)."""
+    fb = frame_buffers(params, rank, world, torch.device("cuda", device_index))
+    render_shard(scene, params, rank, world, device_index, out=fb.tiles)
+    gathered = gather_tiles(fb.tiles, rank, world, group, out=fb.gathered, out_list=getattr(fb, "gather_list", None))
     if rank != 0:
         return None
     if film is None:
-        film = torch.zeros((params.height, params.width, 3), dtype=torch.float32, device=tiles.device)
+        film = torch.zeros((params.height, params.width, 3), dtype=torch.float32, device=fb.tiles.device)
     return add_tiles_to_film(film, gathered, params, world, device_index)

@@ -679,19 +679,33 @@ public:
         p.seed = original_sampler->seed();
         p.width = (int)res.x; p.height = (int)res.y;
         p.tile_w = 16; p.tile_h = 16; p.tile_first = 0; p.tile_step = 1;
-        const int rc = kyhip_render(device_, &scene->flatten(), &p, film->target_origin(), film->row_stride_px());
-        if (rc != KY_OK) throw std::runtime_error(std::string("kyhip_render: ") + kyhip_last_error());
+        // the reference spreads this loop over all cores (3696-3699); here the frame's tiles are spread over devices_
+        const int rc = kyhip_render_multi(devices_.data(), (int)devices_.size(), &scene->flatten(), &p, film->target_origin(), film->row_stride_px());
+        if (rc != KY_OK) throw std::runtime_error(std::string("kyhip_render_multi: ") + kyhip_last_error());
     }
-    // duration of the integrator kernel of the last render(), milliseconds (hipEvents on the launch stream)
-    float last_kernel_ms() const { return kyhip_kernel_ms(device_); }
+    // duration of the integrator kernel of the last render() on the first device, milliseconds (hipEvents on the launch stream)
+    float last_kernel_ms() const { return kyhip_kernel_ms(devices_[0]); }
+
+    // The GPUs render() uses (default: the one device given to the constructor).  Tiles are interleaved over the list and
+    // gathered on its first entry; the image does not depend on the list.  all_devices() = every GPU the process sees.
+    void set_devices(std::vector<int> devices) {
+        if (devices.empty()) throw std::runtime_error("integrator_t::set_devices: empty device list");
+        devices_ = std::move(devices);
+    }
+    const std::vector<int>& devices() const { return devices_; }
+    static std::vector<int> all_devices() {
+        std::vector<int> d(std::max(1, kyhip_device_count()));
+        for (size_t i = 0; i < d.size(); ++i) d[i] = (int)i;
+        return d;
+    }
 
 protected:
     integrator_t(integrator_enum_t kind, int max_path_depth, direct_sample_enum_t direct_sample_enum, int device)
-        : kind_(kind), max_path_depth_(max_path_depth), direct_sample_enum_(direct_sample_enum), device_(device) {}
+        : kind_(kind), max_path_depth_(max_path_depth), direct_sample_enum_(direct_sample_enum), devices_{device} {}
     integrator_enum_t kind_;
     int max_path_depth_;
     direct_sample_enum_t direct_sample_enum_;
-    int device_;
+    std::vector<int> devices_;
 };
 
 // debug_integrator_t(position | normal | basecolor), ky.cpp:4094-4123

@@ -66,10 +66,14 @@ int kyhost_render(void* scene, int integrator_enum, int depth, int direct_sample
         std::unique_ptr<ky::integrator_t> integrator;
         const auto ie = (ky::integrator_enum_t)integrator_enum;
         if (ie == ky::integrator_enum_t::position || ie == ky::integrator_enum_t::normal || ie == ky::integrator_enum_t::basecolor)
-            integrator = std::make_unique<ky::debug_integrator_t>(ie, device);                          // 4730-4731
+            integrator = std::make_unique<ky::debug_integrator_t>(ie, device < 0 ? 0 : device);                          // 4730-4731
         else
-            integrator = ky::create_integrator(ie, depth, (ky::direct_sample_enum_t)direct_sample_enum, device);  // 4621
+            integrator = ky::create_integrator(ie, depth, (ky::direct_sample_enum_t)direct_sample_enum, device < 0 ? 0 : device);  // 4621
         if (!integrator) { status = -2; return; }
+        // device < 0 selects a device LIST: -1 = every visible GPU; -n (n >= 2) = device 0 listed n times, which drives the
+        // multi-device path (shards, gather, one add) on a single GPU
+        if (device == -1) integrator->set_devices(ky::integrator_t::all_devices());
+        else if (device < -1) integrator->set_devices(std::vector<int>((size_t)-device, 0));
         std::unique_ptr<ky::sampler_t> sampler;
         if (sampler_kind == KY_SAMPLER_DEBUG) sampler = std::make_unique<ky::debug_sampler_t>(spp);
         else sampler = std::make_unique<ky::random_sampler_t>(spp);

@@ -1,0 +1,220 @@
+"""BASELINE.json configs[2], [3], [4] as the driver-run GPU tests see them (configs[0] and [1]: tests/test_smallpt*.py,
+tests/test_parity_gpu.py::test_full_size_properties and bench.py itself).
+
+For every configuration: (a) oracle parity at the configuration's FULL samples per pixel on single tiles of the full-size
+frame, selected with tile_first / tile_step -- the oracle honours shards, and one 16 x 16 tile is a second of host time --
+with the north star's tolerance RMSE < 1e-3; (b) size-independent properties of a full-size render (finite, clamped,
+deterministic, tile renders are cut-outs of the frame, statistics agree with a small render); (c) the multi-device entry of
+the C ABI on one GPU.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import film_writers as FW
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVERS = os.path.join(ROOT, "examples", "bin", "ky_drivers")
+
+
+def _tile_number(params, tx, ty):
+    """Number of the tile at tile column tx, tile row ty (include/kyhip.h: rows rotated by their index)."""
+    tiles_x = (params.width + params.tile_w - 1) // params.tile_w
+    return ty * tiles_x + (tx - ty) % tiles_x
+
+
+def _one_tile(A, params, tx, ty):
+    p = A.RenderParams.from_buffer_copy(params)
+    p.tile_first = _tile_number(params, tx, ty)
+    p.tile_step = 1 << 30
+    return p
+
+
+def _tile_parity(A, api, O, scene, params, tiles, tol=1e-3):
+    """GPU vs oracle on single tiles of the full-size frame at the frame's full spp.  Returns the RMSE per tile."""
+    out = []
+    for (tx, ty) in tiles:
+        p = _one_tile(A, params, tx, ty)
+        g = api.render(scene, p)
+        c = O.render(scene, p)
+        x0, y0 = tx * params.tile_w, ty * params.tile_h
+        gt, ct = g[y0:y0 + params.tile_h, x0:x0 + params.tile_w], c[y0:y0 + params.tile_h, x0:x0 + params.tile_w]
+        assert g.sum() == pytest.approx(float(gt.sum())), "pixels outside the selected tile were written"
+        fin = np.isfinite(ct).all(axis=2)          # the reference's own NaN samples (DESIGN.md "Non-finite samples")
+        assert fin.mean() > 0.99 and np.isfinite(gt).all()
+        rmse = float(np.sqrt(np.mean((gt[fin].astype(np.float64) - ct[fin]) ** 2)))
+        assert rmse < tol, ((tx, ty), rmse)
+        out.append(rmse)
+    return out
+
+
+def test_c3_veach_full_size(A, api, O):
+    """configs[2]: render_mis_scene's scene (ky.cpp:4878-4905), 1280 x 720, 4096 spp, path_tracing_iteration d5 both_mis."""
+    W, H, spp = 1280, 720, 4096
+    scene = api.mis_scene(W, H)
+    params = api.make_params(W, H, spp)
+    # tiles on the planks under each light's highlight, on the floor, on the back wall and on a light
+    rmse = _tile_parity(A, api, O, scene, params, [(20, 30), (40, 33), (60, 36), (10, 42), (70, 8), (52, 20)])
+    print("C3 tile RMSE at 4096 spp:", ["%.2e" % r for r in rmse])
+    # the full frame (3.8e9 samples, well under a second of kernel time)
+    a = api.render(scene, params)
+    assert a.shape == (H, W, 3) and np.isfinite(a).all() and a.min() >= 0 and a.max() <= 1
+    # a tile render is a cut-out of the frame, bit for bit (global sample keys, order-independent accumulation)
+    t = api.render(scene, _one_tile(A, params, 40, 33))
+    assert np.array_equal(t[33 * 16:34 * 16, 40 * 16:41 * 16], a[33 * 16:34 * 16, 40 * 16:41 * 16])
+    # statistics: same mean as a quarter-size render of the same scene within Monte-Carlo noise of the small one
+    small = api.render(api.mis_scene(W // 4, H // 4), api.make_params(W // 4, H // 4, 256))
+    assert abs(float(a.mean()) - float(small.mean())) < 3e-3, (a.mean(), small.mean())
+    # all six strategies of the driver at full size, reduced spp: every one finite, and the unbiased ones agree in the mean
+    means = {}
+    for strat in (A.DIRECT_BSDF, A.DIRECT_LIGHT, A.DIRECT_IDLE, A.DIRECT_BSDF_MIS, A.DIRECT_LIGHT_MIS, A.DIRECT_BOTH_MIS):
+        f = api.render(scene, api.make_params(W, H, 64, direct_sample=strat))
+        assert np.isfinite(f).all() and f.min() >= 0 and f.max() <= 1
+        means[strat] = float(f.mean())
+    assert means[A.DIRECT_IDLE] < means[A.DIRECT_BOTH_MIS]
+    # both_mis is half the sum of its two halves (4081-4083), here as an identity between expectations
+    half_sum = 0.5 * (means[A.DIRECT_BSDF_MIS] + means[A.DIRECT_LIGHT_MIS])
+    assert abs(means[A.DIRECT_BOTH_MIS] - half_sum) < 0.01 * half_sum, means
+
+
+BATCH_LIGHTS = ("CB_LIGHT_POINT", "CB_LIGHT_DIRECTION", "CB_LIGHT_AREA", "CB_LIGHT_ENVIRONMENT")
+
+
+def test_c4_batch(A, api, O, tmp_path):
+    """configs[3]: the render_multiple_scene batch (ky.cpp:4819-4876) at 1024 x 1024, 2048 spp -- four Cornell light
+    variants + Veach + a first-hit AOV pass -- through the C++ driver (film_grid_t, integrator->render per cell, BMP out)
+    and, frame by frame, against the oracle on single tiles at the full 2048 spp."""
+    res, spp = 1024, 2048
+    frames = []
+    for name in BATCH_LIGHTS:
+        frames.append((api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | getattr(A, name), res, res), api.make_params(res, res, spp)))
+    veach = api.mis_scene(res, res)
+    frames.append((veach, api.make_params(res, res, spp)))
+    frames.append((veach, api.make_params(res, res, 1, integrator=A.INTEGRATOR_NORMAL, sampler=A.SAMPLER_DEBUG)))
+    # (a) parity at full spp: one tile on the glossy floor near the spheres, one on a wall, for every lit frame
+    for i, (scene, params) in enumerate(frames[:5]):
+        tiles = [(30, 50), (8, 20)] if i < 4 else [(30, 40), (40, 50)]
+        rmse = _tile_parity(A, api, O, scene, params, tiles)
+        print("C4 frame %d tile RMSE at 2048 spp:" % i, ["%.2e" % r for r in rmse])
+    # (b) the whole batch through the C++ driver; its mosaic must be, byte for byte, the numpy writer's encoding of the grid
+    # built through the C ABI from Python (independent writer: oracle/film_writers.py)
+    if not os.path.exists(DRIVERS):
+        pytest.skip("examples not built")
+    out = subprocess.run([DRIVERS, "batch"], cwd=tmp_path, capture_output=True, text=True, check=True).stdout
+    assert "Msamples/s" in out
+    got = open(tmp_path / "batch.bmp", "rb").read()
+    grid = np.zeros((2 * res, 3 * res, 3), np.float32)
+    for cell, (scene, params) in enumerate(frames):
+        api.render(scene, params, film=grid, origin_px=((cell % 3) * res, (cell // 3) * res))
+    assert np.isfinite(grid).all() and grid.min() >= 0 and grid.max() <= 1
+    for cell in range(6):
+        sub = grid[(cell // 3) * res:(cell // 3 + 1) * res, (cell % 3) * res:(cell % 3 + 1) * res]
+        assert sub.mean() > 0.01, cell
+    want = FW.bmp_bytes(grid)
+    assert len(got) == len(want) == 54 + grid.size
+    assert got == want
+
+
+def test_c5_stress(A, api, O):
+    """configs[4]: Cornell 4096 x 4096, 16384 spp, max depth 16.  The whole frame is 2.7e11 samples (tens of seconds on one
+    GPU: bench.py --workload stress); here: oracle parity on single tiles at the full 16384 spp, one rank's 1/8 shard of the
+    frame at reduced spp with the properties a shard must have, and the frame's statistics against a small render."""
+    W = H = 4096
+    spp, depth = 16384, 16
+    scene = api.cornell_box_scene(A.CB_DEFAULT_SCENE, W, H)
+    params = api.make_params(W, H, spp, max_path_depth=depth)
+    rmse = _tile_parity(A, api, O, scene, params, [(128, 200), (60, 128), (170, 215)])   # floor, left wall, under the glass sphere
+    print("C5 tile RMSE at 16384 spp, depth 16:", ["%.2e" % r for r in rmse])
+    # one rank's shard of an 8-GPU run (tiles 3, 11, 19, ...) at 64 spp: 1.3e8 samples
+    p64 = api.make_params(W, H, 64, max_path_depth=depth, tile_first=3, tile_step=8)
+    a = api.render(scene, p64)
+    b = api.render(scene, p64)
+    assert np.array_equal(a, b) and np.isfinite(a).all() and a.min() >= 0 and a.max() <= 1
+    owned = np.zeros((H // 16, W // 16), bool)
+    for t in range(3, (W // 16) * (H // 16), 8):
+        row = t // (W // 16)
+        owned[row, (t % (W // 16) + row) % (W // 16)] = True
+    lit = a.reshape(H // 16, 16, W // 16, 16, 3).sum(axis=(1, 3, 4)) > 0
+    assert not (lit & ~owned).any()                  # nothing outside the shard
+    assert (lit & owned).sum() > 0.95 * owned.sum()  # (a few tiles of the open front see only the black outside)
+    assert abs(owned.sum() - owned.size / 8) <= 1 and owned.any(axis=1).all()   # a comb of diagonals: every tile row is visited
+    # statistics of the shard = statistics of the frame = those of a small render (depth 16 too)
+    small = api.render(api.cornell_box_scene(A.CB_DEFAULT_SCENE, 256, 256), api.make_params(256, 256, 1024, max_path_depth=depth))
+    shard_mean = float(a.reshape(H // 16, 16, W // 16, 16, 3).mean(axis=(1, 3, 4))[owned].mean())
+    assert abs(shard_mean - float(small.mean())) < 3e-3, (shard_mean, small.mean())
+    # the 32-bit limits of the device code are checked, not overflowed: 4096^2 at 2e6 spp has > 2^32 work items
+    lib = A.load_kyhip()
+    import ctypes as C
+    huge = api.make_params(W, H, 2_000_000, max_path_depth=depth)
+    film = np.zeros((8, 8, 3), np.float32)
+    assert lib.kyhip_render(0, scene.flat, C.byref(huge), film.ctypes.data_as(C.c_void_p), W) == A.KY_ERR_LIMIT
+
+
+def test_render_multi_on_one_gpu(A, api):
+    """kyhip_render_multi (the multi-GPU render behind the C ABI) with device 0 listed two and three times: shards on the
+    device's stream, gather block, ONE de-interleaving add -- bit-identical to the single-device call; and the C++ host
+    mirror's integrator_t::set_devices through the same path."""
+    for scene, p in ((api.cornell_box_scene(A.CB_DEFAULT_SCENE, 200, 120), api.make_params(200, 120, 24)),
+                     (api.mis_scene(97, 61), api.make_params(97, 61, 9, tile_w=8, tile_h=24)),
+                     (api.cornell_box_scene(A.CB_DEFAULT_SCENE, 64, 64), api.make_params(64, 64, 5, direct_sample=A.DIRECT_LIGHT, tile_w=32, tile_h=32))):
+        single = api.render(scene, p)
+        for devices in ([0], [0, 0], [0, 0, 0], [0] * 7):
+            multi = api.render_multi(scene, p, devices)
+            assert np.array_equal(single, multi), devices
+        # additive, and a sub-range of tiles through the multi entry
+        twice = api.render_multi(scene, p, [0, 0], film=single.copy())
+        assert np.array_equal(twice, single + single)
+    scene = api.cornell_box_scene(A.CB_DEFAULT_SCENE, 96, 64)
+    one = api.render_host_api(scene, 11, 5, 48, A.SAMPLER_RANDOM, 6, 96, 64, device=0)
+    three = api.render_host_api(scene, 11, 5, 48, A.SAMPLER_RANDOM, 6, 96, 64, device=-3)   # set_devices({0, 0, 0})
+    every = api.render_host_api(scene, 11, 5, 48, A.SAMPLER_RANDOM, 6, 96, 64, device=-1)   # all_devices()
+    assert np.array_equal(one, three) and np.array_equal(one, every)
+    import ctypes as C
+    lib = A.load_kyhip()
+    film = np.zeros((64, 96, 3), np.float32)
+    p = api.make_params(96, 64, 2)
+    assert lib.kyhip_render_multi(None, 1, scene.flat, C.byref(p), film.ctypes.data_as(C.c_void_p), 96) == A.KY_ERR_INVALID_VALUE
+    bad = (C.c_int * 2)(0, 99)
+    assert lib.kyhip_render_multi(bad, 2, scene.flat, C.byref(p), film.ctypes.data_as(C.c_void_p), 96) == A.KY_ERR_INVALID_VALUE
+
+
+def test_streams_on_one_device_do_not_race(A, api):
+    """Two kyhip_render_tiles_device calls in flight on DIFFERENT streams of one device: the library orders the
+    second behind the first on the device, so both images are the ones a lone call produces."""
+    import ctypes as C
+    import torch
+    lib = A.load_kyhip()
+    dev = torch.device("cuda", 0)
+    scene_a, pa = api.cornell_box_scene(A.CB_DEFAULT_SCENE, 512, 384), api.make_params(512, 384, 48)
+    scene_b, pb = api.mis_scene(320, 200), api.make_params(320, 200, 24)
+    ref_a, ref_b = api.render(scene_a, pa), api.render(scene_b, pb)
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    for _ in range(3):
+        ta = torch.zeros((lib.kyhip_shard_float_count(C.byref(pa)),), dtype=torch.float32, device=dev)
+        tb = torch.zeros((lib.kyhip_shard_float_count(C.byref(pb)),), dtype=torch.float32, device=dev)
+        fa = torch.zeros((384, 512, 3), dtype=torch.float32, device=dev)
+        fb = torch.zeros((200, 320, 3), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(dev)
+        api._check(lib.kyhip_render_tiles_device(0, scene_a.flat, C.byref(pa), C.c_void_p(ta.data_ptr()), None, 0, C.c_void_p(s1.cuda_stream)))
+        api._check(lib.kyhip_render_tiles_device(0, scene_b.flat, C.byref(pb), C.c_void_p(tb.data_ptr()), None, 0, C.c_void_p(s2.cuda_stream)))
+        api._check(lib.kyhip_film_add_tiles_device(0, C.byref(pa), C.c_void_p(ta.data_ptr()), C.c_void_p(fa.data_ptr()), 512, C.c_void_p(s1.cuda_stream)))
+        api._check(lib.kyhip_film_add_tiles_device(0, C.byref(pb), C.c_void_p(tb.data_ptr()), C.c_void_p(fb.data_ptr()), 320, C.c_void_p(s2.cuda_stream)))
+        torch.cuda.synchronize(dev)
+        assert np.array_equal(fa.cpu().numpy(), ref_a) and np.array_equal(fb.cpu().numpy(), ref_b)
+
+
+def test_gpu_film_to_bmp_with_odd_width(A, api, tmp_path):
+    """SURVEY 8(f)1 on a GPU film whose width is not a multiple of 4 (the reference's padding quirk): the C++ writer's file
+    equals the numpy restatement's bytes; PPM and HDR likewise."""
+    scene = api.cornell_box_scene(A.CB_DEFAULT_SCENE, 50, 34)
+    film = api.render(scene, api.make_params(50, 34, 16))
+    for kind, fn in (("bmp", FW.bmp_bytes), ("ppm", FW.ppm_bytes), ("hdr", FW.hdr_bytes)):
+        path = str(tmp_path / ("odd." + kind))
+        api.store_image(path, film, kind)
+        assert open(path, "rb").read() == fn(film), kind
+    b = open(tmp_path / "odd.bmp", "rb").read()
+    assert len(b) == 54 + 50 * 34 * 3 and int.from_bytes(b[2:6], "little") == 54 + 152 * 34

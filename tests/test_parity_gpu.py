@@ -333,10 +333,21 @@ def test_cpp_driver_matches_the_c_abi_path(A, api, tmp_path):
     for cell, strat in enumerate((4, 8, 0, 16, 32, 48)):
         p = api.make_params(512, 308, 10, direct_sample=strat)
         api.render(scene, p, film=grid, origin_px=((cell % 3) * 512, (cell // 3) * 308))
-    api.store_image(str(tmp_path / "py.bmp"), grid, "bmp")
-    want = open(tmp_path / "py.bmp", "rb").read()
+    from oracle import film_writers as FW
+    want = FW.bmp_bytes(grid)          # the independent numpy restatement of store_bmp_impl (ky.cpp:1661-1737), not the C++ writer
     assert len(got) == len(want) == 54 + 3 * 512 * 2 * 308 * 3
     assert got == want
+    # render_multiple_scene (4819-4876), the other mosaic driver: 3 strategies x 4 Cornell lights, strategy-major
+    subprocess.check_call([exe, "multiple_scene"], cwd=tmp_path, stdout=subprocess.DEVNULL)
+    got = open(tmp_path / "light_mis.bmp", "rb").read()
+    grid = np.zeros((3 * 256, 4 * 256, 3), np.float32)
+    cell = 0
+    for strat in (4, 8, 48):
+        for flag, spp in ((A.CB_LIGHT_POINT, 10), (A.CB_LIGHT_DIRECTION, 40), (A.CB_LIGHT_AREA, 40), (A.CB_LIGHT_ENVIRONMENT, 10)):
+            sc = api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | flag, 256, 256)
+            api.render(sc, api.make_params(256, 256, spp, direct_sample=strat), film=grid, origin_px=((cell % 4) * 256, (cell // 4) * 256))
+            cell += 1
+    assert got == FW.bmp_bytes(grid)
 
 
 def general_shapes_scene(A, api):

@@ -119,9 +119,10 @@ def add_tiles_to_film(film, gathered, params, world, device_index=0):
         lib = A.load_kyhip()
         stream = torch.cuda.current_stream(film.device).cuda_stream
         assert gathered.is_contiguous() and gathered.shape[0] == world
+        assert film.stride(2) == 1 and film.stride(1) == 3   # a film or a cell of a larger film (film_grid_t): rows may be strided
         rank_stride = gathered[0].numel()
         rc = lib.kyhip_film_add_gathered_device(device_index, C.byref(params), world, C.c_void_p(gathered.data_ptr()), rank_stride,
-                                                C.c_void_p(film.data_ptr()), film.shape[1], C.c_void_p(stream))
+                                                C.c_void_p(film.data_ptr()), film.stride(0) // 3, C.c_void_p(stream))
         api._check(rc, lib)
         return film
     for r in range(world):

@@ -76,9 +76,9 @@ def test_c3_veach_full_size(A, api, O):
         assert np.isfinite(f).all() and f.min() >= 0 and f.max() <= 1
         means[strat] = float(f.mean())
     assert means[A.DIRECT_IDLE] < means[A.DIRECT_BOTH_MIS]
-    # both_mis is half the sum of its two halves (4081-4083), here as an identity between expectations
-    half_sum = 0.5 * (means[A.DIRECT_BSDF_MIS] + means[A.DIRECT_LIGHT_MIS])
-    assert abs(means[A.DIRECT_BOTH_MIS] - half_sum) < 0.01 * half_sum, means
+    # (the per-sample identity both_mis = (bsdf_mis + light_mis) / 2 is tests/test_parity_gpu.py::test_mis_strategies_are_linear;
+    # film means do not obey it: clamp01 per pixel is not linear)
+    assert means[A.DIRECT_IDLE] < min(means[A.DIRECT_BSDF], means[A.DIRECT_LIGHT], means[A.DIRECT_BSDF_MIS], means[A.DIRECT_LIGHT_MIS])
 
 
 BATCH_LIGHTS = ("CB_LIGHT_POINT", "CB_LIGHT_DIRECTION", "CB_LIGHT_AREA", "CB_LIGHT_ENVIRONMENT")

@@ -108,7 +108,7 @@ def workload(args):
 
 def cpu_baseline(frames, gpu_render, target_seconds):
     """Time the CPU oracle (a port of the reference's algorithm, all host threads) on a BOUNDED sample of the same workload:
-    of every frame an interleaved subset of its tiles (about 65k pixels spread over the whole picture; the oracle honours
+    of every frame an interleaved subset of its tiles (about 131k pixels spread over the whole picture; the oracle honours
     tile_first / tile_step) at reduced spp -- the rate depends on neither.  Returns the baseline object and the RMSE of the
     GPU's render of the very same sample against it."""
     from oracle import kyoracle as O
@@ -117,7 +117,7 @@ def cpu_baseline(frames, gpu_render, target_seconds):
     def sample_params(fr, spp):
         p = A.RenderParams.from_buffer_copy(fr.params)
         p.tile_first = 0
-        p.tile_step = max(1, kydist.tiles_total(fr.params) * fr.params.tile_w * fr.params.tile_h // 65536)
+        p.tile_step = max(1, kydist.tiles_total(fr.params) * fr.params.tile_w * fr.params.tile_h // 131072)
         p.samples_per_pixel = max(1, min(fr.params.samples_per_pixel, spp))
         return p
 

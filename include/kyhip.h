@@ -290,6 +290,15 @@ int kyhip_kat_occluded(int device, const ky_scene* scene, const float* in9, int 
 int kyhip_kat_li(int device, const ky_scene* scene, const ky_render_params* params,
                  int x, int y, int s0, int n, float* out3);
 
+/* The same sample of path_tracing_iteration_t vertex by vertex (the reference's LOG_VAST at ky.cpp:4578 prints the same facts):
+   one row of 26 floats per vertex that reaches the continuation sample (4586):
+   {bounces, surface (caller's index), lobe (0 lambert, 1 mirror, 2 glass, 3 phong), position[3], normal[3], wo[3],
+    beta[3] before the bounce, Lo[3] after this vertex's direct lighting, bs.f[3], bs.pdf, |dot(bs.wi, normal)|, bsdf flags,
+    bits of the lights whose BSDF-sampling estimate was non-black, bits of the lights whose light-sampling estimate was}.
+   Returns the number of rows written (<= max_rows) or a negative ky_status; li3 (optional) receives the sample's radiance. */
+int kyhip_kat_li_trace(int device, const ky_scene* scene, const ky_render_params* params, int x, int y, int s,
+                       float* rows26, int max_rows, float* li3);
+
 /* ---- the smallpt lineage's own scene, in double precision -----------------------------------------
    smallpt2pbrt/smallpt.cpp is the 99-line path tracer ky grew out of (smallpt_milo.cpp is its 256 x 256 build):
    9 spheres -- the walls are spheres of radius 1e5, which is why ky's fp32 sphere test cannot render this scene

@@ -177,6 +177,17 @@ def kat_li(scene, params, x, y, s0, n, device=0):
     return out
 
 
+def kat_li_trace(scene, params, x, y, s, max_rows=64, device=0):
+    """kyhip_kat_li_trace: (rows [n, 26], li [3]) of one camera sample of path_tracing_iteration_t."""
+    lib = A.load_kyhip()
+    rows = np.zeros((max_rows, 26), np.float32)
+    li = np.zeros(3, np.float32)
+    n = lib.kyhip_kat_li_trace(device, _scene_ptr(scene), C.byref(params), x, y, s, _fptr(rows), max_rows, _fptr(li))
+    if n < 0:
+        _check(n, lib)
+    return rows[:n], li
+
+
 # ---- SURVEY 8(f)4: smallpt's own scene in double precision --------------------------------------
 
 def smallpt_scene():

@@ -1058,8 +1058,11 @@ KY_DEV f3 estimate_by_emitter(const DScene* __restrict__ S, const LdsScene& Lds,
 
 // sample_all_light, 3834-3872.  Wave-uniform call; `active` lanes draw 4 numbers per light (+2 for the plain bsdf
 // strategy, 3900) and accumulate the estimators.
+// `decisions` (KAT tracing only; a null constant everywhere else, which removes the code): bit li = the BSDF half of light li's
+// estimate was non-black, bit 16 + li = its light half.
 template <bool DEBUG_SAMPLER>
-KY_DEV f3 sample_all_light(const DScene* __restrict__ S, const LdsScene& Lds, const Vertex& v, Sampler& smp, int strategy, bool active) {
+KY_DEV f3 sample_all_light(const DScene* __restrict__ S, const LdsScene& Lds, const Vertex& v, Sampler& smp, int strategy, bool active,
+                           unsigned* decisions = nullptr) {
     f3 Ld = mk3(0, 0, 0);
     const int nl = S->n_lights;
     for (int li = 0; li < nl; ++li) {
@@ -1076,25 +1079,28 @@ KY_DEV f3 sample_all_light(const DScene* __restrict__ S, const LdsScene& Lds, co
                 Ll = estimate_by_emitter<true>(S, Lds, v, li, ul0, ul1);
             }
             Ld = Ld + (0.5f * Lb + 0.5f * Ll);
+            if (decisions && li < 16) *decisions |= (is_black(Lb) ? 0u : 1u << li) | (is_black(Ll) ? 0u : 1u << (16 + li));
             continue;
         }
         if (active) { ul0 = sampler_next<DEBUG_SAMPLER>(smp); ul1 = sampler_next<DEBUG_SAMPLER>(smp); }
         KY_CLK(3);
-        if (strategy == KY_DIRECT_BOTH_MIS) {
-        } else if (strategy == KY_DIRECT_BSDF_MIS) {
-            Ld = Ld + estimate_by_bsdf<true>(S, Lds, v, li, ub0, ub1, active);
+        f3 Lb = mk3(0, 0, 0), Ll = mk3(0, 0, 0);
+        if (strategy == KY_DIRECT_BSDF_MIS) {
+            Lb = estimate_by_bsdf<true>(S, Lds, v, li, ub0, ub1, active);
         } else if (strategy == KY_DIRECT_LIGHT_MIS) {
-            if (active) Ld = Ld + estimate_by_emitter<true>(S, Lds, v, li, ul0, ul1);
+            if (active) Ll = estimate_by_emitter<true>(S, Lds, v, li, ul0, ul1);
         } else if (strategy == KY_DIRECT_LIGHT) {
-            if (active) Ld = Ld + estimate_by_emitter<false>(S, Lds, v, li, ul0, ul1);
+            if (active) Ll = estimate_by_emitter<false>(S, Lds, v, li, ul0, ul1);
         } else if (strategy == KY_DIRECT_BSDF) {
             const int lk = S->light[li].kind;
             if (!(lk == KY_LIGHT_POINT || lk == KY_LIGHT_DIRECTION)) {  // the third float2 is drawn after the delta test (3894-3900)
                 float u0 = 0.f, u1 = 0.f;
                 if (active) { u0 = sampler_next<DEBUG_SAMPLER>(smp); u1 = sampler_next<DEBUG_SAMPLER>(smp); }
-                Ld = Ld + estimate_by_bsdf<false>(S, Lds, v, li, u0, u1, active);
+                Lb = estimate_by_bsdf<false>(S, Lds, v, li, u0, u1, active);
             }
         }
+        Ld = Ld + (Lb + Ll);
+        if (decisions && li < 16) *decisions |= (is_black(Lb) ? 0u : 1u << li) | (is_black(Ll) ? 0u : 1u << (16 + li));
         // KY_DIRECT_IDLE: estimate_direct_lighting_idle, 3880-3886
     }
     return Ld;
@@ -1180,9 +1186,16 @@ KY_DEV int path_pick_lobe(PathState& ps, int surface, const LdsScene& Lds) {
 
 // Second half: material, direct lighting, continuation.  WAVE-UNIFORM call: every lane of the wave calls it, `active`
 // says whether this lane holds a vertex.  Returns true when the (active) lane's path continues.
+// per-vertex trace of one path (kyhip_kat_li_trace): rows of 26 floats, the format of the oracle's kyo_trace_li
+struct VertexTrace {
+    float* rows;
+    int max_rows, n;
+};
+
+// `tr` is a null constant everywhere but in the trace KAT kernel, which removes the tracing code.
 template <bool DEBUG_SAMPLER>
 KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, const LdsScene& Lds, const RenderConst& rc, bool active,
-                       int lobe = -1) {
+                       int lobe = -1, VertexTrace* tr = nullptr) {
     if (active) {
         // material->scattering(isect) for the nearest hit (3083); only plastic draws a lobe number (2663).
         // lobe >= 0: the caller has already made that draw (path_pick_lobe).
@@ -1217,8 +1230,9 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, c
     const bool delta = bsdf_is_delta(v.bsdf);
     const bool nee = active && !delta;  // 4571
     KY_PROBE(6);
+    unsigned decisions = 0;
     if (!simple) {  // simple_path_tracing_recursion_t samples the BSDF only
-        const f3 Ld = sample_all_light<DEBUG_SAMPLER>(S, Lds, v, ps.smp, rc.strategy, nee);  // 4575 / 4337 / 4458
+        const f3 Ld = sample_all_light<DEBUG_SAMPLER>(S, Lds, v, ps.smp, rc.strategy, nee, tr ? &decisions : nullptr);  // 4575 / 4337 / 4458
         if (nee) ps.Lo = ps.Lo + ps.beta * Ld;
     }
     KY_CLK(8);
@@ -1248,6 +1262,15 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, c
     KY_PROBE(7);
     BsdfSample bs = bsdf_sample_local(v.bsdf, vertex_wo(v), u0, u1);
     bs.wi = to_world(vertex_frame(v), bs.wi);
+    if (tr && tr->n < tr->max_rows) {
+        float* r = tr->rows + 26 * tr->n++;
+        const f3 wo = -ps.d;
+        r[0] = (float)ps.bounces; r[1] = (float)S->orig[v.surface]; r[2] = (float)v.bsdf.lobe;
+        r[3] = v.position.x; r[4] = v.position.y; r[5] = v.position.z; r[6] = v.normal.x; r[7] = v.normal.y; r[8] = v.normal.z;
+        r[9] = wo.x; r[10] = wo.y; r[11] = wo.z; r[12] = ps.beta.x; r[13] = ps.beta.y; r[14] = ps.beta.z;
+        r[15] = ps.Lo.x; r[16] = ps.Lo.y; r[17] = ps.Lo.z; r[18] = bs.f.x; r[19] = bs.f.y; r[20] = bs.f.z; r[21] = bs.pdf;
+        r[22] = fabsf(dot(bs.wi, v.normal)); r[23] = (float)bs.flags; r[24] = (float)(decisions & 0xffffu); r[25] = (float)(decisions >> 16);
+    }
     if (is_black(bs.f) || bs.pdf == 0.f) return false;  // 4588 / 4215 / 4385 / 4497
     if (rc.integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION) {
         ps.beta = ps.beta * (bs.f * (fabsf(dot(bs.wi, v.normal)) * rcp(bs.pdf)));  // 4592

@@ -462,6 +462,25 @@ __global__ void kat_li_kernel(const DScene* __restrict__ S, RenderConst rc, int 
     if (i < n) { out3[3 * (size_t)i] = ps.Lo.x; out3[3 * (size_t)i + 1] = ps.Lo.y; out3[3 * (size_t)i + 2] = ps.Lo.z; }
 }
 
+// one camera sample, traced vertex by vertex (lane 0 walks the path; the other lanes only keep the wave-uniform calls company)
+template <bool DEBUG_SAMPLER>
+__global__ void kat_li_trace_kernel(const DScene* __restrict__ S, RenderConst rc, int x, int y, int s, int max_rows, float* __restrict__ out) {
+    __shared__ LdsScene Lds;
+    stage_scene(Lds, S);
+    PathState ps;
+    bool alive = threadIdx.x == 0;
+    VertexTrace tr{out + 4, max_rows, 0};
+    if (alive) path_begin<DEBUG_SAMPLER>(ps, S, sampler_pixel_key(rc.seed, (uint32_t)(y * rc.width + x)), x, y, s);
+    while (__any(alive)) {
+        Vertex v;
+        bool have_vertex = false;
+        if (alive) have_vertex = path_intersect<DEBUG_SAMPLER>(ps, v, S, Lds, rc);
+        const bool cont = path_shade<DEBUG_SAMPLER>(ps, v, S, Lds, rc, have_vertex, -1, &tr);
+        alive = have_vertex && cont;
+    }
+    if (threadIdx.x == 0) { out[0] = (float)tr.n; out[1] = ps.Lo.x; out[2] = ps.Lo.y; out[3] = ps.Lo.z; }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1187,6 +1206,28 @@ int kyhip_kat_li(int device, const ky_scene* scene, const ky_render_params* p, i
         else hipLaunchKernelGGL(kat_li_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, 0, c->d_scene, rc, x, y, s0, n, d_out);
         return (int)KY_OK;
     });
+}
+
+int kyhip_kat_li_trace(int device, const ky_scene* scene, const ky_render_params* p, int x, int y, int s, float* rows26, int max_rows, float* li3) {
+    if (!valid_params(p)) return fail(KY_ERR_INVALID_VALUE, "invalid render params");
+    if (p->integrator != KY_INTEGRATOR_PATH_TRACING_ITERATION) return fail(KY_ERR_INVALID_VALUE, "the vertex trace follows path_tracing_iteration_t");
+    if (!scene || !rows26 || max_rows <= 0 || max_rows > 4096 || s < 0 || x < 0 || y < 0 || x >= p->width || y >= p->height) return fail(KY_ERR_INVALID_VALUE, "bad KAT arguments");
+    const RenderConst rc = make_rc(p);
+    const bool dbg = p->sampler == KY_SAMPLER_DEBUG;
+    std::vector<float> host((size_t)4 + (size_t)max_rows * 26, 0.f);
+    float dummy = 0.f;
+    const int rcode = kat_run(device, &dummy, 4, host.data(), host.size() * 4, [&](DeviceCtx* c, const float*, float* d_out) {
+        int r = upload_scene(c, scene, 0);
+        if (r != KY_OK) return r;
+        if (dbg) hipLaunchKernelGGL(kat_li_trace_kernel<true>, dim3(1), dim3(64), 0, 0, c->d_scene, rc, x, y, s, max_rows, d_out);
+        else hipLaunchKernelGGL(kat_li_trace_kernel<false>, dim3(1), dim3(64), 0, 0, c->d_scene, rc, x, y, s, max_rows, d_out);
+        return (int)KY_OK;
+    });
+    if (rcode != KY_OK) return rcode;
+    const int n = (int)host[0];
+    std::memcpy(rows26, host.data() + 4, (size_t)n * 26 * sizeof(float));
+    if (li3) { li3[0] = host[1]; li3[1] = host[2]; li3[2] = host[3]; }
+    return n;
 }
 
 // ---- smallpt's scene in double precision (ky_smallpt.hpp) ----

@@ -801,8 +801,11 @@ inline ray_t generate_ray(const ky_camera& cam, vec2_t p_film) {
 struct integrator_t {
     const scene_t* scene;
     int kind, max_path_depth, direct_sample;
-    // optional per-vertex trace (kyo_trace_li; the analogue of LOG_VAST, ky.cpp:4578): 24 floats per vertex
+    // optional per-vertex trace (kyo_trace_li; the analogue of LOG_VAST, ky.cpp:4578): 26 floats per vertex
     mutable std::vector<float>* trace = nullptr;
+    // which per-light estimates of the last sample_all_light call were non-black: bit li = the BSDF-sampling half,
+    // bit 16 + li = the light-sampling half (the discrete outcome of the carrier / occlusion / zero-value tests)
+    mutable unsigned decisions = 0;
 
     // estimate_direct_lighting_by_bsdf, 3889-3930
     color_t by_bsdf(const isect_t& isect, int li, sampler_t& sampler, counters_t* c) const {
@@ -882,6 +885,7 @@ struct integrator_t {
     // sample_all_light, 3834-3872.  Returns false for an illegal strategy value (bad_function_call, quirk 10).
     color_t sample_all_light(const isect_t& isect, sampler_t& sampler, counters_t* c) const {
         color_t Ld;
+        decisions = 0;
         if (c) c->nee_vertices++;
         const int n = (int)scene->lights.size();
         for (int li = 0; li < n; ++li) {
@@ -890,19 +894,21 @@ struct integrator_t {
             vec2_t random_bsdf  = sampler.get_float2();
             vec2_t random_light = sampler.get_float2();
             if (c) c->light_estimates++;
+            color_t Lb, Ll;
             switch (direct_sample) {
             case KY_DIRECT_IDLE: break;                                                             // 3880-3886
-            case KY_DIRECT_BSDF: Ld += by_bsdf(isect, li, sampler, c); break;
-            case KY_DIRECT_LIGHT: Ld += by_emitter(isect, li, random_light, c); break;
-            case KY_DIRECT_BSDF_MIS: Ld += by_bsdf_mis(isect, li, random_bsdf, c); break;
-            case KY_DIRECT_LIGHT_MIS: Ld += by_emitter_mis(isect, li, random_light, c); break;
+            case KY_DIRECT_BSDF: Lb = by_bsdf(isect, li, sampler, c); Ld += Lb; break;
+            case KY_DIRECT_LIGHT: Ll = by_emitter(isect, li, random_light, c); Ld += Ll; break;
+            case KY_DIRECT_BSDF_MIS: Lb = by_bsdf_mis(isect, li, random_bsdf, c); Ld += Lb; break;
+            case KY_DIRECT_LIGHT_MIS: Ll = by_emitter_mis(isect, li, random_light, c); Ld += Ll; break;
             case KY_DIRECT_BOTH_MIS: {                                                              // 4076-4088
-                color_t Lb = by_bsdf_mis(isect, li, random_bsdf, c);
-                color_t Ll = by_emitter_mis(isect, li, random_light, c);
+                Lb = by_bsdf_mis(isect, li, random_bsdf, c);
+                Ll = by_emitter_mis(isect, li, random_light, c);
                 Ld += 0.5f * Lb + 0.5f * Ll;
                 break;
             }
             }
+            if (li < 16) decisions |= (Lb.is_black() ? 0u : 1u << li) | (Ll.is_black() ? 0u : 1u << (16 + li));
         }
         return Ld;
     }
@@ -921,6 +927,7 @@ struct integrator_t {
                 else Lo += beta * scene->environment_lighting();
             }
             if (!hit || bounces >= max_path_depth) break;
+            decisions = 0;
             if (!isect.bsdf.is_delta()) {
                 color_t Ld = beta * sample_all_light(isect, sampler, c);
                 Lo += Ld;
@@ -928,10 +935,11 @@ struct integrator_t {
             if (c) c->bsdf_path_samples++;
             bsdf_sample_t bs = isect.bsdf.sample(isect.wo, sampler.get_float2());
             if (trace) {
-                const float row[24] = {(float)bounces, (float)isect.surface, (float)isect.bsdf.lobe, isect.position.x, isect.position.y, isect.position.z,
+                const float row[26] = {(float)bounces, (float)isect.surface, (float)isect.bsdf.lobe, isect.position.x, isect.position.y, isect.position.z,
                                        isect.normal.x, isect.normal.y, isect.normal.z, isect.wo.x, isect.wo.y, isect.wo.z, beta.r, beta.g, beta.b,
-                                       Lo.r, Lo.g, Lo.b, bs.f.r, bs.f.g, bs.f.b, bs.pdf, abs_dot(bs.wi, isect.normal), (float)bs.bsdf_type};
-                trace->insert(trace->end(), row, row + 24);
+                                       Lo.r, Lo.g, Lo.b, bs.f.r, bs.f.g, bs.f.b, bs.pdf, abs_dot(bs.wi, isect.normal), (float)bs.bsdf_type,
+                                       (float)(decisions & 0xffffu), (float)(decisions >> 16)};
+                trace->insert(trace->end(), row, row + 26);
             }
             if (bs.f.is_black() || bs.pdf == 0.f) break;
             beta *= bs.f * abs_dot(bs.wi, isect.normal) / bs.pdf;
@@ -1137,8 +1145,10 @@ int kyo_li(const ky_scene* cscene, const ky_render_params* p, int x, int y, int 
     return KY_OK;
 }
 
-// per-vertex trace of one camera sample (path integrator): rows of 24 floats
-// {bounce, surface, lobe, p[3], n[3], wo[3], beta[3], Lo[3], bs.f[3], bs.pdf, |cos|, flags}; returns the row count
+// per-vertex trace of one camera sample (path_tracing_iteration_t): one row of 26 floats per vertex that reaches the
+// continuation sample (4586): {bounce, surface, lobe, p[3], n[3], wo[3], beta[3] before the bounce, Lo[3] after this vertex's
+// direct lighting, bs.f[3], bs.pdf, |cos|, bsdf flags, which per-light BSDF-half estimates were non-black (bits), which
+// light-half estimates}; returns the row count.  The twin of kyhip_kat_li_trace.
 int kyo_trace_li(const ky_scene* cscene, const ky_render_params* p, int x, int y, int s, float* rows, int max_rows) {
     scene_t scene(*cscene);
     integrator_t integrator{&scene, p->integrator, p->max_path_depth, p->direct_sample};
@@ -1149,8 +1159,8 @@ int kyo_trace_li(const ky_scene* cscene, const ky_render_params* p, int x, int y
     sampler.start_sample(p->seed, (uint32_t)(y * p->width + x), (uint32_t)s);
     vec2_t cs = sampler.get_camera_sample({(float)x, (float)y});
     integrator.Li(generate_ray(scene.camera, cs), sampler, nullptr);
-    int n = std::min<int>((int)tr.size() / 24, max_rows);
-    std::memcpy(rows, tr.data(), (size_t)n * 24 * sizeof(float));
+    int n = std::min<int>((int)tr.size() / 26, max_rows);
+    std::memcpy(rows, tr.data(), (size_t)n * 26 * sizeof(float));
     return n;
 }
 

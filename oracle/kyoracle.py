@@ -81,7 +81,7 @@ def li(scene, params, x, y, s0, n):
 
 
 def trace_li(scene, params, x, y, s, max_rows=64):
-    rows = np.zeros((max_rows, 24), np.float32)
+    rows = np.zeros((max_rows, 26), np.float32)
     lib = load()
     lib.kyo_trace_li.argtypes = [A.SP, A.PP, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
     n = lib.kyo_trace_li(_sp(scene), C.byref(params), x, y, s, _f(rows), max_rows)

@@ -192,8 +192,10 @@ def test_li_per_sample_cornell(flag, strategy, A, api, O):
     params = api.make_params(64, 64, 128, direct_sample=strategy)
     pixels = [(32, 32), (5, 5), (21, 42), (44, 45), (60, 61), (32, 4), (18, 50), (46, 52)]
     bad, tot, sg, sc = li_agreement(api, O, scene, params, pixels)
-    assert bad <= 0.02 * tot, (bad, tot)
-    assert abs(sg - sc) <= 0.02 * max(sc, 1.0)
+    # measured (round 2, tools/measure_tolerances.py): 0 of 1024 samples differ in every one of the 24 cases, sums agree to 8e-6;
+    # what a mismatch would be is settled by tests/test_mismatch_gpu.py (a decision flip, never a continuous difference)
+    assert bad <= 0.002 * tot, (bad, tot)
+    assert abs(sg - sc) <= 1e-4 * max(sc, 1.0)
 
 
 @pytest.mark.parametrize("strategy", STRATEGIES)
@@ -203,8 +205,10 @@ def test_li_per_sample_veach(strategy, depth, A, api, O):
     params = api.make_params(96, 54, 128, direct_sample=strategy, max_path_depth=depth)
     pixels = [(48, 27), (5, 5), (30, 40), (70, 30), (48, 50), (20, 20), (80, 45), (60, 8)]
     bad, tot, sg, sc = li_agreement(api, O, scene, params, pixels)
-    assert bad <= 0.03 * tot, (bad, tot)
-    assert abs(sg - sc) <= 0.03 * max(sc, 1.0)
+    # measured: 9 of 1024 samples differ for the strategies with a light-sampling half (shadow rays at the sphere lights'
+    # self-occlusion threshold, quirk 1: tests/test_mismatch_gpu.py), 0 for the others; sums agree to 2e-3
+    assert bad <= 0.015 * tot, (bad, tot)
+    assert abs(sg - sc) <= 5e-3 * max(sc, 1.0)
 
 
 def test_debug_sampler_and_aov_integrators(A, api, O):
@@ -247,7 +251,10 @@ def test_film_parity(case, A, api, O):
     assert (~fin).sum() <= 2   # the reference's own inf * 0 at exactly-grazing mirror hits (DESIGN.md "Non-finite samples")
     assert np.isfinite(g).all() and g.min() >= 0 and g.max() <= 1
     e = rmse(g[fin], c[fin])
-    assert e < film_tolerance(spp), e
+    assert e < film_tolerance(spp), e          # the north star's tolerance
+    # measured at 1024 spp (round 2): cornell_area 2.2e-6, env 2.6e-5, point 4.9e-6, direction 4.4e-5, depth16 4.0e-6,
+    # direct_lighting 2.4e-6, veach 2.5e-4 -- kept within 4x of that
+    assert e < (1e-3 if case == "veach" else 2e-4), (case, e)
 
 
 def test_mis_strategies_are_linear(A, api):
@@ -511,7 +518,7 @@ def test_edge_cases(A, api, O):
         p = api.make_params(w, h, spp, max_path_depth=depth)
         g, c = api.render(sc, p), O.render(sc, p)
         assert g.shape == (h, w, 3) and np.isfinite(g).all()
-        assert rmse(g, c) < 0.05 / np.sqrt(spp) + 1e-6, (w, h, spp, depth, rmse(g, c))
+        assert rmse(g, c) < 1e-5, (w, h, spp, depth, rmse(g, c))     # measured <= 6e-7: no sample of these frames differs
     d0 = api.render(cornell, api.make_params(13, 7, 8, max_path_depth=0))
     assert set(np.unique(d0)) <= {0.0, 1.0}        # only the light's own surface shows (radiance 25, clamped)
 

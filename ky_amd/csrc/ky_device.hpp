@@ -69,6 +69,9 @@ __device__ __noinline__ void ky_clk_mark(int k) {
 #ifndef KY_ABL
 #define KY_ABL 0
 #endif
+#ifndef KY_SQ_ABL
+#define KY_SQ_ABL 0
+#endif
 
 namespace kyd {
 
@@ -158,8 +161,7 @@ struct DHit {  // what is needed once the nearest surface is known; gathered per
     int32_t kind;
     int32_t material;
     int32_t area_light;
-    int32_t pad[2];
-};  // 32 B
+};  // 24 B
 
 struct DMat {  // ky_material, gathered per lane from LDS
     float c0[3];        // lambert albedo | mirror R | glass R; plastic: Kd / P_diff, the Lambert lobe's albedo (2667)
@@ -188,6 +190,8 @@ struct DLight {  // light_t + the shape an area light samples; wave-uniform inde
     float n[3];           // stored normal
     int32_t n_carriers;   // surfaces whose surface_t::area_light is this light (sorted indices); -1: more than KY_MAX_CARRIERS
     int32_t carrier[4];
+    int32_t sampled_is_surface;   // the shape this light samples is also the shape of some surface of the scene (so it occludes)
+    int32_t pad_l[3];
     DSurf isect;          // traversal record of the sampled shape (pdf_direction re-intersects it, 1057-1061)
 };
 constexpr int KY_MAX_CARRIERS = 4;
@@ -219,7 +223,7 @@ struct DAar {
 struct DScene {
     int32_t n_surfaces, n_lights, n_materials, env_light;
     int32_t n_par, n_sph, n_gen, n_aar;   // n_aar = n_aar_axis[0] + [1] + [2]
-    int32_t n_aar_axis[3], pad_n;         // rectangles per axis plane (x, y, z), stored in that order
+    int32_t n_aar_axis[3], general;       // rectangles per axis plane (x, y, z), stored in that order; general: SceneRef::general
     float cam_position[3], cam_inv_w;
     float cam_front[3], cam_inv_h;
     float cam_right[3], pad0;
@@ -236,6 +240,18 @@ struct DScene {
     DLight light[KYHIP_MAX_LIGHTS];
 };
 
+// How device functions see the scene: the pointer plus one compile-time fact.  `general` = the scene may hold shapes that
+// need the reference's own formulations (quads that are not parallelograms, triangles, disks: full_shape_hit, ~150 VALU and
+// the register peak of the whole kernel).  The hot instantiation of the render kernel is launched only for scenes without
+// them (every scene ky ships) and passes `false`, which removes that code; everything else converts from the bare pointer.
+struct SceneRef {
+    const DScene* p;
+    bool general;
+    __device__ __forceinline__ SceneRef(const DScene* p_) : p(p_), general(true) {}
+    __device__ __forceinline__ SceneRef(const DScene* p_, bool general_) : p(p_), general(general_) {}
+    __device__ __forceinline__ const DScene* operator->() const { return p; }
+};
+
 struct LdsScene {  // the per-workgroup LDS copy of the tables that are indexed per lane
     DHit hit[KYHIP_MAX_SURFACES];
     DMat mat[KYHIP_MAX_MATERIALS];
@@ -245,7 +261,7 @@ struct LdsScene {  // the per-workgroup LDS copy of the tables that are indexed 
 KY_DEV f3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
 
 // cooperative copy global -> LDS, whole workgroup
-KY_DEV void stage_scene(LdsScene& L, const DScene* __restrict__ S) {
+KY_DEV void stage_scene(LdsScene& L, SceneRef S) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const uint32_t* src_h = reinterpret_cast<const uint32_t*>(S->hit);
     uint32_t* dst_h = reinterpret_cast<uint32_t*>(L.hit);
@@ -293,7 +309,7 @@ KY_DEV float sampler_next(Sampler& s) {
 // ---------------------------------------------------------------------------------------------
 // camera_t::generate_ray, ky.cpp:1884-1892
 // ---------------------------------------------------------------------------------------------
-KY_DEV void generate_ray(const DScene* __restrict__ S, float px, float py, f3& o, f3& d) {
+KY_DEV void generate_ray(SceneRef S, float px, float py, f3& o, f3& d) {
     const float sx = px * S->cam_inv_w - 0.5f;
     const float sy = 0.5f - py * S->cam_inv_h;
     const f3 dir = ld3(S->cam_front) + ld3(S->cam_right) * sx + ld3(S->cam_up) * sy;
@@ -375,7 +391,7 @@ KY_DEV bool aar_hit(const float4 q0, const float ov, f3 o, f3 d, f3 inv_d, float
 
 // the axis-aligned rectangles of one axis: records [first, first + n) of S->aar, whose sorted surface indices are the same
 template <int AXIS, bool NEAREST>
-KY_DEV void aar_scan(const DScene* __restrict__ S, int first, int n, f3 o, f3 d, f3 inv_d, float& tmax, int& best, bool& occ) {
+KY_DEV void aar_scan(SceneRef S, int first, int n, f3 o, f3 d, f3 inv_d, float& tmax, int& best, bool& occ) {
     if (n <= 0) return;
     float4 q0 = S->aar[first].q0;
     float ov = S->aar[first].q1.x;
@@ -408,17 +424,18 @@ KY_DEV bool sph_hit(const float4 c, f3 o, f3 d, float tmax, float& t_out) {
 }
 
 // one shape given as a generic record (KAT entry point, light shapes re-intersected by pdf_direction)
-KY_DEV bool surf_hit(const DSurf& S, const DShapeFull* __restrict__ full, f3 o, f3 d, float tmax, float& t_out) {
+// `general` false: the caller knows the record is a parallelogram or a sphere (SceneRef::general)
+KY_DEV bool surf_hit(const DSurf& S, const DShapeFull* __restrict__ full, f3 o, f3 d, float tmax, float& t_out, bool general = true) {
     if (S.kind == TK_PARALLELOGRAM)
         return par_hit(make_float4(S.f[0], S.f[1], S.f[2], S.f[3]), make_float4(S.f[4], S.f[5], S.f[6], S.f[7]), make_float4(S.f[8], S.f[9], S.f[10], S.f[11]), o, d, tmax, t_out);
-    if (S.kind == TK_SPHERE) return sph_hit(make_float4(S.f[0], S.f[1], S.f[2], S.f[3]), o, d, tmax, t_out);
+    if (!general || S.kind == TK_SPHERE) return sph_hit(make_float4(S.f[0], S.f[1], S.f[2], S.f[3]), o, d, tmax, t_out);
     return full_shape_hit(full[S.full], o, d, tmax, t_out);
 }
 
 // scene_t::intersect, ky.cpp:3172-3184: linear scan, tmax shrinks, first of equals wins.  Returns the SORTED surface index.
 // The record of surface i+1 is fetched (scalar loads) while surface i is being tested, so the scalar-cache latency
 // overlaps the VALU work instead of being exposed once per surface.
-KY_DEV int trace_nearest(const DScene* __restrict__ S, f3 o, f3 d, float& tmax) {
+KY_DEV int trace_nearest(SceneRef S, f3 o, f3 d, float& tmax) {
     int best = -1;
     const int n_aar = S->n_aar, n_par = S->n_par, n_sph = S->n_sph, n_gen = S->n_gen;
     if (n_aar > 0) {
@@ -451,7 +468,7 @@ KY_DEV int trace_nearest(const DScene* __restrict__ S, f3 o, f3 d, float& tmax) 
             c = nc;
         }
     }
-    for (int i = 0; i < n_gen; ++i) {
+    for (int i = 0; S.general && i < n_gen; ++i) {
         float t;
         if (full_shape_hit(S->full[S->gen[i].full], o, d, tmax, t)) {
             tmax = t;
@@ -462,7 +479,7 @@ KY_DEV int trace_nearest(const DScene* __restrict__ S, f3 o, f3 d, float& tmax) 
 }
 
 // scene_t::occluded's traversal (3193-3195): any hit inside (eps, tmax) occludes.
-KY_DEV bool trace_any(const DScene* __restrict__ S, f3 o, f3 d, float tmax) {
+KY_DEV bool trace_any(SceneRef S, f3 o, f3 d, float tmax) {
     bool occ = false;
     const int n_aar = S->n_aar, n_par = S->n_par, n_sph = S->n_sph, n_gen = S->n_gen;
     float t;
@@ -490,7 +507,7 @@ KY_DEV bool trace_any(const DScene* __restrict__ S, f3 o, f3 d, float tmax) {
             c = nc;
         }
     }
-    for (int i = 0; i < n_gen; ++i) occ = occ || full_shape_hit(S->full[S->gen[i].full], o, d, tmax, t);
+    for (int i = 0; S.general && i < n_gen; ++i) occ = occ || full_shape_hit(S->full[S->gen[i].full], o, d, tmax, t);
     return occ;
 }
 
@@ -807,7 +824,7 @@ KY_DEV void shape_sample_direction(const DLight& L, f3 p, f3 p_normal, float u0,
 }
 
 // shape_t::pdf_direction (1055-1090) and sphere_t::pdf_direction (1503-1513)
-KY_DEV float shape_pdf_direction(const DLight& L, const DShapeFull* __restrict__ full, f3 p, f3 p_normal, f3 wi) {
+KY_DEV float shape_pdf_direction(const DLight& L, const DShapeFull* __restrict__ full, f3 p, f3 p_normal, f3 wi, bool general = true) {
     const f3 c = ld3(L.p1);
     const float dc2 = length_sq(p - c);
     if (L.shape_kind == KY_SHAPE_SPHERE && !(dc2 <= L.radius * L.radius)) {
@@ -818,7 +835,7 @@ KY_DEV float shape_pdf_direction(const DLight& L, const DShapeFull* __restrict__
     // base class: re-intersect the light's OWN shape with isect.spawn_ray(wi)
     const f3 o = offset_ray_origin(p, p_normal, wi);
     float t;
-    if (!surf_hit(L.isect, full, o, wi, K_INF, t)) return 0.f;
+    if (!surf_hit(L.isect, full, o, wi, K_INF, t, general)) return 0.f;
     const f3 hp = o + t * wi;
     f3 ln = ld3(L.n);
     if (L.shape_kind == KY_SHAPE_SPHERE) ln = normalize(hp - c);
@@ -876,8 +893,8 @@ KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0,
 }
 
 // light_t::pdf_Li x4 (2855, 2903, 2984, 3043)
-KY_DEV float light_pdf_Li(const DLight& L, const DShapeFull* __restrict__ full, f3 p, f3 p_normal, f3 wi) {
-    if (L.kind == KY_LIGHT_AREA) return shape_pdf_direction(L, full, p, p_normal, wi);
+KY_DEV float light_pdf_Li(const DLight& L, const DShapeFull* __restrict__ full, f3 p, f3 p_normal, f3 wi, bool general = true) {
+    if (L.kind == KY_LIGHT_AREA) return shape_pdf_direction(L, full, p, p_normal, wi, general);
     if (L.kind == KY_LIGHT_ENVIRONMENT) return env_pdf(wi.z);
     return 0;
 }
@@ -904,7 +921,7 @@ KY_DEV f3 surface_emission(const LdsScene& Lds, int surface, f3 normal, f3 wo) {
 // one ballot per query.  With more than KY_TRANSPOSE_MAX queries in the wave, or for scenes the fast path does not
 // cover (general quads / triangles / disks, environment lights, many carriers), the ordinary traversal runs instead.
 template <bool MIS>
-KY_DEV f3 estimate_by_bsdf(const DScene* __restrict__ S, const LdsScene& Lds, const Vertex& v, int li, float u0, float u1, bool active) {
+KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, int li, float u0, float u1, bool active) {
     const DLight& L = S->light[li];
     f3 Ld = mk3(0, 0, 0);
     if (L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION) return Ld;  // light.is_delta(), 3894 / 3977 (wave-uniform)
@@ -933,7 +950,7 @@ KY_DEV f3 estimate_by_bsdf(const DScene* __restrict__ S, const LdsScene& Lds, co
         int c = -1;
         for (int k = 0; k < L.n_carriers; ++k) {
             float t;
-            const bool ok = act & surf_hit(S->all[L.carrier[k]], S->full, o, bs.wi, t_l, t);
+            const bool ok = act & surf_hit(S->all[L.carrier[k]], S->full, o, bs.wi, t_l, t, S.general);
             t_l = ok ? t : t_l;
             c = ok ? L.carrier[k] : c;
         }
@@ -971,7 +988,7 @@ KY_DEV f3 estimate_by_bsdf(const DScene* __restrict__ S, const LdsScene& Lds, co
                 asm volatile("" : "+v"(idx));
                 const DSurf& mine = S->all[idx];   // per-lane record from L2: queries are rare, LDS is worth more as wave capacity
                 float t;
-                const bool ok = (lane < S->n_surfaces) && surf_hit(mine, S->full, qo, qd, qt, t);
+                const bool ok = (lane < S->n_surfaces) && surf_hit(mine, S->full, qo, qd, qt, t, S.general);
                 const bool any = __any(ok);
                 if (lane == src) blocked = any;
             }
@@ -999,7 +1016,7 @@ KY_DEV f3 estimate_by_bsdf(const DScene* __restrict__ S, const LdsScene& Lds, co
     }
     if (live && !is_black(Li)) {
         if (MIS) {
-            const float light_pdf = light_pdf_Li(L, S->full, v.position, v.normal, bs.wi);
+            const float light_pdf = light_pdf_Li(L, S->full, v.position, v.normal, bs.wi, S.general);
             if (light_pdf > 0) Ld = (f_cos * Li) * (2.f * rcp(bs.pdf + light_pdf));  // 4028
         } else {
             Ld = (f_cos * Li) * rcp(bs.pdf);  // 3924
@@ -1008,9 +1025,136 @@ KY_DEV f3 estimate_by_bsdf(const DScene* __restrict__ S, const LdsScene& Lds, co
     return Ld;
 }
 
+// ---------------------------------------------------------------------------------------------
+// deferred shadow rays (the lane engine's QUEUE instantiation, kyhip.hip)
+//
+// scene_t::occluded (3187-3201) is the most expensive step of the light-sampling estimators and the one with the fewest
+// lanes that need it: many light samples are dead before it (back side of the light, zero BSDF value -- a Phong lobe away
+// from its peak) or die on the sampled light's own shape (quirk 1).  Instead of tracing each light's shadow rays at once with
+// whatever lanes have one, a lane that has a live sample evaluates everything else first (BSDF value, MIS weight), pushes
+// {ray, contribution, destination pixel} on a per-wavefront stack in global memory, and goes on.  Whenever 64 rays have
+// piled up the wave traces them with all 64 lanes busy and adds the unoccluded contributions to their pixels' sums.
+// The stack is private to the wave (no synchronisation), SoA so that pushes and pops are coalesced dword accesses, and it
+// stays L2-resident (a few KB per wave are live at any time).  Contributions are added in 32.32 fixed point, so the image
+// does not depend on when a ray is resolved.
+// ---------------------------------------------------------------------------------------------
+constexpr int KY_SQ_FIELDS = 11;                              // origin 3, direction 3, tmax, contribution 3, tag
+constexpr int KY_SQ_CAP = 64 * (KYHIP_MAX_LIGHTS + 1);        // a turn pushes at most 64 rays per light on top of < 64 left over
+struct ShadowQueue {
+    float* base;   // this wave's block: KY_SQ_FIELDS rows of KY_SQ_CAP floats
+    int n;         // rays on the stack (wave-uniform)
+};
+// wave-uniform call
+KY_DEV void sq_push(ShadowQueue& q, bool push, f3 o, f3 d, float tmax, f3 c, unsigned tag) {
+    const unsigned long long m = __ballot(push);
+    if (!m) return;
+#if KY_SQ_ABL == 3
+    if (push && q.n > 100000) {
+#else
+    if (push) {
+#endif
+        const int slot = q.n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        float* p = q.base + slot;
+        p[0 * KY_SQ_CAP] = o.x; p[1 * KY_SQ_CAP] = o.y; p[2 * KY_SQ_CAP] = o.z;
+        p[3 * KY_SQ_CAP] = d.x; p[4 * KY_SQ_CAP] = d.y; p[5 * KY_SQ_CAP] = d.z;
+        p[6 * KY_SQ_CAP] = tmax;
+        p[7 * KY_SQ_CAP] = c.x; p[8 * KY_SQ_CAP] = c.y; p[9 * KY_SQ_CAP] = c.z;
+        p[10 * KY_SQ_CAP] = __uint_as_float(tag);
+    }
+    q.n += __popcll(m);
+}
+
+// light-sampling half with the occlusion test deferred: by_emitter_mis (4035-4074) in the order sample -> BSDF value ->
+// weight -> [sampled shape's own hit] -> push; the reference's order (occlusion before the BSDF value) gives the same sum
+// because every factor is computed from the same inputs and a zero factor zeroes the term either way.
+// Wave-uniform call.  `scale` = throughput x strategy weight x 1 / spp: what multiplies this estimate in the pixel's sum.
+KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, int li, float u0, float u1, bool active, f3 scale,
+                                         unsigned tag, ShadowQueue& q) {
+    const DLight& L = S->light[li];
+    bool push = false;
+    f3 o = mk3(0, 0, 0), dir = mk3(0, 0, 1), C = mk3(0, 0, 0);
+    float tmax = 0.f;
+    if (active) {
+        const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1);
+        if (!(is_black(ls.Li) || ls.pdf <= 0)) {
+            f3 f;
+            float bsdf_pdf;
+            bsdf_eval_pdf(v.bsdf, vertex_wo(v), to_local(vertex_frame(v), ls.wi), f, bsdf_pdf);
+            const f3 f_cos = f * fabsf(dot(ls.wi, v.normal));
+            if (!is_black(f_cos)) {
+                const bool delta_light = L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION;
+                const f3 Ld = delta_light ? (f_cos * ls.Li) * rcp(ls.pdf) : (f_cos * ls.Li) * (2.f * rcp(ls.pdf + bsdf_pdf));   // 4057 / 4070
+                C = Ld * scale;
+                // scene_t::occluded(isect, ls.position), 3187-3201: the ray
+                const f3 to = ls.position - v.position;
+                const float d2 = length_sq(to);
+                const float inv_d = rsq(d2);
+                dir = to * inv_d;
+                tmax = d2 * inv_d - 2e-3f;
+                o = offset_ray_origin(v.position, v.normal, dir);
+                push = !(C.x == 0.f && C.y == 0.f && C.z == 0.f);
+                // the sampled shape itself is the likeliest occluder (quirk 1): one test here saves the ray a full traversal
+                if (KY_SQ_ABL != 1 && push && L.kind == KY_LIGHT_AREA && L.sampled_is_surface) {
+                    float t;
+                    if (surf_hit(L.isect, S->full, o, dir, tmax, t, S.general)) push = false;
+                }
+            }
+        }
+    }
+    sq_push(q, push, o, dir, tmax, C, tag);
+}
+
+// what sq_resolve needs besides the queue: where contributions go
+struct SqSink {
+    const int* c_pix;               // LDS: the pixel every lane of the workgroup is working on (-1: none)
+    unsigned long long* c_def;      // LDS: [3][256] fixed-point sums of resolved contributions, per lane
+    unsigned long long* accum;      // global fixed-point accumulators of the shard
+    unsigned* flags;                // global NaN / inf flags of the shard
+};
+// Pops the top `k` (<= 64) rays, traces them (any hit occludes) and adds the unoccluded contributions to their pixels.
+// Wave-uniform call.
+KY_DEV void sq_resolve(SceneRef S, ShadowQueue& q, int k, const SqSink& sink) {
+    const int lane = (int)__lane_id();
+    q.n -= k;
+    if (lane < k) {
+#if KY_SQ_ABL == 2
+        const float* p = q.base + lane;    // measurement build: always the same (cached) slots
+#else
+        const float* p = q.base + q.n + lane;
+#endif
+        const f3 o = mk3(p[0 * KY_SQ_CAP], p[1 * KY_SQ_CAP], p[2 * KY_SQ_CAP]);
+        const f3 d = mk3(p[3 * KY_SQ_CAP], p[4 * KY_SQ_CAP], p[5 * KY_SQ_CAP]);
+        const float tmax = p[6 * KY_SQ_CAP];
+        if (!trace_any(S, o, d, tmax)) {
+            const float c[3] = {p[7 * KY_SQ_CAP], p[8 * KY_SQ_CAP], p[9 * KY_SQ_CAP]};
+            const unsigned tag = __float_as_uint(p[10 * KY_SQ_CAP]);
+            const int pix = (int)(tag >> 6), owner = (int)((threadIdx.x & ~63u) | (tag & 63u));
+            const bool local = sink.c_pix[owner] == pix;   // the lane that pushed the ray is still on that pixel: its LDS sum takes it
+            unsigned fl = 0;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float a = c[ch];
+                if (a != a) fl |= 1u << ch;
+                else if (a > 2.0e9f) fl |= 8u << ch;
+                else if (a < -2.0e9f) fl |= 64u << ch;
+                else if (a != 0.f) {
+#if KY_SQ_ABL == 4
+                    const unsigned long long fx = (unsigned long long)to_fixed32(a);
+#else
+                    const unsigned long long fx = (unsigned long long)__double2ll_rn((double)a * 4294967296.0);
+#endif
+                    if (local) atomicAdd(&sink.c_def[ch * 256 + owner], fx);
+                    else atomicAdd(&sink.accum[(size_t)pix * 3 + ch], fx);
+                }
+            }
+            if (fl) atomicOr(&sink.flags[pix], fl);
+        }
+    }
+}
+
 // light-sampling half: by_emitter (3933-3962, MIS=false) and by_emitter_mis (4035-4074, MIS=true)
 template <bool MIS>
-KY_DEV f3 estimate_by_emitter(const DScene* __restrict__ S, const LdsScene& Lds, const Vertex& v, int li, float u0, float u1) {
+KY_DEV f3 estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, int li, float u0, float u1) {
     const DLight& L = S->light[li];
     f3 Ld = mk3(0, 0, 0);
     KY_PROBE(3);
@@ -1060,9 +1204,11 @@ KY_DEV f3 estimate_by_emitter(const DScene* __restrict__ S, const LdsScene& Lds,
 // strategy, 3900) and accumulate the estimators.
 // `decisions` (KAT tracing only; a null constant everywhere else, which removes the code): bit li = the BSDF half of light li's
 // estimate was non-black, bit 16 + li = its light half.
+// `sq` (the QUEUE instantiation of the lane engine, strategy both_mis): the light-sampling halves are not returned but pushed on
+// the wave's shadow-ray stack with `scale` x 0.5 as their weight in the pixel's sum.
 template <bool DEBUG_SAMPLER>
-KY_DEV f3 sample_all_light(const DScene* __restrict__ S, const LdsScene& Lds, const Vertex& v, Sampler& smp, int strategy, bool active,
-                           unsigned* decisions = nullptr) {
+KY_DEV f3 sample_all_light(SceneRef S, const LdsScene& Lds, const Vertex& v, Sampler& smp, int strategy, bool active,
+                           unsigned* decisions = nullptr, ShadowQueue* sq = nullptr, f3 scale = f3{0, 0, 0}, unsigned tag = 0) {
     f3 Ld = mk3(0, 0, 0);
     const int nl = S->n_lights;
     for (int li = 0; li < nl; ++li) {
@@ -1074,10 +1220,10 @@ KY_DEV f3 sample_all_light(const DScene* __restrict__ S, const LdsScene& Lds, co
             const f3 Lb = estimate_by_bsdf<true>(S, Lds, v, li, ub0, ub1, active);   // draws nothing itself
             KY_CLK(4);
             f3 Ll = mk3(0, 0, 0);
-            if (active) {   // random_light is drawn here, after the BSDF half: same stream position, two registers fewer across it
-                ul0 = sampler_next<DEBUG_SAMPLER>(smp); ul1 = sampler_next<DEBUG_SAMPLER>(smp);
-                Ll = estimate_by_emitter<true>(S, Lds, v, li, ul0, ul1);
-            }
+            // random_light is drawn here, after the BSDF half: same stream position, two registers fewer across it
+            if (active) { ul0 = sampler_next<DEBUG_SAMPLER>(smp); ul1 = sampler_next<DEBUG_SAMPLER>(smp); }
+            if (sq) estimate_by_emitter_deferred(S, v, li, ul0, ul1, active, scale * 0.5f, tag, *sq);
+            else if (active) Ll = estimate_by_emitter<true>(S, Lds, v, li, ul0, ul1);
             Ld = Ld + (0.5f * Lb + 0.5f * Ll);
             if (decisions && li < 16) *decisions |= (is_black(Lb) ? 0u : 1u << li) | (is_black(Ll) ? 0u : 1u << (16 + li));
             continue;
@@ -1127,7 +1273,7 @@ struct RenderConst {  // wave-uniform launch constants
 };
 
 template <bool DEBUG_SAMPLER>
-KY_DEV void path_begin(PathState& ps, const DScene* __restrict__ S, uint32_t pixel_key, int x, int y, int sample) {
+KY_DEV void path_begin(PathState& ps, SceneRef S, uint32_t pixel_key, int x, int y, int sample) {
     sampler_start(ps.smp, pixel_key, (uint32_t)sample);
     // get_camera_sample, 943-946 / 971-974
     const float u0 = sampler_next<DEBUG_SAMPLER>(ps.smp), u1 = sampler_next<DEBUG_SAMPLER>(ps.smp);
@@ -1141,7 +1287,7 @@ KY_DEV void path_begin(PathState& ps, const DScene* __restrict__ S, uint32_t pix
 // First half of a path vertex: trace the current ray and account for what the hit (or miss) itself contributes.
 // Returns false when the path has ended (radiance complete in ps.Lo); true when `v` holds a vertex to shade.
 template <bool DEBUG_SAMPLER>
-KY_DEV bool path_intersect(PathState& ps, Vertex& v, const DScene* __restrict__ S, const LdsScene& Lds, const RenderConst& rc) {
+KY_DEV bool path_intersect(PathState& ps, Vertex& v, SceneRef S, const LdsScene& Lds, const RenderConst& rc) {
     float t = K_INF;
     KY_PROBE(0);
     const int hs = trace_nearest(S, ps.o, ps.d, t);  // scene->intersect, 4542
@@ -1194,8 +1340,8 @@ struct VertexTrace {
 
 // `tr` is a null constant everywhere but in the trace KAT kernel, which removes the tracing code.
 template <bool DEBUG_SAMPLER>
-KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, const LdsScene& Lds, const RenderConst& rc, bool active,
-                       int lobe = -1, VertexTrace* tr = nullptr) {
+KY_DEV bool path_shade(PathState& ps, Vertex& v, SceneRef S, const LdsScene& Lds, const RenderConst& rc, bool active,
+                       int lobe = -1, VertexTrace* tr = nullptr, ShadowQueue* sq = nullptr, unsigned tag = 0) {
     if (active) {
         // material->scattering(isect) for the nearest hit (3083); only plastic draws a lobe number (2663).
         // lobe >= 0: the caller has already made that draw (path_pick_lobe).
@@ -1232,7 +1378,7 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, const DScene* __restrict__ S, c
     KY_PROBE(6);
     unsigned decisions = 0;
     if (!simple) {  // simple_path_tracing_recursion_t samples the BSDF only
-        const f3 Ld = sample_all_light<DEBUG_SAMPLER>(S, Lds, v, ps.smp, rc.strategy, nee, tr ? &decisions : nullptr);  // 4575 / 4337 / 4458
+        const f3 Ld = sample_all_light<DEBUG_SAMPLER>(S, Lds, v, ps.smp, rc.strategy, nee, tr ? &decisions : nullptr, sq, ps.beta * rc.inv_spp, tag);  // 4575 / 4337 / 4458
         if (nee) ps.Lo = ps.Lo + ps.beta * Ld;
     }
     KY_CLK(8);

@@ -212,7 +212,7 @@ KY_DEV unsigned qe_take_units(QeLds& W, int lane, unsigned n, unsigned* __restri
 // The reference tests occlusion first and evaluates the BSDF only for unoccluded samples; evaluating first drops the shadow
 // rays of samples whose f*cos is black (their Ld is 0 either way).
 template <bool MIS>
-KY_DEV bool emitter_sample(const DScene* __restrict__ S, const Vertex& v, int li, float u0, float u1, f3& dir, float& tmax, f3& Ld) {
+KY_DEV bool emitter_sample(SceneRef S, const Vertex& v, int li, float u0, float u1, f3& dir, float& tmax, f3& Ld) {
     const DLight& L = S->light[li];
     const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1);
     const bool dead = is_black(ls.Li) || (MIS ? (ls.pdf <= 0) : (ls.pdf == 0));
@@ -236,7 +236,7 @@ KY_DEV bool emitter_sample(const DScene* __restrict__ S, const Vertex& v, int li
 // One light of sample_all_light (3834-3872).  Wave-uniform call.  L_now: what the light adds right away (the BSDF-sampling
 // estimator); pending / dir / tmax / L_pending: the light-sampling estimator's shadow ray and its value.
 template <bool DEBUG_SAMPLER>
-KY_DEV void nee_one_light(const DScene* __restrict__ S, const LdsScene& Lds, const Vertex& v, Sampler& smp, int strategy, int li, bool active,
+KY_DEV void nee_one_light(SceneRef S, const LdsScene& Lds, const Vertex& v, Sampler& smp, int strategy, int li, bool active,
                           f3& L_now, bool& pending, f3& dir, float& tmax, f3& L_pending) {
     L_now = mk3(0, 0, 0);
     L_pending = mk3(0, 0, 0);

@@ -71,6 +71,7 @@ static int fail(int code, const char* fmt, ...) {
 #define KY_TAIL_SAMPLES 256
 #endif
 constexpr int KY_CHUNK = KY_CHUNK_BIG;
+static_assert(KY_CHUNK_BIG <= 127, "the lane's sample cursor keeps the chunk's remaining samples in 7 bits");
 constexpr int KY_CHUNK_SMALL = 8;
 constexpr int KY_TAIL = KY_TAIL_SAMPLES;
 #ifndef KY_RING_SLOTS
@@ -93,7 +94,7 @@ struct ShardConst {
 static bool valid_params(const ky_render_params* p) {
     if (!p) return false;
     if (p->width <= 0 || p->height <= 0 || p->samples_per_pixel <= 0 || p->max_path_depth < 0 || p->max_path_depth > 250) return false;
-    if (p->width > 32767 || p->height > 32767) return false;
+    if (p->width > 32767 || p->height > 32767 || p->samples_per_pixel > (1 << 24)) return false;   // packed fields: x | y << 16, sample << 7
     if (p->tile_w <= 0 || p->tile_h <= 0 || (p->tile_w % 8) || (p->tile_h % 8)) return false;
     if (p->tile_first < 0 || p->tile_step <= 0) return false;
     switch (p->integrator) {
@@ -157,6 +158,9 @@ static ShardConst make_shard(const ky_render_params* p) {
 #ifndef KY_WAVES_PER_EU
 #define KY_WAVES_PER_EU 6           // the hot instantiation <false, both_mis>: 80 VGPRs
 #endif
+#ifndef KY_WAVES_PER_EU_QUEUE
+#define KY_WAVES_PER_EU_QUEUE 6     // the instantiation with deferred shadow rays
+#endif
 #ifndef KY_WAVES_PER_EU_GENERIC
 #define KY_WAVES_PER_EU_GENERIC 5   // strategy / integrator read at run time: more code alive at once, 96 VGPRs measured best
 #endif
@@ -166,16 +170,22 @@ struct ItemSlot {  // one fetched work item, decoded once (wave-uniform) and rea
 };
 
 // STRATEGY >= 0 fixes direct_sample_enum at compile time (prunes the other estimators); -1 reads rc.strategy.
-template <bool DEBUG_SAMPLER, int STRATEGY>
-__global__ __launch_bounds__(256, STRATEGY >= 0 ? KY_WAVES_PER_EU : KY_WAVES_PER_EU_GENERIC) void render_kernel(const DScene* __restrict__ S, RenderConst rc, ShardConst sh,
+// QUEUE (with STRATEGY = both_mis): the light-sampling halves' shadow rays are deferred to the wave's stack `queue_mem`
+// (ky_device.hpp, "deferred shadow rays") and traced 64 at a time.
+// GENERAL: the scene may hold quads that are not parallelograms, triangles or disks (SceneRef::general); no shipped scene does.
+template <bool DEBUG_SAMPLER, int STRATEGY, bool QUEUE = false, bool GENERAL = false>
+__global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? KY_WAVES_PER_EU_QUEUE : KY_WAVES_PER_EU) : KY_WAVES_PER_EU_GENERIC) void render_kernel(const DScene* __restrict__ S_, RenderConst rc, ShardConst sh,
                                                                      unsigned* __restrict__ counter, unsigned long long* __restrict__ accum,
-                                                                     unsigned* __restrict__ flags) {
+                                                                     unsigned* __restrict__ flags, float* __restrict__ queue_mem) {
+    static_assert(!QUEUE || STRATEGY == KY_DIRECT_BOTH_MIS, "the deferred shadow rays are built into the both_mis instantiation");
+    const SceneRef S{S_, GENERAL};
     __shared__ LdsScene Lds;
     __shared__ ItemSlot ring[4][KY_RING];
     // the lane's pixel chunk (touched when a path starts or ends, not while a vertex is shaded) lives in LDS, not in registers
     __shared__ float c_lsum[3][256];
-    __shared__ int c_xy[256], c_pix[256], c_s[256], c_s_end[256];
+    __shared__ int c_xy[256], c_pix[256], c_se[256];   // c_se = next sample << 7 | samples left in the chunk
     __shared__ uint32_t c_key[256];
+    __shared__ unsigned long long c_def[QUEUE ? 3 * 256 : 1];   // QUEUE: fixed-point sums of the lane's resolved shadow rays
     const int tid = threadIdx.x;
     stage_scene(Lds, S);
     if (STRATEGY >= 0) { rc.strategy = STRATEGY; rc.integrator = KY_INTEGRATOR_PATH_TRACING_ITERATION; }  // the hot instantiation
@@ -192,6 +202,13 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? KY_WAVES_PER_EU : KY_WAVES_PER
     bool exhausted = false;   // the global counter ran past n_items
     // per lane: the pixel chunk being worked on
     c_lsum[0][tid] = 0.f; c_lsum[1][tid] = 0.f; c_lsum[2][tid] = 0.f;
+    c_pix[tid] = -1;
+    ShadowQueue sq{nullptr, 0};
+    const SqSink sink{c_pix, c_def, accum, flags};
+    if (QUEUE) {
+        c_def[tid] = 0; c_def[256 + tid] = 0; c_def[512 + tid] = 0;
+        sq.base = queue_mem + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * (KY_SQ_FIELDS * KY_SQ_CAP);
+    }
     bool open = false;        // the chunk has samples left to start (s < s_end)
     bool has_item = false, done = false, alive = false;
     PathState ps;
@@ -199,6 +216,9 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? KY_WAVES_PER_EU : KY_WAVES_PER
     KY_CLK(-1);
     for (;;) {
         KY_CLK(9);   // continuation sampling, roulette, loop overhead
+        if (QUEUE) {  // enough deferred shadow rays for a full wavefront: trace them now (wave-uniform)
+            while (sq.n >= 64) sq_resolve(S, sq, 64, sink);
+        }
         // ---- (1) lanes whose pixel chunk is finished flush it and take the next (item, pixel) pair of the wave's pool.
         // A lane is NOT tied to one pixel position: whichever lane is free takes the next pixel, so lanes never wait
         // for each other and the wave drains within one chunk of the end of the queue.
@@ -209,14 +229,18 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? KY_WAVES_PER_EU : KY_WAVES_PER
                 const float v[3] = {c_lsum[0][tid], c_lsum[1][tid], c_lsum[2][tid]};
                 const int pix = c_pix[tid];
                 c_lsum[0][tid] = 0.f; c_lsum[1][tid] = 0.f; c_lsum[2][tid] = 0.f;
+                c_pix[tid] = -1;   // rays of this chunk that are still on the stack go to the global accumulator directly
                 unsigned fl = 0;
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     const float a = v[ch];
+                    unsigned long long fx = 0;
+                    if (QUEUE) { fx = c_def[ch * 256 + tid]; c_def[ch * 256 + tid] = 0; }
                     if (a != a) fl |= 1u << ch;               // NaN
                     else if (a > 2.0e9f) fl |= 8u << ch;      // +inf (or beyond the accumulator's range)
                     else if (a < -2.0e9f) fl |= 64u << ch;    // -inf
-                    else if (a != 0.f) atomicAdd(&accum[(size_t)pix * 3 + ch], (unsigned long long)__double2ll_rn((double)a * KY_FIX_SCALE));
+                    else if (a != 0.f) fx += (unsigned long long)__double2ll_rn((double)a * KY_FIX_SCALE);
+                    if (fx != 0) atomicAdd(&accum[(size_t)pix * 3 + ch], fx);
                 }
                 if (fl) atomicOr(&flags[pix], fl);
                 has_item = false;
@@ -257,8 +281,7 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? KY_WAVES_PER_EU : KY_WAVES_PER
                     c_xy[tid] = x | (y << 16);
                     c_pix[tid] = it.pix0 + py * sh.tile_w + px;
                     c_key[tid] = sampler_pixel_key(rc.seed, (uint32_t)(y * rc.width + x));
-                    c_s[tid] = it.s_begin;
-                    c_s_end[tid] = it.s_end;
+                    c_se[tid] = (it.s_begin << 7) | (it.s_end - it.s_begin);
                     open = in_range && it.s_begin < it.s_end;
                     has_item = in_range;
                 } else {
@@ -277,10 +300,10 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? KY_WAVES_PER_EU : KY_WAVES_PER
         bool have_vertex = false;
         for (int attempt = 0;; ++attempt) {
             if (!alive && !done && open) {  // next camera sample of this lane's pixel, 3712-3715
-                const int xy = c_xy[tid], s = c_s[tid];
-                path_begin<DEBUG_SAMPLER>(ps, S, c_key[tid], xy & 0xffff, xy >> 16, s);
-                c_s[tid] = s + 1;
-                open = s + 1 < c_s_end[tid];
+                const int xy = c_xy[tid], se = c_se[tid];
+                path_begin<DEBUG_SAMPLER>(ps, S, c_key[tid], xy & 0xffff, xy >> 16, se >> 7);
+                c_se[tid] = se + 127;             // next sample + 1, samples left - 1
+                open = (se & 127) > 1;
                 alive = true;
             }
             const bool tracing = alive && !have_vertex;
@@ -304,14 +327,19 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? KY_WAVES_PER_EU : KY_WAVES_PER
             if (__all(done)) break;
             continue;  // lanes are between items: (1) serves them on the next turn
         }
+        unsigned tag = 0;
+        if (QUEUE) tag = ((unsigned)c_pix[tid] << 6) | (unsigned)lane;
         // ---- (3) shade the vertex: direct lighting, continuation ----
         {
-            const bool cont = path_shade<DEBUG_SAMPLER>(ps, v, S, Lds, rc, have_vertex);  // wave-uniform call
+            const bool cont = path_shade<DEBUG_SAMPLER>(ps, v, S, Lds, rc, have_vertex, -1, nullptr, QUEUE ? &sq : nullptr, tag);  // wave-uniform call
             if (have_vertex && !cont) {
                 c_lsum[0][tid] += ps.Lo.x * rc.inv_spp; c_lsum[1][tid] += ps.Lo.y * rc.inv_spp; c_lsum[2][tid] += ps.Lo.z * rc.inv_spp;
                 alive = false;
             }
         }
+    }
+    if (QUEUE) {  // what is left on the stack: the lanes have flushed, so these go to the global accumulators
+        while (sq.n > 0) sq_resolve(S, sq, sq.n < 64 ? sq.n : 64, sink);
     }
     KY_CLK(-2);
 }
@@ -697,6 +725,9 @@ static int pack_scene(const ky_scene* in, DScene* out) {
                 cp3(d.p1, sh.p[0]);
             }
             pack_shape(sh, KYHIP_MAX_SURFACES + i, &d.isect, &out->full[KYHIP_MAX_SURFACES + i]);
+            if (d.isect.kind != TK_PARALLELOGRAM && d.isect.kind != TK_SPHERE) out->general = 1;   // a quad / triangle / disk light
+            d.sampled_is_surface = 0;
+            for (int j2 = 0; j2 < in->surface_count; ++j2) d.sampled_is_surface |= in->surfaces[j2].shape == l.shape;
             // the surfaces that carry this light (surface_t::area_light == &light, 3994), in sorted order
             d.n_carriers = 0;
             for (int j2 = 0; j2 < out->n_surfaces; ++j2) {
@@ -706,7 +737,22 @@ static int pack_scene(const ky_scene* in, DScene* out) {
             }
         }
     }
+    if (out->n_gen > 0) out->general = 1;
     return KY_OK;
+}
+
+// Deferred shadow rays (render_kernel<.., QUEUE>) are used for scenes with at least KY_SQ_MIN_LIGHTS lights; the environment
+// variable KYHIP_SHADOW_QUEUE = 0 / 1 switches them off / on for every scene (A/B measurements).
+#ifndef KY_SQ_MIN_LIGHTS
+#define KY_SQ_MIN_LIGHTS 2
+#endif
+static bool shadow_queue_wanted(int light_count) {
+    static int forced = -2;
+    if (forced == -2) {
+        const char* e = std::getenv("KYHIP_SHADOW_QUEUE");
+        forced = e ? (std::atoi(e) != 0 ? 1 : 0) : -1;
+    }
+    return forced >= 0 ? forced == 1 : light_count >= KY_SQ_MIN_LIGHTS;
 }
 
 // which render kernel runs path_tracing_iteration_t: the lane engine (render_kernel, default) or the queue engine (render_kernel_q)
@@ -748,8 +794,9 @@ struct DeviceCtx {
     bool busy_valid = false, timing_valid = false;
     hipStream_t last_stream = nullptr;
     hipStream_t stream = nullptr;   // the library's own stream on this device (kyhip_render_multi)
-    int blocks_per_cu[3] = {0, 0, 0};
+    int blocks_per_cu[4] = {0, 0, 0, 0};   // render_kernel <false, both_mis>, <false, -1>, <true, -1>, <false, both_mis, QUEUE>
     int q_blocks_per_cu[3] = {0, 0, 0};
+    float* d_shadow_queue = nullptr;       // the wavefronts' shadow-ray stacks (QUEUE instantiation), allocated on first use
     bool scene_valid = false;
 };
 static std::mutex g_ctx_mutex;                          // guards g_ctx itself (creation), never held while enqueueing
@@ -772,6 +819,7 @@ static int create_ctx(int device, DeviceCtx& c) {
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[0], render_kernel<false, KY_DIRECT_BOTH_MIS>, 256, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[1], render_kernel<false, -1>, 256, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[2], render_kernel<true, -1>, 256, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[3], (render_kernel<false, KY_DIRECT_BOTH_MIS, true>), 256, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.q_blocks_per_cu[0], render_kernel_q<false, KY_DIRECT_BOTH_MIS>, QE_THREADS, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.q_blocks_per_cu[1], render_kernel_q<false, -1>, QE_THREADS, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.q_blocks_per_cu[2], render_kernel_q<true, -1>, QE_THREADS, 0));
@@ -952,7 +1000,18 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
     HIP_TRY(hipMemsetAsync(ws, 0, need, stream));
     HIP_TRY(hipMemsetAsync(c->d_counter, 0, sizeof(unsigned), stream));
 
-    const int variant = dbg ? 2 : (p->direct_sample == KY_DIRECT_BOTH_MIS && p->integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION ? 0 : 1);
+    // c->h_scene is the packed scene upload_scene has just compared / uploaded.  Scenes of parallelograms and spheres (every scene
+    // ky ships) run on instantiations without the general-shape code; the both_mis strategy has its own instantiation among those.
+    const bool general = c->h_scene->general != 0;
+    int variant = dbg ? 2 : (p->direct_sample == KY_DIRECT_BOTH_MIS && p->integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION && !general ? 0 : 1);
+    // deferred shadow rays pay when a vertex has several light samples to resolve (ky_device.hpp); KYHIP_SHADOW_QUEUE=0 / 1 forces
+    if (variant == 0 && current_engine() == KY_ENGINE_LANE && sh.n_pix < (1 << 26) && shadow_queue_wanted(scene->light_count)) {
+        variant = 3;
+        if (!c->d_shadow_queue) {
+            const int per_cu = c->blocks_per_cu[3] > 0 ? c->blocks_per_cu[3] : 1;
+            HIP_TRY(hipMalloc(&c->d_shadow_queue, (size_t)c->cus * per_cu * 4 * KY_SQ_FIELDS * KY_SQ_CAP * sizeof(float)));
+        }
+    }
     HIP_TRY(hipEventRecord(c->ev0, stream));
     // the queue engine implements path_tracing_iteration_t; every other integrator runs on the lane engine
     if (current_engine() == KY_ENGINE_QUEUE && p->integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION) {
@@ -970,9 +1029,13 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
         const unsigned need_blocks = sh.n_items / 4 + 1;
         if (grid > need_blocks) grid = need_blocks;
         if (grid < 1) grid = 1;
-        if (variant == 0) hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_BOTH_MIS>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags);
-        else if (variant == 1) hipLaunchKernelGGL((render_kernel<false, -1>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags);
-        else hipLaunchKernelGGL((render_kernel<true, -1>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags);
+        float* const no_queue = nullptr;
+        if (variant == 0) hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_BOTH_MIS>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);
+        else if (variant == 1 && !general) hipLaunchKernelGGL((render_kernel<false, -1>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);
+        else if (variant == 1) hipLaunchKernelGGL((render_kernel<false, -1, false, true>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);
+        else if (variant == 2 && !general) hipLaunchKernelGGL((render_kernel<true, -1>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);
+        else if (variant == 2) hipLaunchKernelGGL((render_kernel<true, -1, false, true>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);
+        else hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_BOTH_MIS, true>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, c->d_shadow_queue);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, stream));

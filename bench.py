@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--depth", type=int, default=0)
+    ap.add_argument("--direct-sample", type=int, default=A.DIRECT_BOTH_MIS, choices=[0, 4, 8, 16, 32, 48],
+                    help="direct_sample_enum_t of the path integrator frames (profiling the run-time-dispatched kernel; the metric's configs use 48)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
@@ -77,17 +79,17 @@ def workload(args):
     """-> (frames, film (height, width), name)"""
     if args.workload == "cornell":
         W, H, spp, depth = args.width or 1024, args.height or 768, args.spp or 1024, args.depth or 5
-        frames = [Frame("cornell", api.cornell_box_scene(A.CB_DEFAULT_SCENE, W, H), api.make_params(W, H, spp, max_path_depth=depth), ITER["cornell"])]
+        frames = [Frame("cornell", api.cornell_box_scene(A.CB_DEFAULT_SCENE, W, H), api.make_params(W, H, spp, max_path_depth=depth, direct_sample=args.direct_sample), ITER["cornell"])]
         name = "BASELINE configs[1]: ky Cornell box (both_small_spheres|light_area) %dx%d, %d spp, path_tracing_iteration d%d both_mis" % (W, H, spp, depth)
         return frames, (H, W), name
     if args.workload == "veach":
         W, H, spp, depth = args.width or 1280, args.height or 720, args.spp or 4096, args.depth or 5
-        frames = [Frame("veach", api.mis_scene(W, H), api.make_params(W, H, spp, max_path_depth=depth), ITER["veach"])]
+        frames = [Frame("veach", api.mis_scene(W, H), api.make_params(W, H, spp, max_path_depth=depth, direct_sample=args.direct_sample), ITER["veach"])]
         name = "BASELINE configs[2]: ky Veach MIS scene (create_mis_scene) %dx%d, %d spp, path_tracing_iteration d%d both_mis" % (W, H, spp, depth)
         return frames, (H, W), name
     if args.workload == "stress":
         W, H, spp, depth = args.width or 4096, args.height or 4096, args.spp or 16384, args.depth or 16
-        frames = [Frame("cornell_d16", api.cornell_box_scene(A.CB_DEFAULT_SCENE, W, H), api.make_params(W, H, spp, max_path_depth=depth), ITER["cornell_d16"])]
+        frames = [Frame("cornell_d16", api.cornell_box_scene(A.CB_DEFAULT_SCENE, W, H), api.make_params(W, H, spp, max_path_depth=depth, direct_sample=args.direct_sample), ITER["cornell_d16"])]
         name = "BASELINE configs[4]: stress, ky Cornell box %dx%d, %d spp, path_tracing_iteration d%d both_mis" % (W, H, spp, depth)
         return frames, (H, W), name
     # batch: render_multiple_scene (ky.cpp:4819-4876) at production size, one film_grid_t(2, 3, res, res)
@@ -96,10 +98,10 @@ def workload(args):
     lights = (("point", A.CB_LIGHT_POINT), ("direction", A.CB_LIGHT_DIRECTION), ("area", A.CB_LIGHT_AREA), ("environment", A.CB_LIGHT_ENVIRONMENT))
     for cell, (lname, flag) in enumerate(lights):
         it = ITER["cornell"] if lname == "area" else ITER["cornell_other_lights"]
-        frames.append(Frame("cornell_" + lname, api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | flag, res, res), api.make_params(res, res, spp, max_path_depth=depth),
+        frames.append(Frame("cornell_" + lname, api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | flag, res, res), api.make_params(res, res, spp, max_path_depth=depth, direct_sample=args.direct_sample),
                             it, ((cell % 3) * res, (cell // 3) * res)))
     veach = api.mis_scene(res, res)
-    frames.append(Frame("veach", veach, api.make_params(res, res, spp, max_path_depth=depth), ITER["veach_square"], (res, res)))
+    frames.append(Frame("veach", veach, api.make_params(res, res, spp, max_path_depth=depth, direct_sample=args.direct_sample), ITER["veach_square"], (res, res)))
     frames.append(Frame("veach_normal_aov", veach, api.make_params(res, res, 1, integrator=A.INTEGRATOR_NORMAL, sampler=A.SAMPLER_DEBUG), ITER["aov"], (2 * res, res)))
     name = ("BASELINE configs[3]: render_multiple_scene batch, 4 Cornell light variants + Veach (path_tracing_iteration d%d both_mis) + first-hit AOV, "
             "each %dx%d at %d spp, film_grid 2x3" % (depth, res, res, spp))
@@ -113,6 +115,15 @@ def cpu_baseline(frames, gpu_render, target_seconds):
     GPU's render of the very same sample against it."""
     from oracle import kyoracle as O
     threads = O.max_threads()
+    # what the host really grants this process: the pool's boxes differ (some confine a job to a few cores' worth of CPU time
+    # whatever the thread count) -- reported next to the thread count so that the baseline can be read
+    granted = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            granted = min(granted, max(1, int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
 
     def sample_params(fr, spp):
         p = A.RenderParams.from_buffer_copy(fr.params)
@@ -153,7 +164,7 @@ def cpu_baseline(frames, gpu_render, target_seconds):
         se += float((d * d).sum()); cnt += d.size; bad += int((~fin).sum())
     spps = sorted({p.samples_per_pixel for p, _ in films})
     return {
-        "value": n / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+        "value": n / dt / 1e6, "unit": "Msamples/s", "cores": min(threads, granted), "kind": "port", "omp_threads": threads, "cpus_granted": granted,
         "sample": "%d frame(s) of the workload, every %d-th tile (interleaved over the picture), %s spp: %.3g samples, %.1f s of CPU work, OpenMP %d threads"
                   % (len(frames), films[0][0].tile_step, "/".join(map(str, spps)), n, dt, threads),
     }, {"rmse_gpu_vs_cpu": (se / max(cnt, 1)) ** 0.5, "rmse_spp": spps[-1], "rmse_excluded_nonfinite_pixels": bad}
@@ -261,7 +272,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": name, "frames": [fr.label for fr in frames], "width": p0.width, "height": p0.height, "spp": p0.samples_per_pixel,
-                       "max_path_depth": p0.max_path_depth, "direct_sample": "both_mis", "seed": p0.seed,
+                       "max_path_depth": p0.max_path_depth, "direct_sample": {0: "idle", 4: "bsdf", 8: "light", 16: "bsdf_mis", 32: "light_mis", 48: "both_mis"}[p0.direct_sample], "seed": p0.seed,
                        "tile": [p0.tile_w, p0.tile_h], "parallelism": "image tiles interleaved over %d GPU(s), one film-tile gather per frame" % world},
             # `achieved` / `peak` / `frac` follow the contract of SURVEY.md 8(d): ALGORITHMIC bytes of an HBM ray-pool tracer (128 B per
             # path iteration + 12 B of film per sample) over the measured kernel time, against the HBM peak.  The kernel built here

@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Builds profiles/valu.json and profiles/hbm_traffic.json from the committed rocprofv3 summaries of a round
+(tools/final_profiles.sh <prefix> on the GPU box, summaries copied to profiles/).
+
+usage: tools/make_valu_json.py <prefix, e.g. r02_c>
+
+What bench.py's `roofline.valu` reports, per kernel / workload, every figure recomputable from the named files:
+  wave_instr_per_sample   SQ_INSTS_VALU / camera samples of the launch
+  lane_occupancy          SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)
+  ns_per_valu_per_simd    kernel time * 1024 SIMDs / SQ_INSTS_VALU
+  issue_frac_2clk         against one wave64 VALU instruction per 2 clocks per SIMD at 2.4 GHz (the guide's figure)
+  issue_frac_ubench       against what profiles/<prefix>_valu_peak_ubench.txt measures at 6 waves per SIMD for this kernel's mix of plain
+                          and quarter-rate instructions (the ceiling this GPU actually reaches)
+  wait_frac / stall_frac  SQ_WAIT_ANY, SQ_WAIT_INST_ANY over SQ_WAVE_CYCLES
+  spill                   scratch bytes per lane of the dispatch, scratch loads / stores per launch, WRITE_SIZE
+"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "profiles")
+SAMPLES = {"cornell": 1024 * 768 * 1024, "veach": 1280 * 720 * 1024, "generic": 1024 * 768 * 1024}
+LABEL = {"cornell": "render_kernel<false,48> on BASELINE configs[1] (Cornell 1024x768x1024)",
+         "veach": "render_kernel<false,48,QUEUE> on configs[2]'s scene at 1024 spp (Veach 1280x720)",
+         "generic": "render_kernel<false,-1> (strategy read at run time) on configs[1]'s scene with direct_sample light_mis"}
+
+
+def counters(path):
+    out = {}
+    disp = None
+    ms = None
+    for line in open(path):
+        m = re.match(r".*render_kernel.*?\s(SQ_[A-Z_0-9]+|FETCH_SIZE|WRITE_SIZE)\s+(\d+)\s+([0-9.]+)\s*$", line)
+        if m:
+            out[m.group(1)] = float(m.group(3))
+        m = re.match(r"void render_kernel.*?\s+(\d+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s*$", line)
+        if m:
+            ms = float(m.group(3)) / 1e3
+        m = re.search(r"render_kernel dispatch: .*scratch=(\d+)", line)
+        if m:
+            disp = int(m.group(1))
+    return out, ms, disp
+
+
+def ubench(path):
+    """ns per wave-instruction per SIMD at 6 waves/SIMD for the instruction classes of valu_peak.hip"""
+    res = {}
+    for line in open(path):
+        m = re.match(r"(.+?)\s+waves/SIMD 6:.*\(([0-9.]+) ns\)", line)
+        if m:
+            res[m.group(1).strip()] = float(m.group(2))
+    return res
+
+
+def main():
+    prefix = sys.argv[1]
+    ub = ubench(os.path.join(PROF, prefix + "_valu_peak_ubench.txt"))
+    plain, trans = ub["v_fmac_f32_e32 (VOP2, 3 vgpr)"], ub["v_rcp_f32"]
+    valu, traffic = {}, None
+    for wl in ("cornell", "veach", "generic"):
+        base = os.path.join(PROF, "%s_%s_" % (prefix, wl))
+        issue, _, scratch = counters(base + "pmc_sq_issue.txt")
+        mix, _, _ = counters(base + "pmc_sq_mix.txt")
+        _, ms, _ = counters(base + "kernel_stats.txt")
+        fetch, _, _ = counters(base + "hbm_fetch_size.txt")
+        write, _, _ = counters(base + "hbm_write_size.txt")
+        n = SAMPLES[wl]
+        insts = issue["SQ_INSTS_VALU"]
+        f_trans = mix["SQ_INSTS_VALU_TRANS_F32"] / insts
+        ns = ms * 1e6 * 1024 / insts
+        ceiling = (1 - f_trans) * plain + f_trans * trans
+        fetch_b, write_b = fetch["FETCH_SIZE"] * 1024 * 2, write["WRITE_SIZE"] * 1024   # KiB; FETCH_SIZE x 2 per the guide's gfx950 note
+        valu[wl] = {
+            "kernel": LABEL[wl], "samples_per_launch": n, "kernel_ms": ms,
+            "wave_instr_per_sample": insts / n,
+            "lane_occupancy": mix["SQ_THREAD_CYCLES_VALU"] / (64 * issue["SQ_ACTIVE_INST_VALU"]),
+            "ns_per_valu_per_simd": ns,
+            "issue_frac_2clk": (2 / 2.4) / ns,
+            "ubench_ceiling_ns": ceiling, "issue_frac_ubench": ceiling / ns,
+            "quarter_rate_fraction": f_trans, "salu_per_valu": issue["SQ_INSTS_SALU"] / insts,
+            "wait_frac": issue["SQ_WAIT_ANY"] / issue["SQ_WAVE_CYCLES"], "stall_frac": issue["SQ_WAIT_INST_ANY"] / issue["SQ_WAVE_CYCLES"],
+            "spill": {"scratch_bytes_per_lane": scratch, "scratch_loads_per_launch": mix["SQ_INSTS_VMEM_RD"], "scratch_stores_per_launch": mix["SQ_INSTS_VMEM_WR"],
+                      "write_size_bytes_per_launch": write_b},
+            "hbm_bytes_per_launch": fetch_b + write_b,
+            "files": [os.path.basename(base) + s for s in ("kernel_stats.txt", "pmc_sq_issue.txt", "pmc_sq_mix.txt", "hbm_fetch_size.txt", "hbm_write_size.txt")]
+                     + [prefix + "_valu_peak_ubench.txt"],
+        }
+        if wl == "cornell":
+            traffic = {"_comment": "HBM traffic of ONE render_kernel launch of the bench workload from rocprofv3 --pmc (two separate passes; FETCH_SIZE / WRITE_SIZE are in "
+                                   "KiB; FETCH_SIZE doubled per /opt/skills/guides/MI355X_MICROARCH.md's gfx950 note, WRITE_SIZE as is).  The kernel keeps all path state in "
+                                   "registers and LDS: what reaches the memory side is the write-back of spilled registers, the fixed-point pixel atomics and the scene.",
+                       "workload": "cornell", "width": 1024, "height": 768, "spp": 1024, "samples_per_launch": n,
+                       "fetch_size_kib": fetch["FETCH_SIZE"], "write_size_kib": write["WRITE_SIZE"], "hbm_bytes_per_launch": fetch_b + write_b, "round": prefix}
+    with open(os.path.join(PROF, "valu.json"), "w") as fh:
+        json.dump(valu, fh, indent=1)
+    with open(os.path.join(PROF, "hbm_traffic.json"), "w") as fh:
+        json.dump(traffic, fh, indent=1)
+    for wl, v in valu.items():
+        print("%-8s %.1f VALU/sample  lanes %.3f  %.3f ns/instr/SIMD  issue %.2f of 2-clk, %.2f of ubench  wait %.2f stall %.2f  scratch %s B/lane  HBM %.2f GB/launch" % (
+            wl, v["wave_instr_per_sample"], v["lane_occupancy"], v["ns_per_valu_per_simd"], v["issue_frac_2clk"], v["issue_frac_ubench"], v["wait_frac"], v["stall_frac"],
+            v["spill"]["scratch_bytes_per_lane"], v["hbm_bytes_per_launch"] / 1e9))
+
+
+if __name__ == "__main__":
+    main()

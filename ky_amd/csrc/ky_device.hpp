@@ -171,7 +171,7 @@ struct DMat {  // ky_material, gathered per lane from LDS
     float exponent, p_diffuse, p_specular;
     int32_t exp_flags;  // bit 0: exponent is integral, bit 1: it is odd (sign of pow(negative, n))
     float cs[3];        // plastic: Ks / P_spec, the Phong lobe's colour (2665)
-    int32_t pad;
+    float inv_eta;      // glass: 1 / eta (`eta_i / eta_t` entering, 1977 / 2388: the same float division, done once on the host)
 };  // 64 B
 
 struct DLight {  // light_t + the shape an area light samples; wave-uniform index
@@ -566,22 +566,6 @@ KY_DEV int pick_lobe(const DMat& M, float lobe_random) {
 KY_DEV Bsdf make_bsdf_for_lobe(const DMat& M, int lobe) { return Bsdf{lobe, &M}; }
 KY_DEV Bsdf make_bsdf(const DMat& M, float lobe_random) { return Bsdf{pick_lobe(M, lobe_random), &M}; }
 
-// fresnel_dielectric, 1963-1996
-KY_DEV float fresnel_dielectric(float cos_theta_i, float eta_i, float eta_t) {
-    cos_theta_i = fminf(fmaxf(cos_theta_i, -1.f), 1.f);
-    if (!(cos_theta_i > 0.f)) {
-        const float tmp = eta_i; eta_i = eta_t; eta_t = tmp;
-        cos_theta_i = fabsf(cos_theta_i);
-    }
-    const float sin_theta_i = fsqrt(fmaxf(0.f, 1 - cos_theta_i * cos_theta_i));
-    const float sin_theta_t = eta_i * rcp(eta_t) * sin_theta_i;
-    if (sin_theta_t >= 1) return 1;
-    const float cos_theta_t = fsqrt(fmaxf(0.f, 1 - sin_theta_t * sin_theta_t));
-    const float r_para = ((eta_t * cos_theta_i) - (eta_i * cos_theta_t)) * rcp((eta_t * cos_theta_i) + (eta_i * cos_theta_t));
-    const float r_perp = ((eta_i * cos_theta_i) - (eta_t * cos_theta_t)) * rcp((eta_i * cos_theta_i) + (eta_t * cos_theta_t));
-    return (r_para * r_para + r_perp * r_perp) * 0.5f;
-}
-
 // std::pow(base, exponent) of the Phong lobe (2499): a negative base is legal for an integral exponent
 KY_DEV float phong_pow(float base, float exponent, int exp_flags) {
     const float m = pow_nonneg(fabsf(base), exponent);
@@ -632,18 +616,33 @@ KY_DEV void concentric_disk(float u0, float u1, float& px, float& py) {
 // The direction half of sample_ for the two non-delta lobes (their value and pdf are eval_ / pdf_ of that direction:
 // 2253-2254, 2526-2527), so that a caller that rarely needs the value can defer it (estimate_by_bsdf).
 KY_DEV f3 bsdf_sample_dir_nondelta(const Bsdf& B, f3 wo, float u0, float u1) {
-    if (B.lobe == LOBE_PHONG) {  // 2510-2524 + 2533-2543
-        const float ct = pow_nonneg(u1, rcp(B.m->exponent + 1.f));
-        const float st = fsqrt(1.f - ct * ct);
-        const f3 local = mk3(cos_rev(u0) * st, sin_rev(u0) * st, ct);   // phi = 2 pi u0
-        const Frame fr = make_frame(mk3(-wo.x, -wo.y, wo.z));           // frame_t(wr): wr is unit because wo is
-        f3 wi = to_world(fr, local);
+    // Both lobes place a point (rad cos, rad sin) on a circle and lift it: the cosine lobe by the concentric disk mapping (710-743), the
+    // Phong lobe by cos(theta) = u1^(1/(n+1)) around the mirror direction (2510-2524).  A wavefront holds vertices of both kinds, so the
+    // angle and the radius are computed per lobe and the two quarter-rate sin / cos are issued once for both.
+    const bool phong = B.lobe == LOBE_PHONG;
+    float ang, rad, ct = 0.f;
+    bool origin = false;
+    if (phong) {
+        ct = pow_nonneg(u1, rcp(B.m->exponent + 1.f));
+        rad = fsqrt(1.f - ct * ct);
+        ang = u0;                                                          // phi = 2 pi u0, in revolutions
+    } else {   // concentric_disk_sample, 710-733 (angles in revolutions: theta / 2 pi)
+        const float rx = 2.f * u0 - 1, ry = 2.f * u1 - 1;
+        const bool xmajor = fabsf(rx) > fabsf(ry);
+        rad = xmajor ? rx : ry;
+        const float ratio = (xmajor ? ry : rx) * rcp(rad);                 // 0/0 = NaN only when rx = ry = 0, handled below
+        ang = xmajor ? 0.125f * ratio : 0.25f - 0.125f * ratio;            // (pi/4) q, pi/2 - (pi/4) q
+        origin = (rx == 0 && ry == 0);
+    }
+    float px = cos_rev(ang) * rad, py = sin_rev(ang) * rad;
+    if (phong) {   // 2533-2543
+        const Frame fr = make_frame(mk3(-wo.x, -wo.y, wo.z));              // frame_t(wr): wr is unit because wo is
+        f3 wi = to_world(fr, mk3(px, py, ct));
         if (wo.z < 0) wi.z = -wi.z;
         return wi;
     }
-    // lambert: cosine_hemisphere_sample 737-743, flipped into wo's hemisphere (2247-2249)
-    float px, py;
-    concentric_disk(u0, u1, px, py);
+    // cosine_hemisphere_sample 737-743, flipped into wo's hemisphere (2247-2249)
+    if (origin) { px = 0.f; py = 0.f; }
     float z = fsqrt(fmaxf(0.f, 1 - px * px - py * py));
     if (wo.z < 0) z = -z;
     return mk3(px, py, z);
@@ -665,33 +664,36 @@ KY_DEV BsdfSample bsdf_sample_local(const Bsdf& B, f3 wo, float u0, float u1) {
         s.f = ld3(B.m->c0) * rcp(fabsf(s.wi.z));
         s.pdf = 1;
         s.flags = BSDF_REFLECTION | BSDF_SPECULAR;
-    } else if (B.lobe == LOBE_GLASS) {  // 2355-2412
+    } else if (B.lobe == LOBE_GLASS) {  // 2355-2412: fresnel_dielectric(wo.z, 1, eta) (1963-1996) and refract (1931-1957) in one pass --
+        // both start from the same cos(theta_i), sin^2(theta_i) and index ratio, and the Fresnel term's cos(theta_t) is the refracted
+        // direction's (the reference computes it twice, as sqrt(1 - (r sin)^2) and as sqrt(1 - r^2 sin^2))
         const float eta_t = B.m->eta;
-        const float reflect_percent = fresnel_dielectric(wo.z, 1.f, eta_t);
+        const bool into = wo.z > 0;
+        const float nz = into ? 1.f : -1.f;
+        const float ratio = into ? B.m->inv_eta : eta_t;                 // eta_i / eta_t seen from wo's side
+        const float ei = into ? 1.f : eta_t, et = into ? eta_t : 1.f;
+        const float cos_theta_i = fminf(fabsf(wo.z), 1.f);
+        const float sin_theta_i_sq = fmaxf(0.f, 1 - cos_theta_i * cos_theta_i);
+        const float sin_theta_t = ratio * fsqrt(sin_theta_i_sq);
+        const bool tir = sin_theta_t >= 1;
+        const float cos_theta_t = fsqrt(fmaxf(0.f, 1 - sin_theta_t * sin_theta_t));
+        const float r_para = ((et * cos_theta_i) - (ei * cos_theta_t)) * rcp((et * cos_theta_i) + (ei * cos_theta_t));
+        const float r_perp = ((ei * cos_theta_i) - (et * cos_theta_t)) * rcp((ei * cos_theta_i) + (et * cos_theta_t));
+        const float reflect_percent = tir ? 1.f : (r_para * r_para + r_perp * r_perp) * 0.5f;
         const float refract_percent = 1 - reflect_percent;
         if (u0 < reflect_percent) {
             s.wi = mk3(-wo.x, -wo.y, wo.z);
             s.pdf = reflect_percent;
             s.f = (ld3(B.m->c0) * reflect_percent) * rcp(fabsf(s.wi.z));
             s.flags = BSDF_REFLECTION | BSDF_SPECULAR;
-        } else {
-            const bool into = wo.z > 0;
-            const float nz = into ? 1.f : -1.f;
-            const float eta = into ? rcp(eta_t) : eta_t;
-            // refract(wo, (0,0,nz), eta), 1931-1957
-            const float cos_theta_i = nz * wo.z;
-            const float sin_theta_i_sq = fmaxf(0.f, 1 - cos_theta_i * cos_theta_i);
-            const float sin_theta_t_sq = eta * eta * sin_theta_i_sq;
-            if (!(sin_theta_t_sq >= 1)) {
-                const float cos_theta_t = fsqrt(1 - sin_theta_t_sq);
-                const float k = eta * cos_theta_i - cos_theta_t;
-                s.wi = mk3(eta * -wo.x, eta * -wo.y, eta * -wo.z + k * nz);
-                s.pdf = refract_percent;
-                s.f = (ld3(B.m->c1) * refract_percent) * rcp(fabsf(s.wi.z));
-                s.flags = BSDF_TRANSMISSION | BSDF_SPECULAR;
-            }
-            // else total internal reflection: f = 0, pdf = 0 (2407)
+        } else if (!tir) {   // (u0 >= 1 cannot happen: total internal reflection always takes the branch above)
+            const float k = ratio * cos_theta_i - cos_theta_t;
+            s.wi = mk3(ratio * -wo.x, ratio * -wo.y, ratio * -wo.z + k * nz);
+            s.pdf = refract_percent;
+            s.f = (ld3(B.m->c1) * refract_percent) * rcp(fabsf(s.wi.z));
+            s.flags = BSDF_TRANSMISSION | BSDF_SPECULAR;
         }
+        // else total internal reflection in the refraction branch: f = 0, pdf = 0 (2407) -- unreachable, kept for clarity
     } else {  // phong, 2510-2529
         s.wi = bsdf_sample_dir_nondelta(B, wo, u0, u1);
         bsdf_eval_pdf(B, wo, s.wi, s.f, s.pdf);

@@ -249,8 +249,10 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? KY_WAVES_PER_EU_QUEUE
             // fetch until the pool covers every requesting lane (at most two items: n_need <= 64), or the queue is empty.
             // Slot reuse: item fetched - KY_RING was handed out completely long ago (cursor >= (fetched - 2) * 64).
             while (!exhausted && cursor + n_need > fetched * 64) {
-                unsigned id = 0;
-                if (lane == 0) id = atomicAdd(counter, 1u);
+                // a wave's first item is its own index: the launch does not begin with every wavefront of the chip queueing at one
+                // counter (one word serves ~90 dequeues per microsecond); later items come from the counter, offset by the wave count
+                unsigned id = blockIdx.x * 4u + (threadIdx.x >> 6);
+                if (fetched > 0 && lane == 0) id = atomicAdd(counter, 1u) + gridDim.x * 4u;
                 id = __builtin_amdgcn_readfirstlane(id);
                 if (id >= sh.n_items) { exhausted = true; break; }
                 const int c = (int)(id / (unsigned)sh.n_blocks), b = (int)(id % (unsigned)sh.n_blocks);   // chunk-major

@@ -218,3 +218,24 @@ def test_gpu_film_to_bmp_with_odd_width(A, api, tmp_path):
         assert open(path, "rb").read() == fn(film), kind
     b = open(tmp_path / "odd.bmp", "rb").read()
     assert len(b) == 54 + 50 * 34 * 3 and int.from_bytes(b[2:6], "little") == 54 + 152 * 34
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's N > 1 path end to end (torch.distributed.run, two ranks, shards -> ONE gather -> one add kernel) on a single
+    GPU: KY_BENCH_ONE_GPU=1 puts both ranks on cuda:0 and runs the collective over gloo.  The film must be the one a single rank
+    renders (the JSON line carries its mean), and the line must keep the contract's fields."""
+    import json
+    import sys
+    env = dict(os.environ, KY_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+    args = ["--steps", "2", "--warmup", "1", "--workload", "batch", "--spp", "16", "--width", "256", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, cwd=tmp_path, check=True)
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(29700 + os.getpid() % 200), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args,
+                         capture_output=True, text=True, env=env, cwd=tmp_path, check=True)
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["scaling"] == "strong"
+    assert j1["film_mean"] == j2["film_mean"] and j1["film_mean"] > 0.01
+    for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in j2
+    assert j2["roofline"]["bound"] == "valu" and j2["roofline"]["contract_bound"] == "hbm" and len(j2["config"]["frames"]) == 6

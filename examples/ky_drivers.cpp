@@ -9,6 +9,9 @@
  *   ky_drivers direct_sample     render_direct_sample_enum (4779): 4 Cornell lights x 5 strategies, 4x5 grid
  *   ky_drivers multiple_scene    render_multiple_scene     (4819): 3 strategies x 4 Cornell lights, 3x4 grid
  *   ky_drivers mis               render_mis_scene          (4878): Veach x 6 strategies, 2x3 grid
+ *   ky_drivers lighting_enum [spp] [w] [h]  BASELINE.json configs[1]: the scene of the reference's (commented-out) render_lighting_enum
+ *                                (4907-4935: Cornell, both small spheres, area light) at 1024 x 768, 1024 spp, path_tracing_iteration d5
+ *                                both_mis; writes lighting_enum.bmp
  *   ky_drivers batch [spp] [res] BASELINE.json configs[3]: render_multiple_scene scaled up -- the four Cornell light variants
  *                                (both_mis), Veach (both_mis) and a first-hit AOV pass, each res x res (1024) at spp (2048),
  *                                into a film_grid_t(2, 3, res, res); writes batch.bmp
@@ -176,6 +179,19 @@ static void render_batch(int spp, int res) {
     film.store_image("batch");
 }
 
+// BASELINE.json configs[1]: the headline frame
+static void render_lighting_enum(int spp, int width, int height) {
+    film_t film(width, height);
+    scene_t scene = scene_t::create_cornell_box_scene(cornell_box_enum_t::both_small_spheres | cornell_box_enum_t::light_area, film.get_resolution());
+    std::unique_ptr<sampler_t> sampler = std::make_unique<random_sampler_t>(spp);
+    auto integrator = create_integrator(integrator_enum_t::path_tracing_iteration, 5, direct_sample_enum_t::both_mis);
+    use_devices(*integrator);
+    const double seconds = timing_seconds([&] { integrator->render(&scene, sampler.get(), &film); });
+    std::printf("lighting_enum: %dx%d, %d spp: %.3f seconds (kernel %.3f ms), %.1f Msamples/s\n", width, height, spp, seconds, integrator->last_kernel_ms(),
+                (double)width * height * spp / seconds / 1e6);
+    film.store_image("lighting_enum");
+}
+
 // BASELINE.json configs[4]: the stress frame
 static void render_stress(int spp, int res) {
     film_t film(res, res);
@@ -194,6 +210,8 @@ int main(int argc, char* argv[]) {
         if (!std::strcmp(which, "single")) {
             if (argc > 3) g_spp_scale = std::atoi(argv[3]);
             render_single_scene(argc > 2 ? std::atoi(argv[2]) : 0);
+        } else if (!std::strcmp(which, "lighting_enum")) {
+            render_lighting_enum(argc > 2 ? std::atoi(argv[2]) : 1024, argc > 3 ? std::atoi(argv[3]) : 1024, argc > 4 ? std::atoi(argv[4]) : 768);
         } else if (!std::strcmp(which, "batch")) {
             render_batch(argc > 2 ? std::atoi(argv[2]) : 2048, argc > 3 ? std::atoi(argv[3]) : 1024);
         } else if (!std::strcmp(which, "stress")) {

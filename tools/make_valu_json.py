@@ -2,7 +2,7 @@
 """Builds profiles/valu.json and profiles/hbm_traffic.json from the committed rocprofv3 summaries of a round
 (tools/final_profiles.sh <prefix> on the GPU box, summaries copied to profiles/).
 
-usage: tools/make_valu_json.py <prefix, e.g. r02_c>
+usage: tools/make_valu_json.py <prefix, e.g. r02_d>
 
 What bench.py's `roofline.valu` reports, per kernel / workload, every figure recomputable from the named files:
   wave_instr_per_sample   SQ_INSTS_VALU / camera samples of the launch

@@ -69,9 +69,6 @@ __device__ __noinline__ void ky_clk_mark(int k) {
 #ifndef KY_ABL
 #define KY_ABL 0
 #endif
-#ifndef KY_SQ_ABL
-#define KY_SQ_ABL 0
-#endif
 
 namespace kyd {
 
@@ -1050,11 +1047,7 @@ struct ShadowQueue {
 KY_DEV void sq_push(ShadowQueue& q, bool push, f3 o, f3 d, float tmax, f3 c, unsigned tag) {
     const unsigned long long m = __ballot(push);
     if (!m) return;
-#if KY_SQ_ABL == 3
-    if (push && q.n > 100000) {
-#else
     if (push) {
-#endif
         const int slot = q.n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         float* p = q.base + slot;
         p[0 * KY_SQ_CAP] = o.x; p[1 * KY_SQ_CAP] = o.y; p[2 * KY_SQ_CAP] = o.z;
@@ -1096,7 +1089,7 @@ KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, int li, fl
                 o = offset_ray_origin(v.position, v.normal, dir);
                 push = !(C.x == 0.f && C.y == 0.f && C.z == 0.f);
                 // the sampled shape itself is the likeliest occluder (quirk 1): one test here saves the ray a full traversal
-                if (KY_SQ_ABL != 1 && push && L.kind == KY_LIGHT_AREA && L.sampled_is_surface) {
+                if (push && L.kind == KY_LIGHT_AREA && L.sampled_is_surface) {
                     float t;
                     if (surf_hit(L.isect, S->full, o, dir, tmax, t, S.general)) push = false;
                 }
@@ -1119,11 +1112,7 @@ KY_DEV void sq_resolve(SceneRef S, ShadowQueue& q, int k, const SqSink& sink) {
     const int lane = (int)__lane_id();
     q.n -= k;
     if (lane < k) {
-#if KY_SQ_ABL == 2
-        const float* p = q.base + lane;    // measurement build: always the same (cached) slots
-#else
         const float* p = q.base + q.n + lane;
-#endif
         const f3 o = mk3(p[0 * KY_SQ_CAP], p[1 * KY_SQ_CAP], p[2 * KY_SQ_CAP]);
         const f3 d = mk3(p[3 * KY_SQ_CAP], p[4 * KY_SQ_CAP], p[5 * KY_SQ_CAP]);
         const float tmax = p[6 * KY_SQ_CAP];
@@ -1140,11 +1129,7 @@ KY_DEV void sq_resolve(SceneRef S, ShadowQueue& q, int k, const SqSink& sink) {
                 else if (a > 2.0e9f) fl |= 8u << ch;
                 else if (a < -2.0e9f) fl |= 64u << ch;
                 else if (a != 0.f) {
-#if KY_SQ_ABL == 4
-                    const unsigned long long fx = (unsigned long long)to_fixed32(a);
-#else
                     const unsigned long long fx = (unsigned long long)__double2ll_rn((double)a * 4294967296.0);
-#endif
                     if (local) atomicAdd(&sink.c_def[ch * 256 + owner], fx);
                     else atomicAdd(&sink.accum[(size_t)pix * 3 + ch], fx);
                 }

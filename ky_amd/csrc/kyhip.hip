@@ -10,12 +10,15 @@
  *                     what is merely alive (the lane's pixel chunk, the vertex's shading frame) lives in LDS, which
  *                     is what lets 6 wavefronts per SIMD be resident.  A finished chunk's pixel sum is added to a
  *                     64-bit fixed-point accumulator with integer atomics (order-independent => bit-identical
- *                     images for every tiling / GPU count).
+ *                     images for every tiling / GPU count).  Instantiations: <sampler, strategy fixed at compile time or -1,
+ *                     QUEUE (deferred shadow rays on a per-wave stack, for multi-light scenes), GENERAL (scenes that hold
+ *                     quads that are not parallelograms, triangles or disks)>; the host picks one per launch.
  *   render_kernel_q   (ky_queue.hpp) the wavefront formulation with the path pool and per-state queues in LDS;
  *                     experimental, off by default.
  *   smallpt_kernel    (ky_smallpt.hpp) smallpt's own scene and radiance() in double precision.
  *   resolve_kernel    fixed-point accumulator -> clamp01 -> fp32 tile buffer.
- *   film_add_kernel   film_t::add_color (ky.cpp:1586) for a shard's compact tile buffer.
+ *   film_add_kernel   film_t::add_color (ky.cpp:1586) for a shard's compact tile buffer;
+ *   film_add_gathered_kernel  the same for all shards of a frame at once (after the multi-GPU gather).
  *   kat_*             function-level known-answer-test kernels.
  * gfx950 only; no CPU fallback anywhere in this file.
  */

@@ -767,4 +767,12 @@ inline std::unique_ptr<integrator_t> create_integrator(integrator_enum_t integra
     }
 }
 
+// The same factory for a list of GPUs (kyhip_render_multi): the frame's tiles are interleaved over `devices`.
+inline std::unique_ptr<integrator_t> create_integrator(integrator_enum_t integrator_enum, int depth, direct_sample_enum_t direct_sample_enum, std::vector<int> devices) {
+    if (devices.empty()) throw std::runtime_error("create_integrator: empty device list");
+    auto integrator = create_integrator(integrator_enum, depth, direct_sample_enum, devices[0]);
+    if (integrator) integrator->set_devices(std::move(devices));
+    return integrator;
+}
+
 }  // namespace ky

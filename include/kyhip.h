@@ -290,6 +290,13 @@ int kyhip_kat_occluded(int device, const ky_scene* scene, const float* in9, int 
 int kyhip_kat_li(int device, const ky_scene* scene, const ky_render_params* params,
                  int x, int y, int s0, int n, float* out3);
 
+/* estimate_direct_lighting_{by_bsdf, by_emitter, by_bsdf_mis, by_emitter_mis} (3889-4074) for ONE light at given vertices with given
+   random numbers.  in15: n x {position[3], normal[3], wo[3], surface (index into scene->surfaces), lobe_u (the plastic material's lobe
+   number, 2663), random_bsdf[2], random_light[2]}; out6: n x {the BSDF-sampling half [3], the light-sampling half [3]}.
+   direct_sample 4 / 8: the plain estimators (by_bsdf uses random_bsdf as the float2 it draws itself, 3900); 16 / 32: the MIS halves;
+   48: both MIS halves (not yet weighted by the 0.5 of 4083).  Vertices on delta surfaces return zeros (4571). */
+int kyhip_kat_nee(int device, const ky_scene* scene, int direct_sample, int light, const float* in15, int n, float* out6);
+
 /* The same sample of path_tracing_iteration_t vertex by vertex (the reference's LOG_VAST at ky.cpp:4578 prints the same facts):
    one row of 26 floats per vertex that reaches the continuation sample (4586):
    {bounces, surface (caller's index), lobe (0 lambert, 1 mirror, 2 glass, 3 phong), position[3], normal[3], wo[3],

@@ -177,6 +177,14 @@ def kat_li(scene, params, x, y, s0, n, device=0):
     return out
 
 
+def kat_nee(scene, direct_sample, light, in15, device=0):
+    lib = A.load_kyhip()
+    in15 = np.ascontiguousarray(in15, np.float32)
+    out = np.zeros((in15.shape[0], 6), np.float32)
+    _check(lib.kyhip_kat_nee(device, _scene_ptr(scene), direct_sample, light, _fptr(in15), in15.shape[0], _fptr(out)))
+    return out
+
+
 def kat_li_trace(scene, params, x, y, s, max_rows=64, device=0):
     """kyhip_kat_li_trace: (rows [n, 26], li [3]) of one camera sample of path_tracing_iteration_t."""
     lib = A.load_kyhip()

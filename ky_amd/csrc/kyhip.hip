@@ -495,6 +495,37 @@ __global__ void kat_li_kernel(const DScene* __restrict__ S, RenderConst rc, int 
     if (i < n) { out3[3 * (size_t)i] = ps.Lo.x; out3[3 * (size_t)i + 1] = ps.Lo.y; out3[3 * (size_t)i + 2] = ps.Lo.z; }
 }
 
+// one light's direct-lighting estimate at given vertices with given random numbers (estimate_direct_lighting_*, 3889-4088)
+__global__ void kat_nee_kernel(const DScene* __restrict__ S, int strategy, int li, const float* __restrict__ in15, int n, float* __restrict__ out6) {
+    __shared__ LdsScene Lds;
+    stage_scene(Lds, S);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < n;
+    const float* r = in15 + 15 * (size_t)(active ? i : 0);
+    Vertex v;
+    v.position = ld3(r); v.normal = ld3(r + 3);
+    v.t = 0.f;
+    v.surface = 0;
+    for (int j = 0; j < S->n_surfaces; ++j)
+        if (S->orig[j] == (int)r[9]) v.surface = j;          // the caller's surface index -> the device's sorted index
+    v.bsdf = make_bsdf(Lds.mat[Lds.hit[v.surface].material], r[10]);
+    const Frame fr = make_frame(v.normal);
+    vertex_set_frame(v, fr, to_local(fr, ld3(r + 6)));
+    f3 Lb = mk3(0, 0, 0), Ll = mk3(0, 0, 0);
+    const bool nee = active && !bsdf_is_delta(v.bsdf);        // sample_all_light runs for non-delta vertices only (4571)
+    // (wave-uniform calls: every lane makes them, `nee` says whether it takes part)
+    if (strategy == KY_DIRECT_BSDF) Lb = estimate_by_bsdf<false>(S, Lds, v, li, r[11], r[12], nee);
+    else if (strategy == KY_DIRECT_BSDF_MIS || strategy == KY_DIRECT_BOTH_MIS) Lb = estimate_by_bsdf<true>(S, Lds, v, li, r[11], r[12], nee);
+    if (nee) {
+        if (strategy == KY_DIRECT_LIGHT) Ll = estimate_by_emitter<false>(S, Lds, v, li, r[13], r[14]);
+        else if (strategy == KY_DIRECT_LIGHT_MIS || strategy == KY_DIRECT_BOTH_MIS) Ll = estimate_by_emitter<true>(S, Lds, v, li, r[13], r[14]);
+    }
+    if (active) {
+        float* o = out6 + 6 * (size_t)i;
+        o[0] = Lb.x; o[1] = Lb.y; o[2] = Lb.z; o[3] = Ll.x; o[4] = Ll.y; o[5] = Ll.z;
+    }
+}
+
 // one camera sample, traced vertex by vertex (lane 0 walks the path; the other lanes only keep the wave-uniform calls company)
 template <bool DEBUG_SAMPLER>
 __global__ void kat_li_trace_kernel(const DScene* __restrict__ S, RenderConst rc, int x, int y, int s, int max_rows, float* __restrict__ out) {
@@ -1273,6 +1304,23 @@ int kyhip_kat_li(int device, const ky_scene* scene, const ky_render_params* p, i
         if (r != KY_OK) return r;
         if (dbg) hipLaunchKernelGGL(kat_li_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, 0, c->d_scene, rc, x, y, s0, n, d_out);
         else hipLaunchKernelGGL(kat_li_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, 0, c->d_scene, rc, x, y, s0, n, d_out);
+        return (int)KY_OK;
+    });
+}
+
+int kyhip_kat_nee(int device, const ky_scene* scene, int direct_sample, int light, const float* in15, int n, float* out6) {
+    if (!scene || !in15 || !out6 || n <= 0 || light < 0 || light >= scene->light_count) return fail(KY_ERR_INVALID_VALUE, "bad KAT arguments");
+    if (direct_sample != KY_DIRECT_BSDF && direct_sample != KY_DIRECT_LIGHT && direct_sample != KY_DIRECT_BSDF_MIS && direct_sample != KY_DIRECT_LIGHT_MIS &&
+        direct_sample != KY_DIRECT_BOTH_MIS)
+        return fail(KY_ERR_INVALID_VALUE, "direct_sample %d has no estimator to test", direct_sample);
+    for (int i = 0; i < n; ++i) {
+        const float sf = in15[15 * (size_t)i + 9];
+        if (!(sf >= 0 && sf < scene->surface_count)) return fail(KY_ERR_INVALID_VALUE, "row %d: surface out of range", i);
+    }
+    return kat_run(device, in15, (size_t)n * 15 * 4, out6, (size_t)n * 6 * 4, [&](DeviceCtx* c, const float* d_in, float* d_out) {
+        int r = upload_scene(c, scene, 0);
+        if (r != KY_OK) return r;
+        hipLaunchKernelGGL(kat_nee_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, c->d_scene, direct_sample, light, d_in, n, d_out);
         return (int)KY_OK;
     });
 }

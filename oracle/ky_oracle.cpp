@@ -225,6 +225,8 @@ inline uint32_t mix32(uint32_t x) {  // "lowbias32" integer finaliser
 struct sampler_t {
     int      kind = KY_SAMPLER_RANDOM;
     uint32_t state = 0, inc = 1;
+    const float* tape = nullptr;   // function-level KATs: the next numbers to hand out, instead of the generator's
+    int tape_pos = 0;
     // one camera sample = one stream; sampler_t::start_pixel / next_sample (900-908) select it.
     // The 64-bit key (k0, k1) hashed from (seed, pixel, sample) becomes the state and the (odd) increment of a
     // PCG-RXS-M-XS-32 generator, so two samples share a stream only if both 32-bit halves collide.
@@ -234,6 +236,7 @@ struct sampler_t {
         inc   = mix32((h ^ 0x6A09E667u) + sample_index * 0x85EBCA6Bu) | 1u;
     }
     float get_float() {                                                                   // 960
+        if (tape) return tape[tape_pos++];
         if (kind == KY_SAMPLER_DEBUG) return 0.5f;                                        // 933-941
         state = state * 747796405u + inc;
         uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
@@ -1162,6 +1165,37 @@ int kyo_trace_li(const ky_scene* cscene, const ky_render_params* p, int x, int y
     int n = std::min<int>((int)tr.size() / 26, max_rows);
     std::memcpy(rows, tr.data(), (size_t)n * 26 * sizeof(float));
     return n;
+}
+
+// One light's direct-lighting estimate at a given vertex with given random numbers (the halves of estimate_direct_lighting_*,
+// 3889-4088).  in15: n x {p[3], normal[3], wo[3], surface (caller's index), lobe_u, random_bsdf[2], random_light[2]};
+// out6: n x {BSDF-sampling half [3], light-sampling half [3]} -- by_bsdf / by_emitter for the plain strategies 4 / 8 (by_bsdf takes
+// random_bsdf as the float2 it draws itself, 3900), the _mis variants for 16 / 32 / 48 (both halves, unweighted by the 0.5 of 4083).
+int kyo_kat_nee(const ky_scene* cscene, int direct_sample, int light, const float* in15, int n, float* out6) {
+    if (!valid_direct_sample(direct_sample) || light < 0 || light >= cscene->light_count) return KY_ERR_INVALID_VALUE;
+    scene_t scene(*cscene);
+    integrator_t integrator{&scene, KY_INTEGRATOR_PATH_TRACING_ITERATION, 5, direct_sample};
+    for (int i = 0; i < n; ++i) {
+        const float* r = in15 + 15 * i;
+        isect_t isect;
+        isect.position = vec3_t(r); isect.normal = vec3_t(r + 3); isect.wo = vec3_t(r + 6); isect.surface = (int)r[9];
+        scene.scattering(&isect, r[10]);
+        const vec2_t ub{r[11], r[12]}, ul{r[13], r[14]};
+        color_t Lb, Ll;
+        sampler_t sampler;
+        sampler.tape = r + 11;
+        switch (direct_sample) {
+        case KY_DIRECT_BSDF: Lb = integrator.by_bsdf(isect, light, sampler, nullptr); break;
+        case KY_DIRECT_LIGHT: Ll = integrator.by_emitter(isect, light, ul, nullptr); break;
+        case KY_DIRECT_BSDF_MIS: Lb = integrator.by_bsdf_mis(isect, light, ub, nullptr); break;
+        case KY_DIRECT_LIGHT_MIS: Ll = integrator.by_emitter_mis(isect, light, ul, nullptr); break;
+        case KY_DIRECT_BOTH_MIS: Lb = integrator.by_bsdf_mis(isect, light, ub, nullptr); Ll = integrator.by_emitter_mis(isect, light, ul, nullptr); break;
+        default: break;
+        }
+        float* o = out6 + 6 * i;
+        o[0] = Lb.r; o[1] = Lb.g; o[2] = Lb.b; o[3] = Ll.r; o[4] = Ll.g; o[5] = Ll.b;
+    }
+    return KY_OK;
 }
 
 int kyo_kat_intersect(const ky_shape* shape, const float* rays7, int n, float* out8) {

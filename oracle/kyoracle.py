@@ -116,6 +116,17 @@ def kat_light(scene, light, in11):
     return out
 
 
+def kat_nee(scene, direct_sample, light, in15):
+    in15 = np.ascontiguousarray(in15, np.float32)
+    out = np.zeros((in15.shape[0], 6), np.float32)
+    lib = load()
+    lib.kyo_kat_nee.argtypes = [A.SP, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    rc = lib.kyo_kat_nee(_sp(scene), direct_sample, light, _f(in15), in15.shape[0], _f(out))
+    if rc != 0:
+        raise ValueError(f"kyo_kat_nee returned {rc}")
+    return out
+
+
 def kat_scene_intersect(scene, rays7):
     rays7 = np.ascontiguousarray(rays7, np.float32)
     out = np.zeros((rays7.shape[0], 9), np.float32)

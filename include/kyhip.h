@@ -284,6 +284,17 @@ int kyhip_kat_light(int device, const ky_scene* scene, int light, const float* i
    occluded: in n x {p[3], normal[3], target[3]}, out n x {0/1}. */
 int kyhip_kat_scene_intersect(int device, const ky_scene* scene, const float* rays7, int n, float* out9);
 int kyhip_kat_occluded(int device, const ky_scene* scene, const float* in9, int n, float* out1);
+/* The same query against the occluder tables the render kernels use for shadow rays ("occluder tables").
+   light = -1: p and target are promised to lie on surfaces, area lights' shapes or point lights of the scene; rectangles that have the
+   whole scene in one closed half-space of their plane (the walls of a room) are not tested.
+   light >= 0: additionally target is a point of the shape area light `light` samples and p lies in front of it (where light_t::sample_Li
+   returns a non-black Li, 2957-2960); for a planar sampled shape the surfaces on or behind its plane are not tested either.
+   For segments that keep the promise the answer equals kyhip_kat_occluded's. */
+int kyhip_kat_occluded_between(int device, const ky_scene* scene, int light, const float* in9, int n, float* out1);
+/* Host only (no GPU needed): left_out[i] = 1 when surface i (the caller's index) is not in the occluder table for `light` (-1: the table
+   for any two scene points).  n = entries in left_out, at least scene->surface_count.  Returns the number of surfaces left out, or a
+   negative ky_status. */
+int kyhip_scene_non_occluders(const ky_scene* scene, int light, int* left_out, int n);
 
 /* integrator_t::Li per camera sample (3714-3717): for pixel (x, y) and samples [s0, s0+n) writes the
    unclamped radiance Li (3 floats per sample) -- the quantity `dL` is built from. */

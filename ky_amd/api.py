@@ -162,12 +162,28 @@ def kat_scene_intersect(scene, rays7, device=0):
     return out
 
 
-def kat_occluded(scene, in9, device=0):
+def kat_occluded(scene, in9, device=0, table=None):
+    """scene_t::occluded for n x {p, normal, target}.  table None: every surface is tested; -1 / a light index: the occluder table the
+    render kernels use for segments between scene points / for shadow rays towards samples of that light (kyhip_kat_occluded_between)."""
     lib = A.load_kyhip()
     in9 = np.ascontiguousarray(in9, np.float32)
     out = np.zeros((in9.shape[0],), np.float32)
-    _check(lib.kyhip_kat_occluded(device, _scene_ptr(scene), _fptr(in9), in9.shape[0], _fptr(out)))
+    if table is None:
+        _check(lib.kyhip_kat_occluded(device, _scene_ptr(scene), _fptr(in9), in9.shape[0], _fptr(out)))
+    else:
+        _check(lib.kyhip_kat_occluded_between(device, _scene_ptr(scene), int(table), _fptr(in9), in9.shape[0], _fptr(out)))
     return out
+
+
+def scene_non_occluders(scene, light=-1):
+    """kyhip_scene_non_occluders (host only): bool per surface -- not in the occluder table for `light` (-1: any two scene points)."""
+    lib = A.load_kyhip()
+    n = _scene_ptr(scene).contents.surface_count
+    out = np.zeros(max(1, n), np.int32)
+    rc = lib.kyhip_scene_non_occluders(_scene_ptr(scene), int(light), out.ctypes.data_as(C.c_void_p), n)
+    if rc < 0:
+        _check(rc)
+    return out[:n].astype(bool)
 
 
 def kat_li(scene, params, x, y, s0, n, device=0):

@@ -188,7 +188,8 @@ struct DLight {  // light_t + the shape an area light samples; wave-uniform inde
     int32_t n_carriers;   // surfaces whose surface_t::area_light is this light (sorted indices); -1: more than KY_MAX_CARRIERS
     int32_t carrier[4];
     int32_t sampled_is_surface;   // the shape this light samples is also the shape of some surface of the scene (so it occludes)
-    int32_t pad_l[3];
+    int32_t occ_ok;               // shadow rays towards samples of this light may use DScene::occ
+    int32_t pad_l[2];
     DSurf isect;          // traversal record of the sampled shape (pdf_direction re-intersects it, 1057-1061)
 };
 constexpr int KY_MAX_CARRIERS = 4;
@@ -217,16 +218,29 @@ struct DAar {
 // index used on the device are in this sorted order; orig[] maps back to the caller's surface index.  (Ties: the
 // reference's "first surface in list order wins an exactly equal distance" (3177-3180) is preserved inside a group;
 // an exact tie between shapes of different kinds has measure zero.)
+struct DTrav {   // the planar part of a traversal table: axis-aligned rectangles grouped by axis (x, y, z planes), then other parallelograms
+    int32_t n_aar, n_par, pad_t0, pad_t1;   // n_aar = n_aar_axis[0] + [1] + [2]
+    int32_t n_aar_axis[3], pad_t2;
+    DAar aar[KYHIP_MAX_SURFACES + 1];   // one readable record past the end: the traversal reads i + 1
+    DPar par[KYHIP_MAX_SURFACES + 1];
+};
 struct DScene {
     int32_t n_surfaces, n_lights, n_materials, env_light;
-    int32_t n_par, n_sph, n_gen, n_aar;   // n_aar = n_aar_axis[0] + [1] + [2]
-    int32_t n_aar_axis[3], general;       // rectangles per axis plane (x, y, z), stored in that order; general: SceneRef::general
+    int32_t n_sph, n_gen, general, occ_deferred_ok;   // general: SceneRef::general; occ_deferred_ok: shadow rays towards every light may use `occ`
     float cam_position[3], cam_inv_w;
     float cam_front[3], cam_inv_h;
     float cam_right[3], pad0;
     float cam_up[3], pad1;
-    DAar aar[KYHIP_MAX_SURFACES + 1];   // grouped by axis; one readable record past the end: the traversal reads i + 1
-    DPar par[KYHIP_MAX_SURFACES + 1];
+    DTrav trav;                         // every planar surface; its order is the sorted surface order
+    // Occluder tables (host: find_non_occluders, which states the conditions): `trav` without surfaces that provably hold no point of a
+    // shadow ray.
+    //  occ            without the walls of a room: planar surfaces that have the whole scene in one closed half-space of their plane.
+    //                 For rays that end at a scene point (the MIS rays' "is anything in front of the carrier" query) and, when
+    //                 occ_deferred_ok, for the deferred shadow rays of all lights.
+    //                 Shadow rays towards a SAMPLE of light li (by_emitter) use it when DLight::occ_ok: the light keeps clear of every
+    //                 wall's plane by more than the ray origin's offset (never for directional / environment lights).
+    //  Spheres are in none of these tables: they are always tested.
+    DTrav occ;
     DSph sph[KYHIP_MAX_SURFACES + 1];
     DSurf gen[KYHIP_MAX_SURFACES];
     DSurf all[KYHIP_MAX_SURFACES];      // every surface as a generic record, sorted order (carrier tests, surface-parallel queries)
@@ -388,13 +402,13 @@ KY_DEV bool aar_hit(const float4 q0, const float ov, f3 o, f3 d, f3 inv_d, float
 
 // the axis-aligned rectangles of one axis: records [first, first + n) of S->aar, whose sorted surface indices are the same
 template <int AXIS, bool NEAREST>
-KY_DEV void aar_scan(SceneRef S, int first, int n, f3 o, f3 d, f3 inv_d, float& tmax, int& best, bool& occ) {
+KY_DEV void aar_scan(const DAar* __restrict__ aar, int first, int n, f3 o, f3 d, f3 inv_d, float& tmax, int& best, bool& occ) {
     if (n <= 0) return;
-    float4 q0 = S->aar[first].q0;
-    float ov = S->aar[first].q1.x;
+    float4 q0 = aar[first].q0;
+    float ov = aar[first].q1.x;
     for (int i = first; i < first + n; ++i) {
-        const float4 n0 = S->aar[i + 1].q0;   // record n_aar exists (padding)
-        const float nv = S->aar[i + 1].q1.x;
+        const float4 n0 = aar[i + 1].q0;   // record n_aar exists (padding)
+        const float nv = aar[i + 1].q1.x;
         float t;
         const bool ok = aar_hit<AXIS>(q0, ov, o, d, inv_d, tmax, t);
         if (NEAREST) {
@@ -434,19 +448,20 @@ KY_DEV bool surf_hit(const DSurf& S, const DShapeFull* __restrict__ full, f3 o, 
 // overlaps the VALU work instead of being exposed once per surface.
 KY_DEV int trace_nearest(SceneRef S, f3 o, f3 d, float& tmax) {
     int best = -1;
-    const int n_aar = S->n_aar, n_par = S->n_par, n_sph = S->n_sph, n_gen = S->n_gen;
+    const DTrav& T = S->trav;
+    const int n_aar = T.n_aar, n_par = T.n_par, n_sph = S->n_sph, n_gen = S->n_gen;
     if (n_aar > 0) {
         const f3 inv_d = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
         bool unused = false;
-        const int n0 = S->n_aar_axis[0], n1 = S->n_aar_axis[1], n2 = S->n_aar_axis[2];
-        aar_scan<0, true>(S, 0, n0, o, d, inv_d, tmax, best, unused);
-        aar_scan<1, true>(S, n0, n1, o, d, inv_d, tmax, best, unused);
-        aar_scan<2, true>(S, n0 + n1, n2, o, d, inv_d, tmax, best, unused);
+        const int n0 = T.n_aar_axis[0], n1 = T.n_aar_axis[1], n2 = T.n_aar_axis[2];
+        aar_scan<0, true>(T.aar, 0, n0, o, d, inv_d, tmax, best, unused);
+        aar_scan<1, true>(T.aar, n0, n1, o, d, inv_d, tmax, best, unused);
+        aar_scan<2, true>(T.aar, n0 + n1, n2, o, d, inv_d, tmax, best, unused);
     }
     if (n_par > 0) {
-        float4 q0 = S->par[0].q0, q1 = S->par[0].q1, q2 = S->par[0].q2;
+        float4 q0 = T.par[0].q0, q1 = T.par[0].q1, q2 = T.par[0].q2;
         for (int i = 0; i < n_par; ++i) {
-            const float4 n0 = S->par[i + 1].q0, n1 = S->par[i + 1].q1, n2 = S->par[i + 1].q2;   // record n_par exists (padding)
+            const float4 n0 = T.par[i + 1].q0, n1 = T.par[i + 1].q1, n2 = T.par[i + 1].q2;   // record n_par exists (padding)
             float t;
             const bool ok = par_hit(q0, q1, q2, o, d, tmax, t);
             tmax = ok ? t : tmax;
@@ -475,23 +490,31 @@ KY_DEV int trace_nearest(SceneRef S, f3 o, f3 d, float& tmax) {
     return best;
 }
 
-// scene_t::occluded's traversal (3193-3195): any hit inside (eps, tmax) occludes.
-KY_DEV bool trace_any(SceneRef S, f3 o, f3 d, float tmax) {
+// scene_t::occluded's traversal (3193-3195): any hit inside (eps, tmax) occludes.  `T_` (wave-uniform): the table of planar surfaces
+// to test -- S->trav (all), or the occluder table when the ray qualifies for it (DScene::occ).
+KY_DEV bool trace_any(SceneRef S, const DTrav& T_, f3 o, f3 d, float tmax) {
     bool occ = false;
-    const int n_aar = S->n_aar, n_par = S->n_par, n_sph = S->n_sph, n_gen = S->n_gen;
+#ifdef KY_NO_OCCLUDER_CULL   // A/B measurements
+    const DTrav& T = S->trav;
+#else
+    const DTrav& T = T_;
+#endif
+    const int n_aar = T.n_aar, n_par = T.n_par, n_sph = S->n_sph, n_gen = S->n_gen;
+    const DAar* __restrict__ aar = T.aar;
+    const DPar* __restrict__ par = T.par;
     float t;
     if (n_aar > 0) {
         const f3 inv_d = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
         int unused = -1;
-        const int n0 = S->n_aar_axis[0], n1 = S->n_aar_axis[1], n2 = S->n_aar_axis[2];
-        aar_scan<0, false>(S, 0, n0, o, d, inv_d, tmax, unused, occ);
-        aar_scan<1, false>(S, n0, n1, o, d, inv_d, tmax, unused, occ);
-        aar_scan<2, false>(S, n0 + n1, n2, o, d, inv_d, tmax, unused, occ);
+        const int n0 = T.n_aar_axis[0], n1 = T.n_aar_axis[1], n2 = T.n_aar_axis[2];
+        aar_scan<0, false>(aar, 0, n0, o, d, inv_d, tmax, unused, occ);
+        aar_scan<1, false>(aar, n0, n1, o, d, inv_d, tmax, unused, occ);
+        aar_scan<2, false>(aar, n0 + n1, n2, o, d, inv_d, tmax, unused, occ);
     }
     if (n_par > 0) {
-        float4 q0 = S->par[0].q0, q1 = S->par[0].q1, q2 = S->par[0].q2;
+        float4 q0 = par[0].q0, q1 = par[0].q1, q2 = par[0].q2;
         for (int i = 0; i < n_par; ++i) {
-            const float4 n0 = S->par[i + 1].q0, n1 = S->par[i + 1].q1, n2 = S->par[i + 1].q2;
+            const float4 n0 = par[i + 1].q0, n1 = par[i + 1].q1, n2 = par[i + 1].q2;
             occ = occ | par_hit(q0, q1, q2, o, d, tmax, t);
             q0 = n0; q1 = n1; q2 = n2;
         }
@@ -972,7 +995,7 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, int
             KY_PROBE(2);
             // the traversal may test the carrier with another formulation than (a) did (aar_hit vs par_hit): keep its own
             // hit, a few ulp around t_l, out of the interval
-            if (pending) blocked = trace_any(S, o, bs.wi, t_l * (1.f - 1e-6f));
+            if (pending) blocked = trace_any(S, S->occ, o, bs.wi, t_l * (1.f - 1e-6f));   // from a surface point to a point of a carrier surface
         } else {
             const int lane = (int)__lane_id();
             while (queries) {
@@ -1116,7 +1139,7 @@ KY_DEV void sq_resolve(SceneRef S, ShadowQueue& q, int k, const SqSink& sink) {
         const f3 o = mk3(p[0 * KY_SQ_CAP], p[1 * KY_SQ_CAP], p[2 * KY_SQ_CAP]);
         const f3 d = mk3(p[3 * KY_SQ_CAP], p[4 * KY_SQ_CAP], p[5 * KY_SQ_CAP]);
         const float tmax = p[6 * KY_SQ_CAP];
-        if (!trace_any(S, o, d, tmax)) {
+        if (!trace_any(S, S->occ_deferred_ok ? S->occ : S->trav, o, d, tmax)) {   // rays of all lights share the stack
             const float c[3] = {p[7 * KY_SQ_CAP], p[8 * KY_SQ_CAP], p[9 * KY_SQ_CAP]};
             const unsigned tag = __float_as_uint(p[10 * KY_SQ_CAP]);
             const int pix = (int)(tag >> 6), owner = (int)((threadIdx.x & ~63u) | (tag & 63u));
@@ -1163,7 +1186,7 @@ KY_DEV f3 estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, 
 #if KY_ABL == 3
         const bool occ = o.x == 1e30f;   // never: the traversal's instructions removed, everything after it kept
 #else
-        const bool occ = trace_any(S, o, dir, dist - 2e-3f);
+        const bool occ = trace_any(S, L.occ_ok ? S->occ : S->trav, o, dir, dist - 2e-3f);   // wave-uniform choice
 #endif
         KY_CLK(6);
 #if KY_ABL == 4

@@ -451,7 +451,7 @@ __global__ __launch_bounds__(QE_THREADS, KY_QE_WAVES) void render_kernel_q(const
                 const f3 position = mk3(W.ox[sl], W.oy[sl], W.oz[sl]);
                 const f3 normal = hit_normal(Lds.hit[(inf >> 16) & 0xffu], position, mk3(W.dx[sl], W.dy[sl], W.dz[sl]));
                 const f3 dir = mk3(W.wx[sl], W.wy[sl], W.wz[sl]);
-                occluded = trace_any(S, offset_ray_origin(position, normal, dir), dir, W.wt[sl]);
+                occluded = trace_any(S, S->trav, offset_ray_origin(position, normal, dir), dir, W.wt[sl]);
             }
             if (active) {
                 if (!occluded) { W.lr[sl] += W.cr[sl]; W.lg[sl] += W.cg[sl]; W.lb[sl] += W.cb[sl]; }

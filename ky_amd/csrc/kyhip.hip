@@ -30,6 +30,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -466,7 +467,8 @@ __global__ void kat_scene_intersect_kernel(const DScene* __restrict__ S, const f
     q[2] = p.x; q[3] = p.y; q[4] = p.z; q[5] = nn.x; q[6] = nn.y; q[7] = nn.z; q[8] = hs >= 0 ? (float)S->orig[hs] : -1.f;
 }
 
-__global__ void kat_occluded_kernel(const DScene* __restrict__ S, const float* __restrict__ in9, int n, float* __restrict__ out1) {
+// table: -2 every surface, -1 DScene::occ, l >= 0 what by_emitter uses for light l
+__global__ void kat_occluded_kernel(const DScene* __restrict__ S, const float* __restrict__ in9, int n, float* __restrict__ out1, int table) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* r = in9 + 9 * (size_t)i;
@@ -474,7 +476,7 @@ __global__ void kat_occluded_kernel(const DScene* __restrict__ S, const float* _
     const f3 dir = normalize(target - p);
     const float dist = sqrtf(length_sq(p - target));
     const f3 o = offset_ray_origin(p, pn, dir);
-    out1[i] = trace_any(S, o, dir, dist - 2e-3f) ? 1.f : 0.f;
+    out1[i] = trace_any(S, (table == -1 || (table >= 0 && S->light[table].occ_ok)) ? S->occ : S->trav, o, dir, dist - 2e-3f) ? 1.f : 0.f;
 }
 
 template <bool DEBUG_SAMPLER>
@@ -663,6 +665,109 @@ static bool shape_normal_ok(const ky_shape& sh) {
     return std::fabs(n2 - 1.0) < 1e-4;
 }
 
+// Which surfaces a shadow ray never has to test (DScene::occ).
+//
+// The rays in question (scene_t::occluded 3187-3201 and the carrier query of by_bsdf) start at o = p + w, w = +-1e-2 n_p
+// (offset_ray_origin, 614-620: along the normal of p's surface, on the side the ray leaves to), and run along dir = (q - p) / |q - p|
+// to t = |q - p| - 2e-3: the segment from p to just short of q, SHIFTED by w.  It does not pass through q, and it can end up to 8e-3
+// beyond q's depth (a reference quirk the tables must not hide: in the Cornell box most light samples taken from the floor are blocked
+// by the lamp itself, and a few that miss the lamp's edge by the side panels above it).  p is a point of a surface with a non-delta
+// material (4571), q a point of a light or (carrier query: the ray then ends exactly there) of a surface.
+//
+//  wall[X]      X is a planar rectangle, every surface / area light's shape / point light lies in ONE closed half-space of its plane,
+//               and every non-delta surface that comes within |w| of the plane is planar and perpendicular or parallel to X (the shift
+//               then keeps ray points on the scene's side, or moves them where the ray only leaves).  Such a ray has no point in X
+//               when it ends on a scene point -> X is not in `occ`.
+//  light_ok[l]  shadow rays towards samples of light l may use `occ` too: the shape (position) of l stays further than |w| from every
+//               wall's plane, so the far end of such a ray cannot be shifted across one.
+// Exact arithmetic on the caller's floats where a decision is an equality (the products of an axis-aligned plane are exact in double; a
+// tilted wall whose neighbours' corners were rounded to the other side simply stays an occluder).  Indices are the caller's.
+constexpr double K_HOST_RAY_OFFSET = 1e-2;   // offset_ray_origin 614-620
+static void shape_extent(const ky_shape& sh, const double* n, double& lo, double& hi) {   // range of n.x over the shape
+    auto dotp = [&](const float* p) { return n[0] * p[0] + n[1] * p[1] + n[2] * p[2]; };
+    if (sh.kind == KY_SHAPE_SPHERE || sh.kind == KY_SHAPE_DISK) {   // a disk: bounded by its sphere
+        const double c = dotp(sh.p[0]), r = (double)sh.radius * std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        lo = std::min(lo, c - r); hi = std::max(hi, c + r);
+        return;
+    }
+    const int np = sh.kind == KY_SHAPE_TRIANGLE ? 3 : 4;
+    for (int q = 0; q < np; ++q) { const double c = dotp(sh.p[q]); lo = std::min(lo, c); hi = std::max(hi, c); }
+}
+struct NonOccluders {
+    std::vector<char> wall;                  // [surface]
+    std::vector<char> light_ok;              // [light]
+    bool deferred_ok = false;                // all lights ok (the deferred shadow rays share one stack)
+};
+static void find_non_occluders(const ky_scene* in, NonOccluders& R) {
+    const int ns = in->surface_count, nl = in->light_count;
+    R.wall.assign(ns, 0);
+    R.light_ok.assign(nl, 1);
+    for (int l = 0; l < nl; ++l)
+        if (in->lights[l].kind == KY_LIGHT_DIRECTION || in->lights[l].kind == KY_LIGHT_ENVIRONMENT) R.light_ok[l] = 0;   // their rays leave the scene
+    const double inf = std::numeric_limits<double>::infinity();
+    auto shape_of = [&](int i) -> const ky_shape& { return in->shapes[in->surfaces[i].shape]; };
+    auto is_delta = [&](int i) { const int k = in->materials[in->surfaces[i].material].kind; return k == KY_MATERIAL_MIRROR || k == KY_MATERIAL_GLASS; };
+    // Rays that start on surface y within the origin offset of the plane (unit normal n, offset k; `side` +1: the scene side is n.x >= k)
+    // keep their origin on the scene side or leave moving away: y is planar and perpendicular or parallel to the plane.
+    auto offset_safe = [&](int y, const double* n, double k, int side, double lo_y, double hi_y) {
+        if (is_delta(y)) return true;                                   // no shadow ray starts on a delta surface (4571)
+        const double nearest = side > 0 ? lo_y - k : k - hi_y;          // distance of y's nearest point from the plane
+        if (nearest > 1.01 * K_HOST_RAY_OFFSET) return true;
+        const ky_shape& sh = shape_of(y);
+        if (sh.kind == KY_SHAPE_SPHERE) return false;
+        if (sh.kind == KY_SHAPE_RECTANGLE) {   // its stored normal must be the normal of all four corners' plane
+            double lo = inf, hi = -inf;
+            const double m[3] = {sh.normal[0], sh.normal[1], sh.normal[2]};
+            shape_extent(sh, m, lo, hi);
+            if (hi - lo > 1e-6) return false;
+        }
+        const double c = std::fabs(n[0] * sh.normal[0] + n[1] * sh.normal[1] + n[2] * sh.normal[2]);
+        return c <= 1e-7 || c >= 1.0 - 1e-12;
+    };
+    for (int i = 0; i < ns; ++i) {
+        const ky_shape& sh = shape_of(i);
+        if (sh.kind != KY_SHAPE_RECTANGLE) continue;
+        // the plane through p1 spanned by the two edges (a quad that is not planar never gets a planar traversal record: pack_shape)
+        double a[3], b[3], n[3];
+        for (int j = 0; j < 3; ++j) { a[j] = (double)sh.p[0][j] - sh.p[1][j]; b[j] = (double)sh.p[2][j] - sh.p[1][j]; }
+        n[0] = a[1] * b[2] - a[2] * b[1]; n[1] = a[2] * b[0] - a[0] * b[2]; n[2] = a[0] * b[1] - a[1] * b[0];
+        const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        if (!(len > 0)) continue;
+        // an axis-aligned plane keeps its exact form (n = +-e_axis after the division when the other two components are exact zeros)
+        for (int j = 0; j < 3; ++j) n[j] /= len;
+        const double k = n[0] * sh.p[1][0] + n[1] * sh.p[1][1] + n[2] * sh.p[1][2];
+        double lo = inf, hi = -inf;
+        for (int j = 0; j < ns; ++j) shape_extent(shape_of(j), n, lo, hi);
+        for (int l = 0; l < nl; ++l) {
+            const ky_light& L = in->lights[l];
+            if (L.kind == KY_LIGHT_AREA) shape_extent(in->shapes[L.shape], n, lo, hi);
+            if (L.kind == KY_LIGHT_POINT) { const double c = n[0] * L.position[0] + n[1] * L.position[1] + n[2] * L.position[2]; lo = std::min(lo, c); hi = std::max(hi, c); }
+        }
+        const int side = lo >= k ? 1 : (hi <= k ? -1 : 0);   // nothing strictly on the other side
+        if (side == 0) continue;
+        bool ok = true;
+        for (int y = 0; y < ns && ok; ++y) {
+            if (y == i) continue;
+            double lo_y = inf, hi_y = -inf;
+            shape_extent(shape_of(y), n, lo_y, hi_y);
+            ok = offset_safe(y, n, k, side, lo_y, hi_y);
+        }
+        if (!ok) continue;
+        R.wall[i] = 1;
+        for (int l = 0; l < nl; ++l) {   // can the far end of a ray towards a sample of light l be shifted across this wall's plane?
+            const ky_light& L = in->lights[l];
+            if (L.kind == KY_LIGHT_DIRECTION || L.kind == KY_LIGHT_ENVIRONMENT) continue;
+            double lo_l = inf, hi_l = -inf;
+            if (L.kind == KY_LIGHT_AREA) shape_extent(in->shapes[L.shape], n, lo_l, hi_l);
+            else lo_l = hi_l = n[0] * L.position[0] + n[1] * L.position[1] + n[2] * L.position[2];
+            const double nearest = side > 0 ? lo_l - k : k - hi_l;
+            if (!(nearest > 1.01 * K_HOST_RAY_OFFSET)) R.light_ok[l] = 0;
+        }
+    }
+    R.deferred_ok = true;
+    for (int l = 0; l < nl; ++l) R.deferred_ok = R.deferred_ok && R.light_ok[l];
+}
+
 static int pack_scene(const ky_scene* in, DScene* out) {
     if (!in) return fail(KY_ERR_INVALID_VALUE, "scene is NULL");
     if (in->surface_count < 0 || in->shape_count < 0 || in->material_count < 0 || in->light_count < 0)
@@ -693,8 +798,17 @@ static int pack_scene(const ky_scene* in, DScene* out) {
             return fail(KY_ERR_INVALID_VALUE, "surface %d: area_light must refer to an area light", i);
         pack_shape(sh, 0, &recs[i], &fulls[i]);
     }
+    for (int i = 0; i < in->light_count; ++i)   // checked again, with messages, where the lights are packed
+        if (in->lights[i].kind == KY_LIGHT_AREA && (in->lights[i].shape < 0 || in->lights[i].shape >= in->shape_count))
+            return fail(KY_ERR_INVALID_VALUE, "area light %d: shape out of range", i);
+    for (int i = 0; i < in->surface_count; ++i)   // (checked again, with the other surface fields, below)
+        if (in->surfaces[i].shape < 0 || in->surfaces[i].shape >= in->shape_count || in->surfaces[i].material < 0 || in->surfaces[i].material >= in->material_count)
+            return fail(KY_ERR_INVALID_VALUE, "surface %d has an index out of range", i);
+    NonOccluders non;
+    find_non_occluders(in, non);
     int j = 0;
-    std::vector<DAar> aar_groups[3];
+    struct PlanarEntry { int surface, axis; DAar aar; DPar par; };   // axis -1: a parallelogram record
+    std::vector<PlanarEntry> planar;   // in traversal order: x, y, z planes, then the other parallelograms
     for (int pass = -3; pass < 3; ++pass) {   // -3, -2, -1: axis-aligned rectangles in the x, y, z planes
         for (int i = 0; i < in->surface_count; ++i) {
             const ky_surface& sf = in->surfaces[i];
@@ -704,13 +818,11 @@ static int pack_scene(const ky_scene* in, DScene* out) {
             const int group = axis >= 0 ? axis - 3 : (recs[i].kind == TK_PARALLELOGRAM ? 0 : (recs[i].kind == TK_SPHERE ? 1 : 2));
             if (group != pass) continue;
             if (pass < 0) {
-                out->n_aar_axis[axis]++;
-                out->n_aar++;
-                aar_groups[axis].push_back(aar);
+                planar.push_back(PlanarEntry{i, axis, aar, DPar{}});
             } else if (pass == 0) {
-                DPar& d = out->par[out->n_par++];
-                std::memcpy(&d.q0, &recs[i].f[0], 16); std::memcpy(&d.q1, &recs[i].f[4], 16); std::memcpy(&d.q2, &recs[i].f[8], 16);
-                out->par[out->n_par] = d;   // readable padding record for the prefetch of i + 1
+                PlanarEntry e{i, -1, DAar{}, DPar{}};
+                std::memcpy(&e.par.q0, &recs[i].f[0], 16); std::memcpy(&e.par.q1, &recs[i].f[4], 16); std::memcpy(&e.par.q2, &recs[i].f[8], 16);
+                planar.push_back(e);
             } else if (pass == 1) {
                 std::memcpy(&out->sph[out->n_sph++].c, &recs[i].f[0], 16);
                 out->sph[out->n_sph] = out->sph[out->n_sph - 1];
@@ -729,12 +841,20 @@ static int pack_scene(const ky_scene* in, DScene* out) {
             ++j;
         }
     }
-    {   // lay the axis groups out one after the other (x, y, z planes), plus one readable record past the end
-        int pos = 0;
-        for (int axis = 0; axis < 3; ++axis)
-            for (const DAar& r : aar_groups[axis]) out->aar[pos++] = r;
-        if (pos > 0) out->aar[pos] = out->aar[pos - 1];
-    }
+    // the planar tables: every surface (trav: its order is the sorted surface order), and the occluder tables (DScene::occ, occ_light)
+    auto build_trav = [&](DTrav& T, auto&& skip) {
+        std::memset(&T, 0, sizeof T);
+        for (const PlanarEntry& e : planar) {
+            if (skip(e.surface)) continue;
+            if (e.axis >= 0) { T.n_aar_axis[e.axis]++; T.aar[T.n_aar++] = e.aar; }
+            else T.par[T.n_par++] = e.par;
+        }
+        if (T.n_aar > 0) T.aar[T.n_aar] = T.aar[T.n_aar - 1];   // one readable record past the end for the prefetch of i + 1
+        if (T.n_par > 0) T.par[T.n_par] = T.par[T.n_par - 1];
+    };
+    build_trav(out->trav, [](int) { return false; });
+    build_trav(out->occ, [&](int i) { return non.wall[i] != 0; });
+    out->occ_deferred_ok = non.deferred_ok ? 1 : 0;
     for (int i = 0; i < in->material_count; ++i) {
         const ky_material& m = in->materials[i];
         if (m.kind < KY_MATERIAL_MATTE || m.kind > KY_MATERIAL_PLASTIC) return fail(KY_ERR_INVALID_VALUE, "material %d has an unknown kind", i);
@@ -746,6 +866,7 @@ static int pack_scene(const ky_scene* in, DScene* out) {
         DLight& d = out->light[i];
         cp3(d.color, l.color); cp3(d.position, l.position); cp3(d.direction, l.direction);
         d.kind = l.kind; d.world_radius = l.world_radius; d.shape_kind = -1;
+        d.occ_ok = non.light_ok[i];
         if (l.kind == KY_LIGHT_AREA) {
             if (l.shape < 0 || l.shape >= in->shape_count) return fail(KY_ERR_INVALID_VALUE, "area light %d: shape out of range", i);
             const ky_shape& sh = in->shapes[l.shape];
@@ -1283,14 +1404,43 @@ int kyhip_kat_scene_intersect(int device, const ky_scene* scene, const float* ra
     });
 }
 
-int kyhip_kat_occluded(int device, const ky_scene* scene, const float* in9, int n, float* out1) {
+static int kat_occluded_impl(int device, const ky_scene* scene, const float* in9, int n, float* out1, int table) {
     if (!scene || !in9 || !out1 || n <= 0) return fail(KY_ERR_INVALID_VALUE, "bad KAT arguments");
+    if (table >= scene->light_count) return fail(KY_ERR_INVALID_VALUE, "light %d out of range", table);
     return kat_run(device, in9, (size_t)n * 9 * 4, out1, (size_t)n * 4, [&](DeviceCtx* c, const float* d_in, float* d_out) {
         int r = upload_scene(c, scene, 0);
         if (r != KY_OK) return r;
-        hipLaunchKernelGGL(kat_occluded_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, c->d_scene, d_in, n, d_out);
+        hipLaunchKernelGGL(kat_occluded_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, c->d_scene, d_in, n, d_out, table);
         return (int)KY_OK;
     });
+}
+int kyhip_kat_occluded(int device, const ky_scene* scene, const float* in9, int n, float* out1) { return kat_occluded_impl(device, scene, in9, n, out1, -2); }
+int kyhip_kat_occluded_between(int device, const ky_scene* scene, int light, const float* in9, int n, float* out1) {
+    if (light < -1) return fail(KY_ERR_INVALID_VALUE, "light %d out of range", light);
+    return kat_occluded_impl(device, scene, in9, n, out1, light);
+}
+
+// host only: which surfaces the occluder tables leave out (find_non_occluders)
+int kyhip_scene_non_occluders(const ky_scene* scene, int light, int* left_out, int n) {
+    if (!scene || !left_out || n < 0) return fail(KY_ERR_INVALID_VALUE, "bad arguments");
+    std::vector<DScene> packed(1);   // pack_scene validates the scene
+    const int rc = pack_scene(scene, &packed[0]);
+    if (rc != KY_OK) return rc;
+    if (n < scene->surface_count) return fail(KY_ERR_INVALID_VALUE, "left_out holds %d entries, the scene has %d surfaces", n, scene->surface_count);
+    if (light < -1 || light >= scene->light_count) return fail(KY_ERR_INVALID_VALUE, "light %d out of range", light);
+    NonOccluders non;
+    find_non_occluders(scene, non);
+    const DScene& P = packed[0];
+    int count = 0;
+    for (int j = 0; j < P.n_surfaces; ++j) {
+        const int i = P.orig[j];
+        const bool planar = P.all[j].kind == TK_PARALLELOGRAM;   // only these have records in the planar tables
+        left_out[i] = planar && non.wall[i] && (light < 0 || non.light_ok[light]);
+        count += left_out[i];
+    }
+    const DTrav& T = (light < 0 || non.light_ok[light]) ? P.occ : P.trav;
+    if (count != P.trav.n_aar + P.trav.n_par - T.n_aar - T.n_par) return fail(KY_ERR_DEVICE, "internal: occluder table and classification disagree");
+    return count;
 }
 
 int kyhip_kat_li(int device, const ky_scene* scene, const ky_render_params* p, int x, int y, int s0, int n, float* out3) {

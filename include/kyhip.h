@@ -292,8 +292,9 @@ int kyhip_kat_occluded(int device, const ky_scene* scene, const float* in9, int 
    For segments that keep the promise the answer equals kyhip_kat_occluded's. */
 int kyhip_kat_occluded_between(int device, const ky_scene* scene, int light, const float* in9, int n, float* out1);
 /* Host only (no GPU needed): left_out[i] = 1 when surface i (the caller's index) is not in the occluder table for `light` (-1: the table
-   for any two scene points).  n = entries in left_out, at least scene->surface_count.  Returns the number of surfaces left out, or a
-   negative ky_status. */
+   for rays that end on a scene point), 2 when it is scanned only for rays with an end behind that light's plane (the two-stage scan:
+   what is mounted behind a lamp), 0 when it is always tested.  n = entries in left_out, at least scene->surface_count.  Returns the
+   number of 1s, or a negative ky_status. */
 int kyhip_scene_non_occluders(const ky_scene* scene, int light, int* left_out, int n);
 
 /* integrator_t::Li per camera sample (3714-3717): for pixel (x, y) and samples [s0, s0+n) writes the

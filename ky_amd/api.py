@@ -176,14 +176,15 @@ def kat_occluded(scene, in9, device=0, table=None):
 
 
 def scene_non_occluders(scene, light=-1):
-    """kyhip_scene_non_occluders (host only): bool per surface -- not in the occluder table for `light` (-1: any two scene points)."""
+    """kyhip_scene_non_occluders (host only), per surface: 1 not in the occluder table for `light` (-1: rays that end on a scene point),
+    2 scanned only for rays with an end behind that light's plane, 0 always tested."""
     lib = A.load_kyhip()
     n = _scene_ptr(scene).contents.surface_count
     out = np.zeros(max(1, n), np.int32)
     rc = lib.kyhip_scene_non_occluders(_scene_ptr(scene), int(light), out.ctypes.data_as(C.c_void_p), n)
     if rc < 0:
         _check(rc)
-    return out[:n].astype(bool)
+    return out[:n].copy()
 
 
 def kat_li(scene, params, x, y, s0, n, device=0):

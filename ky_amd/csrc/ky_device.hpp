@@ -241,6 +241,14 @@ struct DScene {
     //                 wall's plane by more than the ray origin's offset (never for directional / environment lights).
     //  Spheres are in none of these tables: they are always tested.
     DTrav occ;
+    // Two-stage scan for shadow rays towards ONE planar area light (ts_light; -1: none): `occ` split by the plane n.x = k of the light's
+    // sampled shape into occ_front (everything not entirely in n.x <= k, plus the light's own surfaces) and occ_behind (the planar
+    // surfaces entirely in n.x <= k: what is mounted behind a lamp).  A segment has a point in that half-space only if one of its ends
+    // has; such rays overshoot the lamp (quirk 1) and the lamp itself stops nearly all of them, so occ_behind is scanned only for the
+    // few that are left, under a wave-uniform branch.
+    int32_t ts_light, ts_pad[3];
+    float ts_plane[4];
+    DTrav occ_front, occ_behind;
     DSph sph[KYHIP_MAX_SURFACES + 1];
     DSurf gen[KYHIP_MAX_SURFACES];
     DSurf all[KYHIP_MAX_SURFACES];      // every surface as a generic record, sorted order (carrier tests, surface-parallel queries)
@@ -492,14 +500,9 @@ KY_DEV int trace_nearest(SceneRef S, f3 o, f3 d, float& tmax) {
 
 // scene_t::occluded's traversal (3193-3195): any hit inside (eps, tmax) occludes.  `T_` (wave-uniform): the table of planar surfaces
 // to test -- S->trav (all), or the occluder table when the ray qualifies for it (DScene::occ).
-KY_DEV bool trace_any(SceneRef S, const DTrav& T_, f3 o, f3 d, float tmax) {
+KY_DEV bool trace_any_planar(const DTrav& T, f3 o, f3 d, float tmax) {
     bool occ = false;
-#ifdef KY_NO_OCCLUDER_CULL   // A/B measurements
-    const DTrav& T = S->trav;
-#else
-    const DTrav& T = T_;
-#endif
-    const int n_aar = T.n_aar, n_par = T.n_par, n_sph = S->n_sph, n_gen = S->n_gen;
+    const int n_aar = T.n_aar, n_par = T.n_par;
     const DAar* __restrict__ aar = T.aar;
     const DPar* __restrict__ par = T.par;
     float t;
@@ -519,6 +522,17 @@ KY_DEV bool trace_any(SceneRef S, const DTrav& T_, f3 o, f3 d, float tmax) {
             q0 = n0; q1 = n1; q2 = n2;
         }
     }
+    return occ;
+}
+KY_DEV bool trace_any(SceneRef S, const DTrav& T_, f3 o, f3 d, float tmax) {
+#ifdef KY_NO_OCCLUDER_CULL   // A/B measurements
+    const DTrav& T = S->trav;
+#else
+    const DTrav& T = T_;
+#endif
+    bool occ = trace_any_planar(T, o, d, tmax);
+    const int n_sph = S->n_sph, n_gen = S->n_gen;
+    float t;
     if (n_sph > 0) {
         float4 c = S->sph[0].c;
         for (int i = 0; i < n_sph; ++i) {
@@ -1163,6 +1177,26 @@ KY_DEV void sq_resolve(SceneRef S, ShadowQueue& q, int k, const SqSink& sink) {
 }
 
 // light-sampling half: by_emitter (3933-3962, MIS=false) and by_emitter_mis (4035-4074, MIS=true)
+// scene_t::occluded for a shadow ray towards a sample of light li (wave-uniform), through the occluder tables that apply to that light
+KY_DEV bool light_sample_occluded(SceneRef S, int li, f3 o, f3 dir, float tmax) {
+    const bool ok = S->light[li].occ_ok != 0;
+#if defined(KY_NO_TWO_STAGE) || defined(KY_NO_OCCLUDER_CULL)
+    return trace_any(S, ok ? S->occ : S->trav, o, dir, tmax);
+#else
+    const bool two = li == S->ts_light;
+    bool occ = trace_any(S, two ? S->occ_front : (ok ? S->occ : S->trav), o, dir, tmax);
+    if (two) {   // what is mounted behind the lamp: only a ray with an end in that half-space can meet it (DScene::occ_behind)
+        const f3 pn = mk3(S->ts_plane[0], S->ts_plane[1], S->ts_plane[2]);
+        const f3 e = o + dir * tmax;
+        const bool need = !occ && (fminf(dot(pn, e), dot(pn, o)) <= S->ts_plane[3]);
+        if (__any(need)) {
+            if (need) occ = trace_any_planar(S->occ_behind, o, dir, tmax);
+        }
+    }
+    return occ;
+#endif
+}
+
 template <bool MIS>
 KY_DEV f3 estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, int li, float u0, float u1) {
     const DLight& L = S->light[li];
@@ -1186,7 +1220,7 @@ KY_DEV f3 estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, 
 #if KY_ABL == 3
         const bool occ = o.x == 1e30f;   // never: the traversal's instructions removed, everything after it kept
 #else
-        const bool occ = trace_any(S, L.occ_ok ? S->occ : S->trav, o, dir, dist - 2e-3f);   // wave-uniform choice
+        const bool occ = light_sample_occluded(S, li, o, dir, dist - 2e-3f);
 #endif
         KY_CLK(6);
 #if KY_ABL == 4

@@ -476,7 +476,10 @@ __global__ void kat_occluded_kernel(const DScene* __restrict__ S, const float* _
     const f3 dir = normalize(target - p);
     const float dist = sqrtf(length_sq(p - target));
     const f3 o = offset_ray_origin(p, pn, dir);
-    out1[i] = trace_any(S, (table == -1 || (table >= 0 && S->light[table].occ_ok)) ? S->occ : S->trav, o, dir, dist - 2e-3f) ? 1.f : 0.f;
+    bool occ;
+    if (table >= 0) occ = light_sample_occluded(S, table, o, dir, dist - 2e-3f);
+    else occ = trace_any(S, table == -1 ? S->occ : S->trav, o, dir, dist - 2e-3f);
+    out1[i] = occ ? 1.f : 0.f;
 }
 
 template <bool DEBUG_SAMPLER>
@@ -697,6 +700,9 @@ struct NonOccluders {
     std::vector<char> wall;                  // [surface]
     std::vector<char> light_ok;              // [light]
     bool deferred_ok = false;                // all lights ok (the deferred shadow rays share one stack)
+    int ts_light = -1;                       // two-stage scan (DScene::occ_front / occ_behind): the light, its plane n.x = k, and
+    double ts_plane[4] = {0, 0, 0, 0};       // the surfaces that lie entirely in n.x <= k (not the light's own)
+    std::vector<char> ts_behind;             // [surface]
 };
 static void find_non_occluders(const ky_scene* in, NonOccluders& R) {
     const int ns = in->surface_count, nl = in->light_count;
@@ -766,6 +772,40 @@ static void find_non_occluders(const ky_scene* in, NonOccluders& R) {
     }
     R.deferred_ok = true;
     for (int l = 0; l < nl; ++l) R.deferred_ok = R.deferred_ok && R.light_ok[l];
+    // Two-stage scan: the first planar area light that may use `occ` and has rectangles mounted behind its plane.  The sampled shape's
+    // stored normal is the emitting side (2957-2960); k = the smallest n.q over the sampled points q, lowered by a rounding margin, so that
+    // "entirely in n.x <= k" is decided on the safe side both here and (end points, fp32) on the device.
+    R.ts_behind.assign(ns, 0);
+    for (int l = 0; l < nl && R.ts_light < 0; ++l) {
+        const ky_light& L = in->lights[l];
+        if (L.kind != KY_LIGHT_AREA || !R.light_ok[l]) continue;
+        const ky_shape& ls = in->shapes[L.shape];
+        if (ls.kind == KY_SHAPE_SPHERE) continue;
+        const double n[3] = {ls.normal[0], ls.normal[1], ls.normal[2]};
+        double k_min = inf, k_max = -inf;
+        if (ls.kind == KY_SHAPE_DISK) {
+            k_min = k_max = n[0] * ls.p[0][0] + n[1] * ls.p[0][1] + n[2] * ls.p[0][2];
+        } else if (ls.kind == KY_SHAPE_TRIANGLE) {
+            shape_extent(ls, n, k_min, k_max);
+        } else {   // rectangle_t samples p1 + (p0 - p1) u + (p2 - p1) v (1310): the parallelogram's fourth corner is p0 + p2 - p1
+            const double c0 = n[0] * ls.p[0][0] + n[1] * ls.p[0][1] + n[2] * ls.p[0][2], c1 = n[0] * ls.p[1][0] + n[1] * ls.p[1][1] + n[2] * ls.p[1][2],
+                         c2 = n[0] * ls.p[2][0] + n[1] * ls.p[2][1] + n[2] * ls.p[2][2];
+            k_min = std::min(std::min(c0, c1), std::min(c2, c0 + c2 - c1));
+        }
+        int count = 0;
+        std::vector<char> behind(ns, 0);
+        for (int y = 0; y < ns; ++y) {
+            const ky_shape& sh = shape_of(y);
+            if (sh.kind != KY_SHAPE_RECTANGLE || R.wall[y] || in->surfaces[y].shape == L.shape) continue;
+            double lo_y = inf, hi_y = -inf;
+            shape_extent(sh, n, lo_y, hi_y);
+            if (hi_y <= k_min) { behind[y] = 1; ++count; }
+        }
+        if (count == 0) continue;
+        R.ts_light = l;
+        R.ts_behind = behind;
+        R.ts_plane[0] = n[0]; R.ts_plane[1] = n[1]; R.ts_plane[2] = n[2]; R.ts_plane[3] = k_min;
+    }
 }
 
 static int pack_scene(const ky_scene* in, DScene* out) {
@@ -855,6 +895,19 @@ static int pack_scene(const ky_scene* in, DScene* out) {
     build_trav(out->trav, [](int) { return false; });
     build_trav(out->occ, [&](int i) { return non.wall[i] != 0; });
     out->occ_deferred_ok = non.deferred_ok ? 1 : 0;
+    out->ts_light = non.ts_light;
+    if (non.ts_light >= 0) {
+        build_trav(out->occ_front, [&](int i) { return non.wall[i] != 0 || non.ts_behind[i] != 0; });
+        build_trav(out->occ_behind, [&](int i) { return non.ts_behind[i] == 0; });
+        // a point x of a surface behind the plane has n.x <= k in exact arithmetic; the device evaluates n.x for a ray's ends in fp32:
+        // raise k by what that can be off (1e-5 of the scene's size is 100 ulp), so that a borderline end counts as "behind"
+        double size = 0;
+        for (int i = 0; i < in->surface_count; ++i)
+            for (int q = 0; q < 4; ++q)
+                for (int c = 0; c < 3; ++c) size = std::max(size, std::fabs((double)in->shapes[in->surfaces[i].shape].p[q][c]));
+        for (int c = 0; c < 3; ++c) out->ts_plane[c] = (float)non.ts_plane[c];
+        out->ts_plane[3] = (float)(non.ts_plane[3] + 1e-5 * (1.0 + size));
+    }
     for (int i = 0; i < in->material_count; ++i) {
         const ky_material& m = in->materials[i];
         if (m.kind < KY_MATERIAL_MATTE || m.kind > KY_MATERIAL_PLASTIC) return fail(KY_ERR_INVALID_VALUE, "material %d has an unknown kind", i);
@@ -1435,8 +1488,9 @@ int kyhip_scene_non_occluders(const ky_scene* scene, int light, int* left_out, i
     for (int j = 0; j < P.n_surfaces; ++j) {
         const int i = P.orig[j];
         const bool planar = P.all[j].kind == TK_PARALLELOGRAM;   // only these have records in the planar tables
-        left_out[i] = planar && non.wall[i] && (light < 0 || non.light_ok[light]);
-        count += left_out[i];
+        left_out[i] = (planar && non.wall[i] && (light < 0 || non.light_ok[light])) ? 1 : 0;
+        if (planar && light >= 0 && light == non.ts_light && non.ts_behind[i]) left_out[i] = 2;
+        count += left_out[i] == 1;
     }
     const DTrav& T = (light < 0 || non.light_ok[light]) ? P.occ : P.trav;
     if (count != P.trav.n_aar + P.trav.n_par - T.n_aar - T.n_par) return fail(KY_ERR_DEVICE, "internal: occluder table and classification disagree");

@@ -21,8 +21,9 @@ def test_classification_of_the_shipped_scenes(A, api):
     # the Cornell box: left, right, ceiling, floor, back wall have the whole scene on one side ...
     walls = [1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0]
     assert api.scene_non_occluders(S["cornell_area"]).astype(int).tolist() == walls
-    # ... for shadow rays towards the ceiling lamp as well: it hangs 2e-2 under the ceiling, more than the ray origin's offset
-    assert api.scene_non_occluders(S["cornell_area"], 0).astype(int).tolist() == walls
+    # ... for shadow rays towards the ceiling lamp as well (it hangs 2e-2 under the ceiling, more than the ray origin's offset); the
+    # lamp's four side panels lie behind its plane and are scanned only for rays that end there (2)
+    assert api.scene_non_occluders(S["cornell_area"], 0).astype(int).tolist() == [1, 1, 1, 1, 1, 0, 0, 2, 2, 2, 2, 0]
     for name in ("cornell_point", "cornell_direction", "cornell_environment"):
         assert api.scene_non_occluders(S[name]).astype(int).tolist() == [1, 1, 1, 1, 1, 0, 0]
     assert api.scene_non_occluders(S["cornell_point"], 0).astype(int).tolist() == [1, 1, 1, 1, 1, 0, 0]
@@ -70,7 +71,8 @@ def test_classification_rules(A, api):
     assert left_out([floor, ball_above], [make_light(A, A.LIGHT_POINT, (1, 1, 1), position=(0, 0, 0.011))], 0) == [1, 0]
     tri_light = [make_light(A, A.LIGHT_AREA, (1, 1, 1), shape=2)]
     assert left_out([floor, ball_above, tri_up, panel_above], tri_light) == [1, 0, 0, 0]
-    assert left_out([floor, ball_above, tri_up, panel_above], tri_light, 0) == [1, 0, 0, 0]
+    assert left_out([floor, ball_above, tri_up, panel_above], tri_light, 0) == [1, 0, 0, 2]      # mounted behind the triangle light's plane
+    assert left_out([floor, ball_above, tri_up, panel_across], tri_light, 0) == [1, 0, 0, 0]     # reaches in front of it
     lamp_on_floor = make_shape(A, A.SHAPE_RECTANGLE, [(-0.2, -0.2, 0), (0.2, -0.2, 0), (0.2, 0.2, 0), (-0.2, 0.2, 0)])
     on_floor = [make_light(A, A.LIGHT_AREA, (1, 1, 1), shape=2)]
     assert left_out([floor, ball_above, lamp_on_floor], on_floor) == [1, 0, 1]

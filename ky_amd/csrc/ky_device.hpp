@@ -164,11 +164,12 @@ struct DMat {  // ky_material, gathered per lane from LDS
     float c0[3];        // lambert albedo | mirror R | glass R; plastic: Kd / P_diff, the Lambert lobe's albedo (2667)
     int32_t kind;
     float c1[3];        // glass T; plastic: Ks
-    float eta;
-    float exponent, p_diffuse, p_specular;
+    float eta;          // glass: eta; plastic: 1 / (exponent + 1), the power of the Phong lobe's cos(theta) = u^(1/(n+1)) (2515)
+    float exponent, phong_pdf_norm, p_specular;   // phong_pdf_norm = (exponent + 1) / 2 pi (2549)
     int32_t exp_flags;  // bit 0: exponent is integral, bit 1: it is odd (sign of pow(negative, n))
     float cs[3];        // plastic: Ks / P_spec, the Phong lobe's colour (2665)
-    float inv_eta;      // glass: 1 / eta (`eta_i / eta_t` entering, 1977 / 2388: the same float division, done once on the host)
+    float inv_eta;      // glass: 1 / eta (`eta_i / eta_t` entering, 1977 / 2388: the same float division, done once on the host);
+                        // plastic: (exponent + 2) / 2 pi, the Phong lobe's normalisation (2505)
 };  // 64 B
 
 struct DLight {  // light_t + the shape an area light samples; wave-uniform index
@@ -623,8 +624,8 @@ KY_DEV void bsdf_eval_pdf(const Bsdf& B, f3 wo, f3 wi, f3& f, float& pdf) {
         const float pe = phong_pow(cos_alpha, exponent, B.m->exp_flags);
         const float p0 = exponent == 0.f ? 1.f : (exponent > 0.f ? 0.f : K_INF);
         const float pp = cos_alpha > 0.f ? pe : p0;
-        if (same) f = (ld3(B.m->cs) * ((exponent + 2.f) * K_INV_2PI)) * pe;
-        pdf = (exponent + 1.f) * pp * K_INV_2PI;
+        if (same) f = (ld3(B.m->cs) * B.m->inv_eta) * pe;   // (exponent + 2) / 2 pi
+        pdf = pp * B.m->phong_pdf_norm;                      // (exponent + 1) / 2 pi
     }
     // mirror / glass: eval 0, pdf 0 (2289-2290, 2352-2353)
 }
@@ -657,7 +658,7 @@ KY_DEV f3 bsdf_sample_dir_nondelta(const Bsdf& B, f3 wo, float u0, float u1) {
     float ang, rad, ct = 0.f;
     bool origin = false;
     if (phong) {
-        ct = pow_nonneg(u1, rcp(B.m->exponent + 1.f));
+        ct = pow_nonneg(u1, B.m->eta);                                     // 1 / (exponent + 1)
         rad = fsqrt(1.f - ct * ct);
         ang = u0;                                                          // phi = 2 pi u0, in revolutions
     } else {   // concentric_disk_sample, 710-733 (angles in revolutions: theta / 2 pi)

@@ -650,10 +650,15 @@ static int axis_aligned_rectangle(const ky_shape& sh, DAar* out) {
 static void pack_material(const ky_material& m, DMat* d) {
     std::memset(d, 0, sizeof *d);
     cp3(d->c0, m.color0); cp3(d->c1, m.color1);
-    d->kind = m.kind; d->eta = m.eta; d->exponent = m.exponent; d->p_diffuse = m.diffuse_probability; d->p_specular = m.specular_probability;
+    d->kind = m.kind; d->eta = m.eta; d->exponent = m.exponent; d->phong_pdf_norm = 0.f; d->p_specular = m.specular_probability;
     d->inv_eta = 1.f / m.eta;   // eta_i / eta_t entering the glass (fresnel_dielectric 1977, fresnel_specular 2388), in float like the reference
     if (m.kind == KY_MATERIAL_PLASTIC) {   // the two lobes' colours, plastic_material_t::scattering 2665 / 2667
         for (int j = 0; j < 3; ++j) { d->c0[j] = m.color0[j] / m.diffuse_probability; d->cs[j] = m.color1[j] / m.specular_probability; }
+        // the Phong lobe's constants, in float like the reference computes them per call (2505, 2515, 2549); eta / inv_eta are glass-only
+        const float inv_2pi = 0.15915494309189535f;
+        d->eta = 1.f / (m.exponent + 1.f);
+        d->inv_eta = (m.exponent + 2.f) * inv_2pi;
+        d->phong_pdf_norm = (m.exponent + 1.f) * inv_2pi;
     }
     const float e = m.exponent;
     const bool integral = std::isfinite(e) && std::fabs(e) < 16777216.f && std::floor(e) == e;

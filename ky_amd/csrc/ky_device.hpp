@@ -81,6 +81,9 @@ KY_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 KY_DEV float sin_rev(float x) { return __builtin_amdgcn_sinf(x); }  // sin(2 pi x)
 KY_DEV float cos_rev(float x) { return __builtin_amdgcn_cosf(x); }  // cos(2 pi x)
 KY_DEV float clamp01f(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 1.f); }
+// A value that is never read: what a variable holds on the paths that do not assign it.  (An explicit default would be a v_mov per
+// register at every level of nested divergent control flow; this is "any register content", which costs nothing.)
+KY_DEV float any_f() { float x; return __builtin_nondeterministic_value(x); }
 // x^n for x >= 0 (pow(0, n > 0) = 0, pow(x, 0) = 1)
 KY_DEV float pow_nonneg(float x, float n) { return n == 0.f ? 1.f : __builtin_amdgcn_exp2f(n * __builtin_amdgcn_logf(x)); }
 
@@ -91,6 +94,7 @@ struct f3 {
     float x, y, z;
 };
 KY_DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+KY_DEV f3 any3() { return f3{any_f(), any_f(), any_f()}; }
 KY_DEV f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 KY_DEV f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 KY_DEV f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }
@@ -687,7 +691,7 @@ KY_DEV f3 bsdf_sample_dir_nondelta(const Bsdf& B, f3 wo, float u0, float u1) {
 KY_DEV BsdfSample bsdf_sample_local(const Bsdf& B, f3 wo, float u0, float u1) {
     BsdfSample s;
     s.f = mk3(0, 0, 0);
-    s.wi = mk3(0, 0, 0);
+    s.wi = any3();   // read only where f and pdf are non-zero, and every such path sets it
     s.pdf = 0.f;
     s.flags = 0;
     if (B.lobe == LOBE_LAMBERT) {  // 2242-2257
@@ -891,22 +895,19 @@ KY_DEV float env_pdf(float wz) {
 
 // light_t::sample_Li x4 (2825, 2891, 2964, 3026)
 KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0, float u1) {
-    LightSample s;
-    s.position = mk3(0, 0, 0);
-    s.wi = mk3(0, 0, 0);
-    s.Li = mk3(0, 0, 0);
-    s.pdf = 0.f;
+    LightSample s;   // every kind (wave-uniform) assigns every field
     if (L.kind == KY_LIGHT_AREA) {
         f3 lposition, lnormal;
         shape_sample_direction(L, p, p_normal, u0, u1, lposition, lnormal, s.pdf);
         s.position = lposition;
         const f3 dv = lposition - p;
         const float d2 = length_sq(dv);
-        if (!(s.pdf == 0 || d2 == 0)) {
-            s.wi = dv * rsq(d2);
-            // areal_radiance(light_isect, -wi) with the SAMPLED (stored) normal: one-sided (quirk 5), 2957-2960
-            if (dot(lnormal, s.wi) < 0) s.Li = ld3(L.color);
-        }
+        const bool ok = !(s.pdf == 0 || d2 == 0);
+        const f3 wi = dv * rsq(d2);
+        s.wi = mk3(ok ? wi.x : 0.f, ok ? wi.y : 0.f, ok ? wi.z : 0.f);
+        // areal_radiance(light_isect, -wi) with the SAMPLED (stored) normal: one-sided (quirk 5), 2957-2960
+        const bool lit = ok && dot(lnormal, wi) < 0;
+        s.Li = mk3(lit ? L.color[0] : 0.f, lit ? L.color[1] : 0.f, lit ? L.color[2] : 0.f);
     } else if (L.kind == KY_LIGHT_POINT) {
         const f3 lp = ld3(L.position);
         const f3 dv = lp - p;
@@ -966,9 +967,11 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, int
     return Ld;
 #endif
     BsdfSample bs;
-    f3 f_cos = mk3(0, 0, 0), o = mk3(0, 0, 0), Li = mk3(0, 0, 0);
-    bs.wi = mk3(0, 0, 1);
-    bs.pdf = 0.f;
+    // what `live` guards: read at the end only for lanes whose sample counts (and, in the query loop, through __shfl from such lanes)
+    f3 f_cos = any3(), o = any3(), Li = mk3(0, 0, 0);
+    bs.wi = any3();
+    bs.f = any3();
+    bs.pdf = any_f();
     bool live = false;
     const bool fast = L.kind == KY_LIGHT_AREA && L.n_carriers >= 0 && S->n_gen == 0;  // wave-uniform
     if (fast) {
@@ -976,7 +979,7 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, int
         // lanes whose ray reaches a carrier that emits towards it -- for all other lanes Li = 0 decides the estimate (3996-4003).
         // (Delta lobes never get here: sample_all_light runs for non-delta vertices only, 4571.)
         const bool act = active && !bsdf_is_delta(v.bsdf);
-        f3 wi_l = mk3(0, 0, 1);
+        f3 wi_l = any3();
         if (act) {
             wi_l = bsdf_sample_dir_nondelta(v.bsdf, vertex_wo(v), u0, u1);
             bs.wi = to_world(vertex_frame(v), wi_l);  // 2176
@@ -1105,33 +1108,32 @@ KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, int li, fl
                                          unsigned tag, ShadowQueue& q) {
     const DLight& L = S->light[li];
     bool push = false;
-    f3 o = mk3(0, 0, 0), dir = mk3(0, 0, 1), C = mk3(0, 0, 0);
-    float tmax = 0.f;
+    f3 o = any3(), dir = any3(), C = any3();   // read by sq_push only for lanes that push
+    float tmax = any_f();
     if (active) {
+        // Straight-line from here: every lane runs every instruction and `push` says whether its values mean anything.  (Skipping the
+        // work of a dead sample would need ALL lanes of the wave dead; the nested version paid for its structure with defaults and
+        // exec-mask bookkeeping at every level instead.)
         const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1);
-        if (!(is_black(ls.Li) || ls.pdf <= 0)) {
-            f3 f;
-            float bsdf_pdf;
-            bsdf_eval_pdf(v.bsdf, vertex_wo(v), to_local(vertex_frame(v), ls.wi), f, bsdf_pdf);
-            const f3 f_cos = f * fabsf(dot(ls.wi, v.normal));
-            if (!is_black(f_cos)) {
-                const bool delta_light = L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION;
-                const f3 Ld = delta_light ? (f_cos * ls.Li) * rcp(ls.pdf) : (f_cos * ls.Li) * (2.f * rcp(ls.pdf + bsdf_pdf));   // 4057 / 4070
-                C = Ld * scale;
-                // scene_t::occluded(isect, ls.position), 3187-3201: the ray
-                const f3 to = ls.position - v.position;
-                const float d2 = length_sq(to);
-                const float inv_d = rsq(d2);
-                dir = to * inv_d;
-                tmax = d2 * inv_d - 2e-3f;
-                o = offset_ray_origin(v.position, v.normal, dir);
-                push = !(C.x == 0.f && C.y == 0.f && C.z == 0.f);
-                // the sampled shape itself is the likeliest occluder (quirk 1): one test here saves the ray a full traversal
-                if (push && L.kind == KY_LIGHT_AREA && L.sampled_is_surface) {
-                    float t;
-                    if (surf_hit(L.isect, S->full, o, dir, tmax, t, S.general)) push = false;
-                }
-            }
+        f3 f;
+        float bsdf_pdf;
+        bsdf_eval_pdf(v.bsdf, vertex_wo(v), to_local(vertex_frame(v), ls.wi), f, bsdf_pdf);
+        const f3 f_cos = f * fabsf(dot(ls.wi, v.normal));
+        const bool delta_light = L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION;
+        const f3 Ld = delta_light ? (f_cos * ls.Li) * rcp(ls.pdf) : (f_cos * ls.Li) * (2.f * rcp(ls.pdf + bsdf_pdf));   // 4057 / 4070
+        C = Ld * scale;
+        // scene_t::occluded(isect, ls.position), 3187-3201: the ray
+        const f3 to = ls.position - v.position;
+        const float d2 = length_sq(to);
+        const float inv_d = rsq(d2);
+        dir = to * inv_d;
+        tmax = d2 * inv_d - 2e-3f;
+        o = offset_ray_origin(v.position, v.normal, dir);
+        push = !(is_black(ls.Li) || ls.pdf <= 0) && !is_black(f_cos) && !(C.x == 0.f && C.y == 0.f && C.z == 0.f);
+        // the sampled shape itself is the likeliest occluder (quirk 1): one test here saves the ray a full traversal
+        if (L.kind == KY_LIGHT_AREA && L.sampled_is_surface) {   // wave-uniform
+            float t;
+            if (surf_hit(L.isect, S->full, o, dir, tmax, t, S.general)) push = false;
         }
     }
     sq_push(q, push, o, dir, tmax, C, tag);
@@ -1258,7 +1260,7 @@ KY_DEV f3 sample_all_light(SceneRef S, const LdsScene& Lds, const Vertex& v, Sam
     const int nl = S->n_lights;
     for (int li = 0; li < nl; ++li) {
         // the reference's GCC build draws random_bsdf first, then random_light (3866-3868), for every light and strategy
-        float ub0 = 0.f, ub1 = 0.f, ul0 = 0.f, ul1 = 0.f;
+        float ub0 = any_f(), ub1 = any_f(), ul0 = any_f(), ul1 = any_f();   // drawn, and read, by the active lanes only
         if (active) { ub0 = sampler_next<DEBUG_SAMPLER>(smp); ub1 = sampler_next<DEBUG_SAMPLER>(smp); }
         if (strategy == KY_DIRECT_BOTH_MIS) {  // 4076-4088
             KY_CLK(3);
@@ -1285,7 +1287,7 @@ KY_DEV f3 sample_all_light(SceneRef S, const LdsScene& Lds, const Vertex& v, Sam
         } else if (strategy == KY_DIRECT_BSDF) {
             const int lk = S->light[li].kind;
             if (!(lk == KY_LIGHT_POINT || lk == KY_LIGHT_DIRECTION)) {  // the third float2 is drawn after the delta test (3894-3900)
-                float u0 = 0.f, u1 = 0.f;
+                float u0 = any_f(), u1 = any_f();
                 if (active) { u0 = sampler_next<DEBUG_SAMPLER>(smp); u1 = sampler_next<DEBUG_SAMPLER>(smp); }
                 Lb = estimate_by_bsdf<false>(S, Lds, v, li, u0, u1, active);
             }

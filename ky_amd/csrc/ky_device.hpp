@@ -108,6 +108,15 @@ KY_DEV f3 normalize(f3 a) { return a * rsq(dot(a, a)); }  // vec3_t::normalize, 
 KY_DEV float max3(f3 a) { return fmaxf(a.x, fmaxf(a.y, a.z)); }
 KY_DEV bool is_black(f3 c) { return (c.x <= 0) && (c.y <= 0) && (c.z <= 0); }  // color_t::is_black, 258
 
+// One channel of a film sum -> what goes into the 32.32 fixed-point accumulator and into the pixel's flag word, without a branch:
+// NaN, +inf and -inf (or beyond the accumulator's range) set flag bits 1 << ch, 8 << ch, 64 << ch and add nothing.
+KY_DEV unsigned long long film_fixed(float a, int ch, unsigned& flags) {
+    const bool nan = a != a, pos = a > 2.0e9f, neg = a < -2.0e9f;
+    flags |= (nan ? 1u << ch : 0u) | (pos ? 8u << ch : 0u) | (neg ? 64u << ch : 0u);
+    const float b = (nan | pos | neg) ? 0.f : a;
+    return (unsigned long long)__double2ll_rn((double)b * 4294967296.0);
+}
+
 // float -> 32.32 fixed point (|a| <= 2e9): exact for |a| >= 2^-8, truncated below
 KY_DEV long long to_fixed32(float a) {
     const float aa = fabsf(a);

@@ -237,13 +237,8 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? KY_WAVES_PER_EU_QUEUE
                 unsigned fl = 0;
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
-                    const float a = v[ch];
-                    unsigned long long fx = 0;
-                    if (QUEUE) { fx = c_def[ch * 256 + tid]; c_def[ch * 256 + tid] = 0; }
-                    if (a != a) fl |= 1u << ch;               // NaN
-                    else if (a > 2.0e9f) fl |= 8u << ch;      // +inf (or beyond the accumulator's range)
-                    else if (a < -2.0e9f) fl |= 64u << ch;    // -inf
-                    else if (a != 0.f) fx += (unsigned long long)__double2ll_rn((double)a * KY_FIX_SCALE);
+                    unsigned long long fx = film_fixed(v[ch], ch, fl);   // NaN / +-inf: flag bits, nothing added
+                    if (QUEUE) { fx += c_def[ch * 256 + tid]; c_def[ch * 256 + tid] = 0; }
                     if (fx != 0) atomicAdd(&accum[(size_t)pix * 3 + ch], fx);
                 }
                 if (fl) atomicOr(&flags[pix], fl);

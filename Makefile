@@ -28,7 +28,14 @@ examples/bin/%: examples/%.cpp ky_amd/host/ky.hpp include/kyhip.h $(LIBDIR)/libk
 	@mkdir -p examples/bin
 	$(CXX) -O2 -std=c++17 -Wall -o $@ $< -L$(LIBDIR) -lkyhip -L$(ROCM)/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)' -Wl,-rpath,$(ROCM)/lib
 
+# the micro-benchmarks tools/final_profiles.sh runs (not part of `all`; build_variants/ is scratch that travels to the GPU box)
+UBENCH := $(patsubst tools/ubench/%.hip,build_variants/%,$(wildcard tools/ubench/*.hip))
+ubench: $(UBENCH)
+build_variants/%: tools/ubench/%.hip
+	@mkdir -p build_variants
+	$(HIPCC) --offload-arch=gfx950 -O2 -Wno-unused-value -o $@ $<
+
 clean:
 	rm -rf $(LIBDIR) examples/bin
 	$(MAKE) -C oracle clean
-.PHONY: all oracle examples clean
+.PHONY: all oracle examples ubench clean

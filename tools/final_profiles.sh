@@ -1,5 +1,5 @@
 #!/bin/bash
-# Regenerates the judged profile set of a round on the GPU box: tools/final_profiles.sh <prefix, e.g. r02_c>
+# Regenerates the judged profile set of a round on the GPU box: tools/final_profiles.sh <prefix, e.g. r02_c>   (after `make all ubench` here)
 # For each of three kernels -- render_kernel<false,48> (Cornell, configs[1]), the instantiation with deferred shadow rays
 # (Veach, configs[2]) and the run-time-dispatched render_kernel<false,-1> (Cornell, light_mis) -- five summaries: kernel trace +
 # stats, SQ issue counters, SQ instruction mix, FETCH_SIZE and WRITE_SIZE in separate pmc passes.  Then the bench lines.
@@ -23,8 +23,11 @@ run cornell --workload cornell
 run veach --workload veach --spp 1024
 run generic --workload cornell --direct-sample 32
 ./build_variants/valu_peak > gpurun_out/final/${P}_valu_peak_ubench.txt 2>&1
+./build_variants/valu_pk > gpurun_out/final/${P}_valu_pk_ubench.txt 2>&1
+./build_variants/salu_mix > gpurun_out/final/${P}_salu_mix_ubench.txt 2>&1
 python3 bench.py 2>/dev/null | tail -1 > gpurun_out/final/${P}_bench_line_cornell.json
 python3 bench.py --workload veach 2>/dev/null | tail -1 > gpurun_out/final/${P}_bench_line_veach.json
 python3 bench.py --workload batch 2>/dev/null | tail -1 > gpurun_out/final/${P}_bench_line_batch.json
 python3 bench.py --workload stress --steps 1 --warmup 0 2>/dev/null | tail -1 > gpurun_out/final/${P}_bench_line_stress.json
+python3 bench.py --workload cornell --direct-sample 32 2>/dev/null | tail -1 > gpurun_out/final/${P}_bench_line_cornell_light_mis.json
 ls -la gpurun_out/final | tail -40

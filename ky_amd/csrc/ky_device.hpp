@@ -1112,8 +1112,8 @@ KY_DEV void sq_push(ShadowQueue& q, bool push, f3 o, f3 d, float tmax, f3 c, uns
 // light-sampling half with the occlusion test deferred: by_emitter_mis (4035-4074) in the order sample -> BSDF value ->
 // weight -> [sampled shape's own hit] -> push; the reference's order (occlusion before the BSDF value) gives the same sum
 // because every factor is computed from the same inputs and a zero factor zeroes the term either way.
-// Wave-uniform call.  `scale` = throughput x strategy weight x 1 / spp: what multiplies this estimate in the pixel's sum.
-KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, int li, float u0, float u1, bool active, f3 scale,
+// Wave-uniform call.  beta x weight = throughput x strategy weight x 1 / spp: what multiplies this estimate in the pixel's sum.
+KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, int li, float u0, float u1, bool active, f3 beta, float weight,
                                          unsigned tag, ShadowQueue& q) {
     const DLight& L = S->light[li];
     bool push = false;
@@ -1130,7 +1130,7 @@ KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, int li, fl
         const f3 f_cos = f * fabsf(dot(ls.wi, v.normal));
         const bool delta_light = L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION;
         const f3 Ld = delta_light ? (f_cos * ls.Li) * rcp(ls.pdf) : (f_cos * ls.Li) * (2.f * rcp(ls.pdf + bsdf_pdf));   // 4057 / 4070
-        C = Ld * scale;
+        C = (Ld * beta) * weight;   // the product beta x weight is not kept in registers across the lights loop: three multiplies per light instead
         // scene_t::occluded(isect, ls.position), 3187-3201: the ray
         const f3 to = ls.position - v.position;
         const float d2 = length_sq(to);
@@ -1261,10 +1261,10 @@ KY_DEV f3 estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, 
 // `decisions` (KAT tracing only; a null constant everywhere else, which removes the code): bit li = the BSDF half of light li's
 // estimate was non-black, bit 16 + li = its light half.
 // `sq` (the QUEUE instantiation of the lane engine, strategy both_mis): the light-sampling halves are not returned but pushed on
-// the wave's shadow-ray stack with `scale` x 0.5 as their weight in the pixel's sum.
+// the wave's shadow-ray stack with beta x weight x 0.5 as their weight in the pixel's sum.
 template <bool DEBUG_SAMPLER>
 KY_DEV f3 sample_all_light(SceneRef S, const LdsScene& Lds, const Vertex& v, Sampler& smp, int strategy, bool active,
-                           unsigned* decisions = nullptr, ShadowQueue* sq = nullptr, f3 scale = f3{0, 0, 0}, unsigned tag = 0) {
+                           unsigned* decisions = nullptr, ShadowQueue* sq = nullptr, f3 beta = f3{0, 0, 0}, float weight = 0.f, unsigned tag = 0) {
     f3 Ld = mk3(0, 0, 0);
     const int nl = S->n_lights;
     for (int li = 0; li < nl; ++li) {
@@ -1278,7 +1278,7 @@ KY_DEV f3 sample_all_light(SceneRef S, const LdsScene& Lds, const Vertex& v, Sam
             f3 Ll = mk3(0, 0, 0);
             // random_light is drawn here, after the BSDF half: same stream position, two registers fewer across it
             if (active) { ul0 = sampler_next<DEBUG_SAMPLER>(smp); ul1 = sampler_next<DEBUG_SAMPLER>(smp); }
-            if (sq) estimate_by_emitter_deferred(S, v, li, ul0, ul1, active, scale * 0.5f, tag, *sq);
+            if (sq) estimate_by_emitter_deferred(S, v, li, ul0, ul1, active, beta, weight * 0.5f, tag, *sq);
             else if (active) Ll = estimate_by_emitter<true>(S, Lds, v, li, ul0, ul1);
             Ld = Ld + (0.5f * Lb + 0.5f * Ll);
             if (decisions && li < 16) *decisions |= (is_black(Lb) ? 0u : 1u << li) | (is_black(Ll) ? 0u : 1u << (16 + li));
@@ -1434,7 +1434,7 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, SceneRef S, const LdsScene& Lds
     KY_PROBE(6);
     unsigned decisions = 0;
     if (!simple) {  // simple_path_tracing_recursion_t samples the BSDF only
-        const f3 Ld = sample_all_light<DEBUG_SAMPLER>(S, Lds, v, ps.smp, rc.strategy, nee, tr ? &decisions : nullptr, sq, ps.beta * rc.inv_spp, tag);  // 4575 / 4337 / 4458
+        const f3 Ld = sample_all_light<DEBUG_SAMPLER>(S, Lds, v, ps.smp, rc.strategy, nee, tr ? &decisions : nullptr, sq, ps.beta, rc.inv_spp, tag);  // 4575 / 4337 / 4458
         if (nee) ps.Lo = ps.Lo + ps.beta * Ld;
     }
     KY_CLK(8);

@@ -11,6 +11,8 @@ What bench.py's `roofline.valu` reports, per kernel / workload, every figure rec
   issue_frac_2clk         against one wave64 VALU instruction per 2 clocks per SIMD at 2.4 GHz (the guide's figure)
   issue_frac_ubench       against what profiles/<prefix>_valu_peak_ubench.txt measures at 6 waves per SIMD for this kernel's mix of plain
                           and quarter-rate instructions (the ceiling this GPU actually reaches)
+  mix_model_ns,           what profiles/<prefix>_salu_mix_ubench.txt measures for a VALU stream with this kernel's SALU instructions per VALU
+  issue_frac_mix_model    instruction (interpolated), plus the quarter-rate surcharge of its VALU mix; and that figure over the kernel's
   wait_frac / stall_frac  SQ_WAIT_ANY, SQ_WAIT_INST_ANY over SQ_WAVE_CYCLES
   spill                   scratch bytes per lane of the dispatch, scratch loads / stores per launch, WRITE_SIZE
 """
@@ -54,9 +56,28 @@ def ubench(path):
     return res
 
 
+def salu_curve(path):
+    """ns per v_fmac slot at 6 waves/SIMD against SALU instructions per VALU instruction (tools/ubench/salu_mix.hip)"""
+    pts = {}
+    ratio = {"v_fmac alone": 0.0, "v_fmac + 1/8 SALU": 0.125, "v_fmac + 1/4 SALU": 0.25, "v_fmac + 1/2 SALU": 0.5, "v_fmac + 3/4 SALU": 0.75, "v_fmac + 1 SALU": 1.0}
+    for line in open(path):
+        m = re.match(r"(.+?)\s+waves/SIMD 6:.*?([0-9.]+) ns per slot", line)
+        if m and m.group(1).strip() in ratio:
+            pts[ratio[m.group(1).strip()]] = float(m.group(2))
+    return sorted(pts.items())
+
+
+def interpolate(curve, x):
+    for (x0, y0), (x1, y1) in zip(curve, curve[1:]):
+        if x0 <= x <= x1:
+            return y0 + (y1 - y0) * (x - x0) / (x1 - x0)
+    return curve[-1][1]
+
+
 def main():
     prefix = sys.argv[1]
     ub = ubench(os.path.join(PROF, prefix + "_valu_peak_ubench.txt"))
+    curve = salu_curve(os.path.join(PROF, prefix + "_salu_mix_ubench.txt"))
     plain, trans = ub["v_fmac_f32_e32 (VOP2, 3 vgpr)"], ub["v_rcp_f32"]
     valu, traffic = {}, None
     for wl in ("cornell", "veach", "generic"):
@@ -80,12 +101,15 @@ def main():
             "issue_frac_2clk": (2 / 2.4) / ns,
             "ubench_ceiling_ns": ceiling, "issue_frac_ubench": ceiling / ns,
             "quarter_rate_fraction": f_trans, "salu_per_valu": issue["SQ_INSTS_SALU"] / insts,
+            # what a v_fmac stream with this much scalar company reaches, plus what the kernel's quarter-rate instructions add to a plain stream
+            "mix_model_ns": interpolate(curve, issue["SQ_INSTS_SALU"] / insts) + (ceiling - plain),
+            "issue_frac_mix_model": (interpolate(curve, issue["SQ_INSTS_SALU"] / insts) + (ceiling - plain)) / ns,
             "wait_frac": issue["SQ_WAIT_ANY"] / issue["SQ_WAVE_CYCLES"], "stall_frac": issue["SQ_WAIT_INST_ANY"] / issue["SQ_WAVE_CYCLES"],
             "spill": {"scratch_bytes_per_lane": scratch, "scratch_loads_per_launch": mix["SQ_INSTS_VMEM_RD"], "scratch_stores_per_launch": mix["SQ_INSTS_VMEM_WR"],
                       "write_size_bytes_per_launch": write_b},
             "hbm_bytes_per_launch": fetch_b + write_b,
             "files": [os.path.basename(base) + s for s in ("kernel_stats.txt", "pmc_sq_issue.txt", "pmc_sq_mix.txt", "hbm_fetch_size.txt", "hbm_write_size.txt")]
-                     + [prefix + "_valu_peak_ubench.txt"],
+                     + [prefix + "_valu_peak_ubench.txt", prefix + "_salu_mix_ubench.txt"],
         }
         if wl == "cornell":
             traffic = {"_comment": "HBM traffic of ONE render_kernel launch of the bench workload from rocprofv3 --pmc (two separate passes; FETCH_SIZE / WRITE_SIZE are in "
@@ -98,8 +122,8 @@ def main():
     with open(os.path.join(PROF, "hbm_traffic.json"), "w") as fh:
         json.dump(traffic, fh, indent=1)
     for wl, v in valu.items():
-        print("%-8s %.1f VALU/sample  lanes %.3f  %.3f ns/instr/SIMD  issue %.2f of 2-clk, %.2f of ubench  wait %.2f stall %.2f  scratch %s B/lane  HBM %.2f GB/launch" % (
-            wl, v["wave_instr_per_sample"], v["lane_occupancy"], v["ns_per_valu_per_simd"], v["issue_frac_2clk"], v["issue_frac_ubench"], v["wait_frac"], v["stall_frac"],
+        print("%-8s %.1f VALU/sample  lanes %.3f  %.3f ns/instr/SIMD  issue %.2f of 2-clk, %.2f of ubench, %.2f of the VALU+SALU model (%.2f SALU/VALU)  wait %.2f stall %.2f  scratch %s B/lane  HBM %.2f GB/launch" % (
+            wl, v["wave_instr_per_sample"], v["lane_occupancy"], v["ns_per_valu_per_simd"], v["issue_frac_2clk"], v["issue_frac_ubench"], v["issue_frac_mix_model"], v["salu_per_valu"], v["wait_frac"], v["stall_frac"],
             v["spill"]["scratch_bytes_per_lane"], v["hbm_bytes_per_launch"] / 1e9))
 
 

@@ -773,8 +773,8 @@ static void find_non_occluders(const ky_scene* in, NonOccluders& R) {
     R.deferred_ok = true;
     for (int l = 0; l < nl; ++l) R.deferred_ok = R.deferred_ok && R.light_ok[l];
     // Two-stage scan: the first planar area light that may use `occ` and has rectangles mounted behind its plane.  The sampled shape's
-    // stored normal is the emitting side (2957-2960); k = the smallest n.q over the sampled points q, lowered by a rounding margin, so that
-    // "entirely in n.x <= k" is decided on the safe side both here and (end points, fp32) on the device.
+    // stored normal is the emitting side (2957-2960); k = the smallest n.q over the sampled points q.  "Entirely in n.x <= k" is decided
+    // here in exact arithmetic; the device, which evaluates n.x for a ray's ends in fp32, gets k raised by a margin (pack_scene).
     R.ts_behind.assign(ns, 0);
     for (int l = 0; l < nl && R.ts_light < 0; ++l) {
         const ky_light& L = in->lights[l];
@@ -881,7 +881,7 @@ static int pack_scene(const ky_scene* in, DScene* out) {
             ++j;
         }
     }
-    // the planar tables: every surface (trav: its order is the sorted surface order), and the occluder tables (DScene::occ, occ_light)
+    // the planar tables: every surface (trav: its order is the sorted surface order), and the occluder tables (DScene::occ, occ_front, occ_behind)
     auto build_trav = [&](DTrav& T, auto&& skip) {
         std::memset(&T, 0, sizeof T);
         for (const PlanarEntry& e : planar) {

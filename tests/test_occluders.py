@@ -167,3 +167,23 @@ def test_shadow_rays_towards_light_samples(A, api, O):
             seg = np.concatenate([p[:m], n[:m], tq], 1).astype(np.float32)
             full, culled = api.kat_occluded(room, seg), api.kat_occluded(room, seg, table=l)
             assert np.array_equal(full, culled), (seed, kinds, l, int((full != culled).sum()))
+
+
+def test_classification_entry_rejects_bad_arguments(A, api):
+    import ctypes as C
+    lib = A.load_kyhip()
+    scene = api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | A.CB_LIGHT_AREA, 64, 64)
+    with pytest.raises(api.KyError, match="out of range"):
+        api.scene_non_occluders(scene, light=1)                       # the scene has one light
+    with pytest.raises(api.KyError, match="out of range"):
+        api.scene_non_occluders(scene, light=-2)
+    out = (C.c_int32 * 4)()
+    assert lib.kyhip_scene_non_occluders(scene.flat, -1, out, 4) == A.KY_ERR_INVALID_VALUE        # room for 4 of 12 surfaces
+    assert b"12 surfaces" in lib.kyhip_last_error()
+    assert lib.kyhip_scene_non_occluders(None, -1, out, 4) == A.KY_ERR_INVALID_VALUE
+    assert lib.kyhip_scene_non_occluders(scene.flat, -1, None, 12) == A.KY_ERR_INVALID_VALUE
+    # a scene that does not validate is reported as such, not classified
+    bad = api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | A.CB_LIGHT_AREA, 64, 64)
+    bad.c.surfaces[3].material = 99
+    big = (C.c_int32 * 64)()
+    assert lib.kyhip_scene_non_occluders(bad.flat, -1, big, 64) == A.KY_ERR_INVALID_VALUE

@@ -260,7 +260,7 @@ struct DScene {
     // surfaces entirely in n.x <= k: what is mounted behind a lamp).  A segment has a point in that half-space only if one of its ends
     // has; such rays overshoot the lamp (quirk 1) and the lamp itself stops nearly all of them, so occ_behind is scanned only for the
     // few that are left, under a wave-uniform branch.
-    int32_t ts_light, ts_pad[3];
+    int32_t ts_light, single_area, ts_pad[2];   // single_area: SceneRef::single_area holds for this scene (host: pack_scene)
     float ts_plane[4];
     DTrav occ_front, occ_behind;
     DSph sph[KYHIP_MAX_SURFACES + 1];
@@ -280,8 +280,10 @@ struct DScene {
 struct SceneRef {
     const DScene* p;
     bool general;
-    __device__ __forceinline__ SceneRef(const DScene* p_) : p(p_), general(true) {}
-    __device__ __forceinline__ SceneRef(const DScene* p_, bool general_) : p(p_), general(general_) {}
+    bool single_area;   // the scene's lights are exactly ONE area light (no environment light): the other light kinds' code, the environment
+                        // term and the lights loop fold away -- every Cornell-box configuration of BASELINE.json; false: nothing is assumed
+    __device__ __forceinline__ SceneRef(const DScene* p_) : p(p_), general(true), single_area(false) {}
+    __device__ __forceinline__ SceneRef(const DScene* p_, bool general_, bool single_area_ = false) : p(p_), general(general_), single_area(single_area_) {}
     __device__ __forceinline__ const DScene* operator->() const { return p; }
 };
 
@@ -903,9 +905,9 @@ KY_DEV float env_pdf(float wz) {
 }
 
 // light_t::sample_Li x4 (2825, 2891, 2964, 3026)
-KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0, float u1) {
+KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0, float u1, bool area_only = false) {
     LightSample s;   // every kind (wave-uniform) assigns every field
-    if (L.kind == KY_LIGHT_AREA) {
+    if (area_only || L.kind == KY_LIGHT_AREA) {
         f3 lposition, lnormal;
         shape_sample_direction(L, p, p_normal, u0, u1, lposition, lnormal, s.pdf);
         s.position = lposition;
@@ -940,8 +942,8 @@ KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0,
 }
 
 // light_t::pdf_Li x4 (2855, 2903, 2984, 3043)
-KY_DEV float light_pdf_Li(const DLight& L, const DShapeFull* __restrict__ full, f3 p, f3 p_normal, f3 wi, bool general = true) {
-    if (L.kind == KY_LIGHT_AREA) return shape_pdf_direction(L, full, p, p_normal, wi, general);
+KY_DEV float light_pdf_Li(const DLight& L, const DShapeFull* __restrict__ full, f3 p, f3 p_normal, f3 wi, bool general = true, bool area_only = false) {
+    if (area_only || L.kind == KY_LIGHT_AREA) return shape_pdf_direction(L, full, p, p_normal, wi, general);
     if (L.kind == KY_LIGHT_ENVIRONMENT) return env_pdf(wi.z);
     return 0;
 }
@@ -971,7 +973,7 @@ template <bool MIS>
 KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, int li, float u0, float u1, bool active) {
     const DLight& L = S->light[li];
     f3 Ld = mk3(0, 0, 0);
-    if (L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION) return Ld;  // light.is_delta(), 3894 / 3977 (wave-uniform)
+    if (!S.single_area && (L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION)) return Ld;  // light.is_delta(), 3894 / 3977 (wave-uniform)
 #if KY_ABL == 1 || KY_ABL == 7   // measurement builds only (tools/ablate_pmc.sh): this estimator's instructions removed
     return Ld;
 #endif
@@ -982,7 +984,7 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, int
     bs.f = any3();
     bs.pdf = any_f();
     bool live = false;
-    const bool fast = L.kind == KY_LIGHT_AREA && L.n_carriers >= 0 && S->n_gen == 0;  // wave-uniform
+    const bool fast = (S.single_area || L.kind == KY_LIGHT_AREA) && L.n_carriers >= 0 && S->n_gen == 0;  // wave-uniform
     if (fast) {
         // Only the DIRECTION is sampled up front; the BSDF value and pdf (a pow for the Phong lobe) are evaluated for the few
         // lanes whose ray reaches a carrier that emits towards it -- for all other lanes Li = 0 decides the estimate (3996-4003).
@@ -1059,13 +1061,13 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, int
                 const f3 hp = o + t * bs.wi;
                 Li = surface_emission(Lds, hs, hit_normal(Lds.hit[hs], hp, bs.wi), -bs.wi);
             }
-        } else if (live && L.kind == KY_LIGHT_ENVIRONMENT) {
+        } else if (live && !S.single_area && L.kind == KY_LIGHT_ENVIRONMENT) {
             Li = ld3(L.color);  // light.environmental_radiance(ray), 3918 / 4000
         }
     }
     if (live && !is_black(Li)) {
         if (MIS) {
-            const float light_pdf = light_pdf_Li(L, S->full, v.position, v.normal, bs.wi, S.general);
+            const float light_pdf = light_pdf_Li(L, S->full, v.position, v.normal, bs.wi, S.general, S.single_area);
             if (light_pdf > 0) Ld = (f_cos * Li) * (2.f * rcp(bs.pdf + light_pdf));  // 4028
         } else {
             Ld = (f_cos * Li) * rcp(bs.pdf);  // 3924
@@ -1217,7 +1219,7 @@ KY_DEV f3 estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, 
 #if KY_ABL == 2 || KY_ABL == 7
     return Ld;
 #endif
-    const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1);
+    const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1, S.single_area);
     const bool dead = is_black(ls.Li) || (MIS ? (ls.pdf <= 0) : (ls.pdf == 0));
     KY_CLK(5);
     if (!dead) {
@@ -1246,7 +1248,7 @@ KY_DEV f3 estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, 
             bsdf_eval_pdf(v.bsdf, vertex_wo(v), to_local(vertex_frame(v), ls.wi), f, bsdf_pdf);
             const f3 f_cos = f * fabsf(dot(ls.wi, v.normal));
             if (!is_black(f_cos)) {
-                const bool delta_light = L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION;
+                const bool delta_light = !S.single_area && (L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION);
                 if (!MIS || delta_light) Ld = (f_cos * ls.Li) * rcp(ls.pdf);          // 3956 / 4057
                 else Ld = (f_cos * ls.Li) * (2.f * rcp(ls.pdf + bsdf_pdf));            // 4070
             }
@@ -1266,7 +1268,7 @@ template <bool DEBUG_SAMPLER>
 KY_DEV f3 sample_all_light(SceneRef S, const LdsScene& Lds, const Vertex& v, Sampler& smp, int strategy, bool active,
                            unsigned* decisions = nullptr, ShadowQueue* sq = nullptr, f3 beta = f3{0, 0, 0}, float weight = 0.f, unsigned tag = 0) {
     f3 Ld = mk3(0, 0, 0);
-    const int nl = S->n_lights;
+    const int nl = S.single_area ? 1 : S->n_lights;
     for (int li = 0; li < nl; ++li) {
         // the reference's GCC build draws random_bsdf first, then random_light (3866-3868), for every light and strategy
         float ub0 = any_f(), ub1 = any_f(), ul0 = any_f(), ul1 = any_f();   // drawn, and read, by the active lanes only
@@ -1358,7 +1360,7 @@ KY_DEV bool path_intersect(PathState& ps, Vertex& v, SceneRef S, const LdsScene&
         emission = surface_emission(Lds, hs, v.normal, -ps.d);
     }
 
-    const f3 env = S->env_light >= 0 ? ld3(S->light[S->env_light].color) : mk3(0, 0, 0);  // environment_lighting, 3231
+    const f3 env = (!S.single_area && S->env_light >= 0) ? ld3(S->light[S->env_light].color) : mk3(0, 0, 0);  // environment_lighting, 3231
     if (rc.integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION || rc.integrator == KY_INTEGRATOR_DIRECT_LIGHTING ||
         rc.integrator == KY_INTEGRATOR_PATH_TRACING_RECURSION_DEFERED) {
         if (ps.bounces == 0 || ps.prev_specular) ps.Lo = ps.Lo + ps.beta * (hit ? emission : env);  // 4548-4559 / 4449-4452

@@ -177,12 +177,15 @@ struct ItemSlot {  // one fetched work item, decoded once (wave-uniform) and rea
 // QUEUE (with STRATEGY = both_mis): the light-sampling halves' shadow rays are deferred to the wave's stack `queue_mem`
 // (ky_device.hpp, "deferred shadow rays") and traced 64 at a time.
 // GENERAL: the scene may hold quads that are not parallelograms, triangles or disks (SceneRef::general); no shipped scene does.
-template <bool DEBUG_SAMPLER, int STRATEGY, bool QUEUE = false, bool GENERAL = false>
+// SINGLE_AREA: the scene's lights are exactly one area light and no environment light (SceneRef::single_area): every Cornell-box
+// configuration of BASELINE.json.  Instantiated for the strategy-specialised kernel only.
+template <bool DEBUG_SAMPLER, int STRATEGY, bool QUEUE = false, bool GENERAL = false, bool SINGLE_AREA = false>
 __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? KY_WAVES_PER_EU_QUEUE : KY_WAVES_PER_EU) : KY_WAVES_PER_EU_GENERIC) void render_kernel(const DScene* __restrict__ S_, RenderConst rc, ShardConst sh,
                                                                      unsigned* __restrict__ counter, unsigned long long* __restrict__ accum,
                                                                      unsigned* __restrict__ flags, float* __restrict__ queue_mem) {
     static_assert(!QUEUE || STRATEGY == KY_DIRECT_BOTH_MIS, "the deferred shadow rays are built into the both_mis instantiation");
-    const SceneRef S{S_, GENERAL};
+    static_assert(!SINGLE_AREA || (STRATEGY == KY_DIRECT_BOTH_MIS && !QUEUE && !GENERAL && !DEBUG_SAMPLER), "one instantiation carries the single-area-light specialisation");
+    const SceneRef S{S_, GENERAL, SINGLE_AREA};
     __shared__ LdsScene Lds;
     __shared__ ItemSlot ring[4][KY_RING];
     // the lane's pixel chunk (touched when a path starts or ends, not while a vertex is shaded) lives in LDS, not in registers
@@ -808,6 +811,17 @@ static void find_non_occluders(const ky_scene* in, NonOccluders& R) {
     }
 }
 
+// Scene-specialised instantiations (today: SINGLE_AREA) can be switched off: KYHIP_SPECIALISE=0 or kyhip_set_specialisation(0).  The image
+// does not depend on it (tests/test_configs_gpu.py); the switch exists for that test and for A/B measurements.
+static int g_specialise = -1;
+static bool specialisation_enabled() {
+    if (g_specialise < 0) {
+        const char* e = std::getenv("KYHIP_SPECIALISE");
+        g_specialise = (e && std::atoi(e) == 0) ? 0 : 1;
+    }
+    return g_specialise != 0;
+}
+
 static int pack_scene(const ky_scene* in, DScene* out) {
     if (!in) return fail(KY_ERR_INVALID_VALUE, "scene is NULL");
     if (in->surface_count < 0 || in->shape_count < 0 || in->material_count < 0 || in->light_count < 0)
@@ -896,6 +910,7 @@ static int pack_scene(const ky_scene* in, DScene* out) {
     build_trav(out->occ, [&](int i) { return non.wall[i] != 0; });
     out->occ_deferred_ok = non.deferred_ok ? 1 : 0;
     out->ts_light = non.ts_light;
+    out->single_area = (specialisation_enabled() && in->light_count == 1 && in->lights[0].kind == KY_LIGHT_AREA && in->environment_light < 0) ? 1 : 0;
     if (non.ts_light >= 0) {
         build_trav(out->occ_front, [&](int i) { return non.wall[i] != 0 || non.ts_behind[i] != 0; });
         build_trav(out->occ_behind, [&](int i) { return non.ts_behind[i] == 0; });
@@ -1028,6 +1043,11 @@ static int create_ctx(int device, DeviceCtx& c) {
     HIP_TRY(hipEventCreateWithFlags(&c.busy, hipEventDisableTiming));
     HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[0], render_kernel<false, KY_DIRECT_BOTH_MIS>, 256, 0));
+    {   // the single-area-light instantiation shares slot 0: same launch bounds, and the grid must fit both
+        int sa = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&sa, (render_kernel<false, KY_DIRECT_BOTH_MIS, false, false, true>), 256, 0));
+        c.blocks_per_cu[0] = std::min(c.blocks_per_cu[0], sa);
+    }
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[1], render_kernel<false, -1>, 256, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[2], render_kernel<true, -1>, 256, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[3], (render_kernel<false, KY_DIRECT_BOTH_MIS, true>), 256, 0));
@@ -1151,6 +1171,11 @@ int kyhip_set_engine(int engine) {
     if (engine == KY_ENGINE_LANE || engine == KY_ENGINE_QUEUE) g_engine = engine;
     return prev;
 }
+int kyhip_set_specialisation(int on) {
+    const int prev = specialisation_enabled() ? 1 : 0;
+    if (on == 0 || on == 1) g_specialise = on;
+    return prev;
+}
 int kyhip_abi_version(void) { return KYHIP_ABI_VERSION; }
 int kyhip_device_count(void) {
     int n = 0;
@@ -1241,7 +1266,8 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
         if (grid > need_blocks) grid = need_blocks;
         if (grid < 1) grid = 1;
         float* const no_queue = nullptr;
-        if (variant == 0) hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_BOTH_MIS>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);
+        if (variant == 0 && c->h_scene->single_area) hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_BOTH_MIS, false, false, true>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);
+        else if (variant == 0) hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_BOTH_MIS>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);
         else if (variant == 1 && !general) hipLaunchKernelGGL((render_kernel<false, -1>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);
         else if (variant == 1) hipLaunchKernelGGL((render_kernel<false, -1, false, true>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);
         else if (variant == 2 && !general) hipLaunchKernelGGL((render_kernel<true, -1>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);

@@ -265,3 +265,27 @@ def test_c2_headline_frame_through_the_cpp_driver(A, api, O, tmp_path):
     assert "Msamples/s" in out
     got = open(tmp_path / "lighting_enum.bmp", "rb").read()
     assert got == FW.bmp_bytes(api.render(scene, params))
+
+
+def test_single_area_light_instantiation_changes_nothing(A, api, O):
+    """Scenes whose lights are exactly one area light run a render kernel compiled without the other light kinds, the environment term
+    and the lights loop (SceneRef::single_area).  Same arithmetic, same random streams: the image must be the same BITS as the general
+    instantiation's (kyhip_set_specialisation switches between them), here on the two Cornell geometries and a custom room."""
+    lib = A.load_kyhip()
+    from test_random_scenes_gpu import random_room
+    scenes = [(api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | A.CB_LIGHT_AREA, 96, 72), 96, 72),
+              (api.cornell_box_scene(A.CB_DEFAULT_SCENE, 64, 64), 64, 64)]
+    room, kinds = random_room(A, api, O, 4242 + 8, False, 48, 40)       # room 8: a rectangle light and a point light -> not specialised, still equal
+    scenes.append((room, 48, 40))
+    prev = lib.kyhip_set_specialisation(1)
+    try:
+        for scene, w, h in scenes:
+            for depth in (5, 16):
+                p = api.make_params(w, h, 96, max_path_depth=depth, tile_w=16, tile_h=8)
+                lib.kyhip_set_specialisation(1)
+                on = api.render(scene, p)
+                lib.kyhip_set_specialisation(0)
+                off = api.render(scene, p)
+                assert on.mean() > 0.01 and np.array_equal(on, off)
+    finally:
+        lib.kyhip_set_specialisation(prev)

@@ -24,7 +24,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
 SAMPLES = {"cornell": 1024 * 768 * 1024, "veach": 1280 * 720 * 1024, "generic": 1024 * 768 * 1024}
-LABEL = {"cornell": "render_kernel<false,48> on BASELINE configs[1] (Cornell 1024x768x1024)",
+LABEL = {"cornell": "render_kernel<false,48,false,false,SINGLE_AREA> on BASELINE configs[1] (Cornell 1024x768x1024)",
          "veach": "render_kernel<false,48,QUEUE> on configs[2]'s scene at 1024 spp (Veach 1280x720)",
          "generic": "render_kernel<false,-1> (strategy read at run time) on configs[1]'s scene with direct_sample light_mis"}
 

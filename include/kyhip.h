@@ -186,9 +186,12 @@ const char* kyhip_last_error(void);
    images differ by float summation order only.  The default is read from the environment variable KYHIP_ENGINE
    ("lane" / "queue").  Returns the previous engine.  Not part of the reference's interface: a tuning knob. */
 int         kyhip_set_engine(int engine);
-/* Scene-specialised kernel instantiations (a scene whose lights are exactly one area light runs a render kernel without the other
-   light kinds' code, the environment term and the lights loop) on = 1 (default; environment variable KYHIP_SPECIALISE=0 turns them
-   off) / off = 0.  The image does not depend on it.  Returns the previous setting.  A tuning knob, like kyhip_set_engine. */
+/* Specialised kernel instantiations -- a scene lit by exactly one rectangle area light runs a both_mis kernel compiled without the
+   other light kinds, the environment term, the lights loop and the other light shapes' sampling; each of the other five
+   direct-lighting strategies of the iterative integrator has its own kernel instead of the run-time-dispatched one -- on = 1 (default;
+   environment variable KYHIP_SPECIALISE=0 turns them off) / off = 0.  The image does not depend on it (to the last bit of a pixel: the
+   compiler contracts a few multiply-adds differently once code around them is gone).  Returns the previous setting.
+   A tuning knob, like kyhip_set_engine. */
 int         kyhip_set_specialisation(int on);
 int         kyhip_abi_version(void);
 int         kyhip_device_count(void);

@@ -260,7 +260,7 @@ struct DScene {
     // surfaces entirely in n.x <= k: what is mounted behind a lamp).  A segment has a point in that half-space only if one of its ends
     // has; such rays overshoot the lamp (quirk 1) and the lamp itself stops nearly all of them, so occ_behind is scanned only for the
     // few that are left, under a wave-uniform branch.
-    int32_t ts_light, single_area, ts_pad[2];   // single_area: SceneRef::single_area holds for this scene (host: pack_scene)
+    int32_t ts_light, feat, ts_pad[2];   // feat: the KY_FEAT_* facts that hold for this scene (host: pack_scene)
     float ts_plane[4];
     DTrav occ_front, occ_behind;
     DSph sph[KYHIP_MAX_SURFACES + 1];
@@ -277,14 +277,24 @@ struct DScene {
 // need the reference's own formulations (quads that are not parallelograms, triangles, disks: full_shape_hit, ~150 VALU and
 // the register peak of the whole kernel).  The hot instantiation of the render kernel is launched only for scenes without
 // them (every scene ky ships) and passes `false`, which removes that code; everything else converts from the bare pointer.
+// Compile-time facts about a scene (SceneRef::feat, a mask): what a render-kernel instantiation may assume, and so what code it does
+// not carry.  Code a scene never executes still costs it registers and instruction-cache space; each of these was measured
+// (DESIGN.md 3).  The host computes the scene's facts (pack_scene -> DScene::feat) and launches an instantiation whose assumptions
+// are a subset of them; 0 assumes nothing.
+enum : int {
+    KY_FEAT_SINGLE_AREA = 1,     // the lights are exactly ONE area light, no environment light: no other light kind's code, no environment term, no lights loop
+    KY_FEAT_RECT_LIGHTS = 2      // every area light samples a rectangle (the Cornell lamp): no sphere / triangle / disk light sampling
+};
+// (Measured and not kept: "every area light samples a sphere" + "no mirror or glass material" for the Veach scene: 11 fewer spilled
+// registers in the instantiation with deferred shadow rays, no change in time.)
 struct SceneRef {
     const DScene* p;
     bool general;
-    bool single_area;   // the scene's lights are exactly ONE area light (no environment light): the other light kinds' code, the environment
-                        // term and the lights loop fold away -- every Cornell-box configuration of BASELINE.json; false: nothing is assumed
-    __device__ __forceinline__ SceneRef(const DScene* p_) : p(p_), general(true), single_area(false) {}
-    __device__ __forceinline__ SceneRef(const DScene* p_, bool general_, bool single_area_ = false) : p(p_), general(general_), single_area(single_area_) {}
+    int feat;
+    __device__ __forceinline__ SceneRef(const DScene* p_) : p(p_), general(true), feat(0) {}
+    __device__ __forceinline__ SceneRef(const DScene* p_, bool general_, int feat_ = 0) : p(p_), general(general_), feat(feat_) {}
     __device__ __forceinline__ const DScene* operator->() const { return p; }
+    __device__ __forceinline__ bool single_area() const { return (feat & KY_FEAT_SINGLE_AREA) != 0; }
 };
 
 struct LdsScene {  // the per-workgroup LDS copy of the tables that are indexed per lane
@@ -811,8 +821,8 @@ KY_DEV f3 uniform_sphere_sample(float u0, float u1) {  // 761-769
 }
 
 // shape_t::sample_position x4 (1144, 1225, 1307, 1404); normals are the stored (unit) ones
-KY_DEV void shape_sample_position(const DLight& L, float u0, float u1, f3& position, f3& normal) {
-    if (L.shape_kind == KY_SHAPE_RECTANGLE) {
+KY_DEV void shape_sample_position(const DLight& L, float u0, float u1, f3& position, f3& normal, int feat = 0) {
+    if ((feat & KY_FEAT_RECT_LIGHTS) || L.shape_kind == KY_SHAPE_RECTANGLE) {
         position = ld3(L.p1) + ld3(L.e0) * u0 + ld3(L.e1) * u1;
         normal = ld3(L.n);
     } else if (L.shape_kind == KY_SHAPE_SPHERE) {
@@ -834,8 +844,8 @@ KY_DEV void shape_sample_position(const DLight& L, float u0, float u1, f3& posit
 }
 
 // shape_t::sample_direction (1028-1051) and sphere_t::sample_direction (1419-1501)
-KY_DEV void shape_sample_direction(const DLight& L, f3 p, f3 p_normal, float u0, float u1, f3& lposition, f3& lnormal, float& pdf) {
-    const bool sphere = L.shape_kind == KY_SHAPE_SPHERE;
+KY_DEV void shape_sample_direction(const DLight& L, f3 p, f3 p_normal, float u0, float u1, f3& lposition, f3& lnormal, float& pdf, int feat = 0) {
+    const bool sphere = (feat & KY_FEAT_RECT_LIGHTS) == 0 && L.shape_kind == KY_SHAPE_SPHERE;
     const f3 c = ld3(L.p1);
     const float dc2 = length_sq(p - c);
     if (sphere && !(dc2 <= L.radius * L.radius)) {
@@ -861,7 +871,7 @@ KY_DEV void shape_sample_direction(const DLight& L, f3 p, f3 p_normal, float u0,
         pdf = rcp(2 * K_PI * (1 - cos_theta_max));
         return;
     }
-    shape_sample_position(L, u0, u1, lposition, lnormal);
+    shape_sample_position(L, u0, u1, lposition, lnormal, feat);
     const f3 wv = lposition - p;
     const float d2 = length_sq(wv);
     if (d2 == 0) {
@@ -876,10 +886,11 @@ KY_DEV void shape_sample_direction(const DLight& L, f3 p, f3 p_normal, float u0,
 }
 
 // shape_t::pdf_direction (1055-1090) and sphere_t::pdf_direction (1503-1513)
-KY_DEV float shape_pdf_direction(const DLight& L, const DShapeFull* __restrict__ full, f3 p, f3 p_normal, f3 wi, bool general = true) {
+KY_DEV float shape_pdf_direction(const DLight& L, const DShapeFull* __restrict__ full, f3 p, f3 p_normal, f3 wi, bool general = true, int feat = 0) {
+    const bool sphere = (feat & KY_FEAT_RECT_LIGHTS) == 0 && L.shape_kind == KY_SHAPE_SPHERE;
     const f3 c = ld3(L.p1);
     const float dc2 = length_sq(p - c);
-    if (L.shape_kind == KY_SHAPE_SPHERE && !(dc2 <= L.radius * L.radius)) {
+    if (sphere && !(dc2 <= L.radius * L.radius)) {
         const float sin_theta_max_sq = L.radius * L.radius * rcp(dc2);
         const float cos_theta_max = fsqrt(fmaxf(0.f, 1 - sin_theta_max_sq));
         return rcp(2 * K_PI * (1 - cos_theta_max));  // uniform_cone_pdf, 798; never tests the hit (quirk 13)
@@ -890,7 +901,7 @@ KY_DEV float shape_pdf_direction(const DLight& L, const DShapeFull* __restrict__
     if (!surf_hit(L.isect, full, o, wi, K_INF, t, general)) return 0.f;
     const f3 hp = o + t * wi;
     f3 ln = ld3(L.n);
-    if (L.shape_kind == KY_SHAPE_SPHERE) ln = normalize(hp - c);
+    if (sphere) ln = normalize(hp - c);
     float pdf = length_sq(p - hp) * rcp(fabsf(dot(ln, wi)) * L.area);   // |dot| makes the ray-facing flip (1289) irrelevant
     if (isinf(pdf)) pdf = 0.f;
     return pdf;
@@ -905,11 +916,11 @@ KY_DEV float env_pdf(float wz) {
 }
 
 // light_t::sample_Li x4 (2825, 2891, 2964, 3026)
-KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0, float u1, bool area_only = false) {
+KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0, float u1, int feat = 0) {
     LightSample s;   // every kind (wave-uniform) assigns every field
-    if (area_only || L.kind == KY_LIGHT_AREA) {
+    if ((feat & KY_FEAT_SINGLE_AREA) || L.kind == KY_LIGHT_AREA) {
         f3 lposition, lnormal;
-        shape_sample_direction(L, p, p_normal, u0, u1, lposition, lnormal, s.pdf);
+        shape_sample_direction(L, p, p_normal, u0, u1, lposition, lnormal, s.pdf, feat);
         s.position = lposition;
         const f3 dv = lposition - p;
         const float d2 = length_sq(dv);
@@ -942,8 +953,8 @@ KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0,
 }
 
 // light_t::pdf_Li x4 (2855, 2903, 2984, 3043)
-KY_DEV float light_pdf_Li(const DLight& L, const DShapeFull* __restrict__ full, f3 p, f3 p_normal, f3 wi, bool general = true, bool area_only = false) {
-    if (area_only || L.kind == KY_LIGHT_AREA) return shape_pdf_direction(L, full, p, p_normal, wi, general);
+KY_DEV float light_pdf_Li(const DLight& L, const DShapeFull* __restrict__ full, f3 p, f3 p_normal, f3 wi, bool general = true, int feat = 0) {
+    if ((feat & KY_FEAT_SINGLE_AREA) || L.kind == KY_LIGHT_AREA) return shape_pdf_direction(L, full, p, p_normal, wi, general, feat);
     if (L.kind == KY_LIGHT_ENVIRONMENT) return env_pdf(wi.z);
     return 0;
 }
@@ -973,7 +984,7 @@ template <bool MIS>
 KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, int li, float u0, float u1, bool active) {
     const DLight& L = S->light[li];
     f3 Ld = mk3(0, 0, 0);
-    if (!S.single_area && (L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION)) return Ld;  // light.is_delta(), 3894 / 3977 (wave-uniform)
+    if (!S.single_area() && (L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION)) return Ld;  // light.is_delta(), 3894 / 3977 (wave-uniform)
 #if KY_ABL == 1 || KY_ABL == 7   // measurement builds only (tools/ablate_pmc.sh): this estimator's instructions removed
     return Ld;
 #endif
@@ -984,7 +995,7 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, int
     bs.f = any3();
     bs.pdf = any_f();
     bool live = false;
-    const bool fast = (S.single_area || L.kind == KY_LIGHT_AREA) && L.n_carriers >= 0 && S->n_gen == 0;  // wave-uniform
+    const bool fast = (S.single_area() || L.kind == KY_LIGHT_AREA) && L.n_carriers >= 0 && S->n_gen == 0;  // wave-uniform
     if (fast) {
         // Only the DIRECTION is sampled up front; the BSDF value and pdf (a pow for the Phong lobe) are evaluated for the few
         // lanes whose ray reaches a carrier that emits towards it -- for all other lanes Li = 0 decides the estimate (3996-4003).
@@ -1061,13 +1072,13 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, int
                 const f3 hp = o + t * bs.wi;
                 Li = surface_emission(Lds, hs, hit_normal(Lds.hit[hs], hp, bs.wi), -bs.wi);
             }
-        } else if (live && !S.single_area && L.kind == KY_LIGHT_ENVIRONMENT) {
+        } else if (live && !S.single_area() && L.kind == KY_LIGHT_ENVIRONMENT) {
             Li = ld3(L.color);  // light.environmental_radiance(ray), 3918 / 4000
         }
     }
     if (live && !is_black(Li)) {
         if (MIS) {
-            const float light_pdf = light_pdf_Li(L, S->full, v.position, v.normal, bs.wi, S.general, S.single_area);
+            const float light_pdf = light_pdf_Li(L, S->full, v.position, v.normal, bs.wi, S.general, S.feat);
             if (light_pdf > 0) Ld = (f_cos * Li) * (2.f * rcp(bs.pdf + light_pdf));  // 4028
         } else {
             Ld = (f_cos * Li) * rcp(bs.pdf);  // 3924
@@ -1125,7 +1136,7 @@ KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, int li, fl
         // Straight-line from here: every lane runs every instruction and `push` says whether its values mean anything.  (Skipping the
         // work of a dead sample would need ALL lanes of the wave dead; the nested version paid for its structure with defaults and
         // exec-mask bookkeeping at every level instead.)
-        const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1);
+        const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1, S.feat);
         f3 f;
         float bsdf_pdf;
         bsdf_eval_pdf(v.bsdf, vertex_wo(v), to_local(vertex_frame(v), ls.wi), f, bsdf_pdf);
@@ -1219,7 +1230,7 @@ KY_DEV f3 estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, 
 #if KY_ABL == 2 || KY_ABL == 7
     return Ld;
 #endif
-    const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1, S.single_area);
+    const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1, S.feat);
     const bool dead = is_black(ls.Li) || (MIS ? (ls.pdf <= 0) : (ls.pdf == 0));
     KY_CLK(5);
     if (!dead) {
@@ -1248,7 +1259,7 @@ KY_DEV f3 estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, 
             bsdf_eval_pdf(v.bsdf, vertex_wo(v), to_local(vertex_frame(v), ls.wi), f, bsdf_pdf);
             const f3 f_cos = f * fabsf(dot(ls.wi, v.normal));
             if (!is_black(f_cos)) {
-                const bool delta_light = !S.single_area && (L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION);
+                const bool delta_light = !S.single_area() && (L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION);
                 if (!MIS || delta_light) Ld = (f_cos * ls.Li) * rcp(ls.pdf);          // 3956 / 4057
                 else Ld = (f_cos * ls.Li) * (2.f * rcp(ls.pdf + bsdf_pdf));            // 4070
             }
@@ -1268,7 +1279,7 @@ template <bool DEBUG_SAMPLER>
 KY_DEV f3 sample_all_light(SceneRef S, const LdsScene& Lds, const Vertex& v, Sampler& smp, int strategy, bool active,
                            unsigned* decisions = nullptr, ShadowQueue* sq = nullptr, f3 beta = f3{0, 0, 0}, float weight = 0.f, unsigned tag = 0) {
     f3 Ld = mk3(0, 0, 0);
-    const int nl = S.single_area ? 1 : S->n_lights;
+    const int nl = S.single_area() ? 1 : S->n_lights;
     for (int li = 0; li < nl; ++li) {
         // the reference's GCC build draws random_bsdf first, then random_light (3866-3868), for every light and strategy
         float ub0 = any_f(), ub1 = any_f(), ul0 = any_f(), ul1 = any_f();   // drawn, and read, by the active lanes only
@@ -1360,7 +1371,7 @@ KY_DEV bool path_intersect(PathState& ps, Vertex& v, SceneRef S, const LdsScene&
         emission = surface_emission(Lds, hs, v.normal, -ps.d);
     }
 
-    const f3 env = (!S.single_area && S->env_light >= 0) ? ld3(S->light[S->env_light].color) : mk3(0, 0, 0);  // environment_lighting, 3231
+    const f3 env = (!S.single_area() && S->env_light >= 0) ? ld3(S->light[S->env_light].color) : mk3(0, 0, 0);  // environment_lighting, 3231
     if (rc.integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION || rc.integrator == KY_INTEGRATOR_DIRECT_LIGHTING ||
         rc.integrator == KY_INTEGRATOR_PATH_TRACING_RECURSION_DEFERED) {
         if (ps.bounces == 0 || ps.prev_specular) ps.Lo = ps.Lo + ps.beta * (hit ? emission : env);  // 4548-4559 / 4449-4452

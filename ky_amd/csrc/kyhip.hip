@@ -169,6 +169,8 @@ static ShardConst make_shard(const ky_render_params* p) {
 #define KY_WAVES_PER_EU_GENERIC 5   // strategy / integrator read at run time: more code alive at once, 96 VGPRs measured best
 #endif
 
+constexpr int KY_FEAT_CORNELL = KY_FEAT_SINGLE_AREA | KY_FEAT_RECT_LIGHTS;   // what the Cornell-lamp instantiation assumes
+
 struct ItemSlot {  // one fetched work item, decoded once (wave-uniform) and read per lane
     int x0, y0, pix0, s_begin, s_end;
 };
@@ -177,15 +179,15 @@ struct ItemSlot {  // one fetched work item, decoded once (wave-uniform) and rea
 // QUEUE (with STRATEGY = both_mis): the light-sampling halves' shadow rays are deferred to the wave's stack `queue_mem`
 // (ky_device.hpp, "deferred shadow rays") and traced 64 at a time.
 // GENERAL: the scene may hold quads that are not parallelograms, triangles or disks (SceneRef::general); no shipped scene does.
-// SINGLE_AREA: the scene's lights are exactly one area light and no environment light (SceneRef::single_area): every Cornell-box
-// configuration of BASELINE.json.  Instantiated for the strategy-specialised kernel only.
-template <bool DEBUG_SAMPLER, int STRATEGY, bool QUEUE = false, bool GENERAL = false, bool SINGLE_AREA = false>
+// FEAT: KY_FEAT_* facts the instantiation assumes about the scene (SceneRef::feat).  One set is instantiated, for the both_mis kernel:
+// one rectangle area light (every Cornell-box configuration of BASELINE.json).
+template <bool DEBUG_SAMPLER, int STRATEGY, bool QUEUE = false, bool GENERAL = false, int FEAT = 0>
 __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? KY_WAVES_PER_EU_QUEUE : KY_WAVES_PER_EU) : KY_WAVES_PER_EU_GENERIC) void render_kernel(const DScene* __restrict__ S_, RenderConst rc, ShardConst sh,
                                                                      unsigned* __restrict__ counter, unsigned long long* __restrict__ accum,
                                                                      unsigned* __restrict__ flags, float* __restrict__ queue_mem) {
     static_assert(!QUEUE || STRATEGY == KY_DIRECT_BOTH_MIS, "the deferred shadow rays are built into the both_mis instantiation");
-    static_assert(!SINGLE_AREA || (STRATEGY == KY_DIRECT_BOTH_MIS && !QUEUE && !GENERAL && !DEBUG_SAMPLER), "one instantiation carries the single-area-light specialisation");
-    const SceneRef S{S_, GENERAL, SINGLE_AREA};
+    static_assert(FEAT == 0 || (STRATEGY == KY_DIRECT_BOTH_MIS && !QUEUE && !GENERAL && !DEBUG_SAMPLER), "scene facts are instantiated for the both_mis kernel only");
+    const SceneRef S{S_, GENERAL, FEAT};
     __shared__ LdsScene Lds;
     __shared__ ItemSlot ring[4][KY_RING];
     // the lane's pixel chunk (touched when a path starts or ends, not while a vertex is shaded) lives in LDS, not in registers
@@ -811,7 +813,8 @@ static void find_non_occluders(const ky_scene* in, NonOccluders& R) {
     }
 }
 
-// Scene-specialised instantiations (today: SINGLE_AREA) can be switched off: KYHIP_SPECIALISE=0 or kyhip_set_specialisation(0).  The image
+// Specialised instantiations (scene facts KY_FEAT_*, and one kernel per direct-lighting strategy other than both_mis) can be switched
+// off: KYHIP_SPECIALISE=0 or kyhip_set_specialisation(0).  The image
 // does not depend on it (tests/test_configs_gpu.py); the switch exists for that test and for A/B measurements.
 static int g_specialise = -1;
 static bool specialisation_enabled() {
@@ -910,7 +913,14 @@ static int pack_scene(const ky_scene* in, DScene* out) {
     build_trav(out->occ, [&](int i) { return non.wall[i] != 0; });
     out->occ_deferred_ok = non.deferred_ok ? 1 : 0;
     out->ts_light = non.ts_light;
-    out->single_area = (specialisation_enabled() && in->light_count == 1 && in->lights[0].kind == KY_LIGHT_AREA && in->environment_light < 0) ? 1 : 0;
+    out->feat = 0;
+    if (specialisation_enabled()) {   // the KY_FEAT_* facts of this scene
+        if (in->light_count == 1 && in->lights[0].kind == KY_LIGHT_AREA && in->environment_light < 0) out->feat |= KY_FEAT_SINGLE_AREA;
+        bool rect = true;
+        for (int i = 0; i < in->light_count; ++i)
+            if (in->lights[i].kind == KY_LIGHT_AREA) rect = rect && in->shapes[in->lights[i].shape].kind == KY_SHAPE_RECTANGLE;
+        if (rect) out->feat |= KY_FEAT_RECT_LIGHTS;
+    }
     if (non.ts_light >= 0) {
         build_trav(out->occ_front, [&](int i) { return non.wall[i] != 0 || non.ts_behind[i] != 0; });
         build_trav(out->occ_behind, [&](int i) { return non.ts_behind[i] == 0; });
@@ -1043,9 +1053,14 @@ static int create_ctx(int device, DeviceCtx& c) {
     HIP_TRY(hipEventCreateWithFlags(&c.busy, hipEventDisableTiming));
     HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[0], render_kernel<false, KY_DIRECT_BOTH_MIS>, 256, 0));
-    {   // the single-area-light instantiation shares slot 0: same launch bounds, and the grid must fit both
+    {   // the Cornell-lamp instantiation and the other strategies' share slot 0: same launch bounds, and the grid must fit all
         int sa = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&sa, (render_kernel<false, KY_DIRECT_BOTH_MIS, false, false, true>), 256, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&sa, (render_kernel<false, KY_DIRECT_IDLE>), 256, 0)); c.blocks_per_cu[0] = std::min(c.blocks_per_cu[0], sa);
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&sa, (render_kernel<false, KY_DIRECT_BSDF>), 256, 0)); c.blocks_per_cu[0] = std::min(c.blocks_per_cu[0], sa);
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&sa, (render_kernel<false, KY_DIRECT_LIGHT>), 256, 0)); c.blocks_per_cu[0] = std::min(c.blocks_per_cu[0], sa);
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&sa, (render_kernel<false, KY_DIRECT_BSDF_MIS>), 256, 0)); c.blocks_per_cu[0] = std::min(c.blocks_per_cu[0], sa);
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&sa, (render_kernel<false, KY_DIRECT_LIGHT_MIS>), 256, 0)); c.blocks_per_cu[0] = std::min(c.blocks_per_cu[0], sa);
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&sa, (render_kernel<false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL>), 256, 0));
         c.blocks_per_cu[0] = std::min(c.blocks_per_cu[0], sa);
     }
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[1], render_kernel<false, -1>, 256, 0));
@@ -1237,9 +1252,13 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
     HIP_TRY(hipMemsetAsync(c->d_counter, 0, sizeof(unsigned), stream));
 
     // c->h_scene is the packed scene upload_scene has just compared / uploaded.  Scenes of parallelograms and spheres (every scene
-    // ky ships) run on instantiations without the general-shape code; the both_mis strategy has its own instantiation among those.
+    // ky ships) run on instantiations without the general-shape code; among those each direct-lighting strategy of the iterative
+    // integrator has its own (the run-time-dispatched kernel carries all six and the four other integrators: 11 000 instructions against
+    // 4 000-5 000, and one wave per SIMD fewer).
     const bool general = c->h_scene->general != 0;
-    int variant = dbg ? 2 : (p->direct_sample == KY_DIRECT_BOTH_MIS && p->integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION && !general ? 0 : 1);
+    // variant: 0 both_mis, 1 run-time dispatch, 2 debug sampler, 3 both_mis with deferred shadow rays, 4 one of the other five strategies (compiled in)
+    const bool iterative = p->integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION && !general && !dbg;
+    int variant = dbg ? 2 : (iterative ? (p->direct_sample == KY_DIRECT_BOTH_MIS ? 0 : (specialisation_enabled() ? 4 : 1)) : 1);
     // deferred shadow rays pay when a vertex has several light samples to resolve (ky_device.hpp); KYHIP_SHADOW_QUEUE=0 / 1 forces
     if (variant == 0 && current_engine() == KY_ENGINE_LANE && sh.n_pix < (1 << 26) && shadow_queue_wanted(scene->light_count)) {
         variant = 3;
@@ -1251,6 +1270,7 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
     HIP_TRY(hipEventRecord(c->ev0, stream));
     // the queue engine implements path_tracing_iteration_t; every other integrator runs on the lane engine
     if (current_engine() == KY_ENGINE_QUEUE && p->integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION) {
+        if (variant == 4) variant = 1;   // the queue engine has its own three instantiations: both_mis, run-time dispatch, debug sampler
         const int per_cu = c->q_blocks_per_cu[variant] > 0 ? c->q_blocks_per_cu[variant] : 1;
         unsigned grid = (unsigned)(c->cus * per_cu);
         const unsigned need_blocks = (unsigned)(((unsigned long long)sh.n_items * 64u + QE_SLOTS - 1) / QE_SLOTS);
@@ -1260,14 +1280,25 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
         else if (variant == 1) hipLaunchKernelGGL((render_kernel_q<false, -1>), dim3(grid), dim3(QE_THREADS), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags);
         else hipLaunchKernelGGL((render_kernel_q<true, -1>), dim3(grid), dim3(QE_THREADS), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags);
     } else {
-        const int per_cu = c->blocks_per_cu[variant] > 0 ? c->blocks_per_cu[variant] : 1;
+        const int slot = variant == 4 ? 0 : variant;   // the strategy instantiations share the both_mis kernel's launch bounds (and its slot)
+        const int per_cu = c->blocks_per_cu[slot] > 0 ? c->blocks_per_cu[slot] : 1;
         unsigned grid = (unsigned)(c->cus * per_cu);
         const unsigned need_blocks = sh.n_items / 4 + 1;
         if (grid > need_blocks) grid = need_blocks;
         if (grid < 1) grid = 1;
         float* const no_queue = nullptr;
-        if (variant == 0 && c->h_scene->single_area) hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_BOTH_MIS, false, false, true>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);
+        const int feat = c->h_scene->feat;   // an instantiation may run when the scene has every fact it assumes
+        if (variant == 0 && (feat & KY_FEAT_CORNELL) == KY_FEAT_CORNELL) hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);
         else if (variant == 0) hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_BOTH_MIS>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);
+        else if (variant == 4) {
+            switch (p->direct_sample) {   // valid_params has checked the value
+            case KY_DIRECT_IDLE: hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_IDLE>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue); break;
+            case KY_DIRECT_BSDF: hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_BSDF>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue); break;
+            case KY_DIRECT_LIGHT: hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_LIGHT>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue); break;
+            case KY_DIRECT_BSDF_MIS: hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_BSDF_MIS>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue); break;
+            default: hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_LIGHT_MIS>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue); break;
+            }
+        }
         else if (variant == 1 && !general) hipLaunchKernelGGL((render_kernel<false, -1>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);
         else if (variant == 1) hipLaunchKernelGGL((render_kernel<false, -1, false, true>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);
         else if (variant == 2 && !general) hipLaunchKernelGGL((render_kernel<true, -1>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);

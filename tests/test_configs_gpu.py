@@ -267,10 +267,12 @@ def test_c2_headline_frame_through_the_cpp_driver(A, api, O, tmp_path):
     assert got == FW.bmp_bytes(api.render(scene, params))
 
 
-def test_single_area_light_instantiation_changes_nothing(A, api, O):
-    """Scenes whose lights are exactly one area light run a render kernel compiled without the other light kinds, the environment term
-    and the lights loop (SceneRef::single_area).  Same arithmetic, same random streams: the image must be the same BITS as the general
-    instantiation's (kyhip_set_specialisation switches between them), here on the two Cornell geometries and a custom room."""
+def test_specialised_instantiations_change_nothing(A, api, O):
+    """A scene lit by one rectangle area light runs a both_mis kernel compiled without the other light kinds, the environment term, the
+    lights loop and the other light shapes (SceneRef::feat); the other five strategies of the iterative integrator have kernels of their
+    own instead of the run-time-dispatched one.  Same arithmetic, same random streams: the image must be the same either way
+    (kyhip_set_specialisation switches) -- the same bits for the strategy kernels, to the last bit of a pixel for the Cornell-lamp one --
+    here on the two Cornell geometries and a room with two lights, for all six strategies."""
     lib = A.load_kyhip()
     from test_random_scenes_gpu import random_room
     scenes = [(api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | A.CB_LIGHT_AREA, 96, 72), 96, 72),
@@ -280,12 +282,19 @@ def test_single_area_light_instantiation_changes_nothing(A, api, O):
     prev = lib.kyhip_set_specialisation(1)
     try:
         for scene, w, h in scenes:
-            for depth in (5, 16):
-                p = api.make_params(w, h, 96, max_path_depth=depth, tile_w=16, tile_h=8)
+            for depth, strategy in ((5, A.DIRECT_BOTH_MIS), (16, A.DIRECT_BOTH_MIS), (5, A.DIRECT_LIGHT_MIS), (5, A.DIRECT_BSDF_MIS), (5, A.DIRECT_LIGHT),
+                                    (5, A.DIRECT_BSDF), (5, A.DIRECT_IDLE)):
+                p = api.make_params(w, h, 96, max_path_depth=depth, direct_sample=strategy, tile_w=16, tile_h=8)
                 lib.kyhip_set_specialisation(1)
                 on = api.render(scene, p)
                 lib.kyhip_set_specialisation(0)
                 off = api.render(scene, p)
-                assert on.mean() > 0.01 and np.array_equal(on, off)
+                assert on.mean() > 0.01 or strategy == A.DIRECT_IDLE
+                if strategy == A.DIRECT_BOTH_MIS and scene is not room:
+                    # the Cornell-lamp instantiation: the same expressions, but with code removed around them the compiler contracts a
+                    # few multiply-adds differently -- the last bit of some pixels (measured: 6e-8 on 10 % of them)
+                    assert np.abs(on - off).max() <= 1.2e-7, (strategy, depth, np.abs(on - off).max())
+                else:
+                    assert np.array_equal(on, off), (strategy, depth)
     finally:
         lib.kyhip_set_specialisation(prev)

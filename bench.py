@@ -260,11 +260,14 @@ def main():
         achieved = launch_bytes / (kernel_total_ms * 1e-3) / 1e9
         tj = load_json("hbm_traffic.json")
         traffic = None
-        if tj and tj.get("workload") == args.workload and tj.get("samples_per_launch"):
+        if tj and tj.get("workload") == args.workload and tj.get("samples_per_launch") and frames[0].params.direct_sample == A.DIRECT_BOTH_MIS:
             traffic = tj["hbm_bytes_per_launch"] * (samples_per_step / world) / tj["samples_per_launch"]
         vj = load_json("valu.json")
-        valu = vj.get(args.workload) if vj else None
-        if valu is None and vj and args.workload in ("stress", "batch"):
+        both_mis = frames[0].params.direct_sample == A.DIRECT_BOTH_MIS
+        valu = vj.get(args.workload) if (vj and both_mis) else None
+        if vj and not both_mis and args.workload == "cornell" and frames[0].params.direct_sample == A.DIRECT_LIGHT_MIS:
+            valu = vj.get("light_mis")
+        if valu is None and vj and both_mis and args.workload in ("stress", "batch"):
             valu = dict(vj.get("cornell") or {}, note="counters of the cornell workload (same kernel, same scene family)")
         p0 = frames[0].params
         line = {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the judged profile set of a round on the GPU box: tools/final_profiles.sh <prefix, e.g. r02_c>   (after `make all ubench` here)
-# For each of three kernels -- render_kernel<false,48> (Cornell, configs[1]), the instantiation with deferred shadow rays
-# (Veach, configs[2]) and the run-time-dispatched render_kernel<false,-1> (Cornell, light_mis) -- five summaries: kernel trace +
+# For each of four kernels -- the both_mis instantiation for one rectangle light (Cornell, configs[1]), the one with deferred shadow
+# rays (Veach, configs[2]), the light_mis instantiation and the run-time-dispatched render_kernel<false,-1> (both Cornell, light_mis) -- five summaries: kernel trace +
 # stats, SQ issue counters, SQ instruction mix, FETCH_SIZE and WRITE_SIZE in separate pmc passes.  Then the bench lines.
 P=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -21,7 +21,10 @@ run() {  # tag, bench args...
 }
 run cornell --workload cornell
 run veach --workload veach --spp 1024
+run light_mis --workload cornell --direct-sample 32
+export KYHIP_SPECIALISE=0   # the run-time-dispatched kernel (what the recursive integrators and general scenes run on), on the same workload
 run generic --workload cornell --direct-sample 32
+unset KYHIP_SPECIALISE
 ./build_variants/valu_peak > gpurun_out/final/${P}_valu_peak_ubench.txt 2>&1
 ./build_variants/valu_pk > gpurun_out/final/${P}_valu_pk_ubench.txt 2>&1
 ./build_variants/salu_mix > gpurun_out/final/${P}_salu_mix_ubench.txt 2>&1

@@ -283,7 +283,9 @@ struct DScene {
 // are a subset of them; 0 assumes nothing.
 enum : int {
     KY_FEAT_SINGLE_AREA = 1,     // the lights are exactly ONE area light, no environment light: no other light kind's code, no environment term, no lights loop
-    KY_FEAT_RECT_LIGHTS = 2      // every area light samples a rectangle (the Cornell lamp): no sphere / triangle / disk light sampling
+    KY_FEAT_RECT_LIGHTS = 2,     // every area light samples a rectangle (the Cornell lamp): no sphere / triangle / disk light sampling
+    KY_FEAT_CARRIERS = 4         // every area light is carried by at most KY_MAX_CARRIERS surfaces and the scene has no general shapes: the
+                                 // BSDF-sampling estimators always take the carrier test, never the full traversal (estimate_by_bsdf)
 };
 // (Measured and not kept: "every area light samples a sphere" + "no mirror or glass material" for the Veach scene: 11 fewer spilled
 // registers in the instantiation with deferred shadow rays, no change in time.)
@@ -995,7 +997,7 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, int
     bs.f = any3();
     bs.pdf = any_f();
     bool live = false;
-    const bool fast = (S.single_area() || L.kind == KY_LIGHT_AREA) && L.n_carriers >= 0 && S->n_gen == 0;  // wave-uniform
+    const bool fast = (S.single_area() || L.kind == KY_LIGHT_AREA) && ((S.feat & KY_FEAT_CARRIERS) || (L.n_carriers >= 0 && S->n_gen == 0));  // wave-uniform
     if (fast) {
         // Only the DIRECTION is sampled up front; the BSDF value and pdf (a pow for the Phong lobe) are evaluated for the few
         // lanes whose ray reaches a carrier that emits towards it -- for all other lanes Li = 0 decides the estimate (3996-4003).

@@ -169,7 +169,7 @@ static ShardConst make_shard(const ky_render_params* p) {
 #define KY_WAVES_PER_EU_GENERIC 5   // strategy / integrator read at run time: more code alive at once, 96 VGPRs measured best
 #endif
 
-constexpr int KY_FEAT_CORNELL = KY_FEAT_SINGLE_AREA | KY_FEAT_RECT_LIGHTS;   // what the Cornell-lamp instantiation assumes
+constexpr int KY_FEAT_CORNELL = KY_FEAT_SINGLE_AREA | KY_FEAT_RECT_LIGHTS | KY_FEAT_CARRIERS;   // what the Cornell-lamp instantiation assumes
 
 struct ItemSlot {  // one fetched work item, decoded once (wave-uniform) and read per lane
     int x0, y0, pix0, s_begin, s_end;
@@ -974,6 +974,12 @@ static int pack_scene(const ky_scene* in, DScene* out) {
         }
     }
     if (out->n_gen > 0) out->general = 1;
+    if (specialisation_enabled() && !out->general) {   // KY_FEAT_CARRIERS needs the packed lights: carrier lists are built above
+        bool carriers = true;
+        for (int i = 0; i < in->light_count; ++i)
+            if (in->lights[i].kind == KY_LIGHT_AREA && out->light[i].n_carriers < 0) carriers = false;
+        if (carriers) out->feat |= KY_FEAT_CARRIERS;
+    }
     return KY_OK;
 }
 

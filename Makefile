@@ -12,7 +12,7 @@ LIBDIR   := ky_amd/lib
 
 all: $(LIBDIR)/libkyhip.so $(LIBDIR)/libkyhost.so oracle examples
 
-$(LIBDIR)/libkyhip.so: ky_amd/csrc/kyhip.hip ky_amd/csrc/ky_device.hpp ky_amd/csrc/ky_queue.hpp ky_amd/csrc/ky_smallpt.hpp include/kyhip.h
+$(LIBDIR)/libkyhip.so: ky_amd/csrc/kyhip.hip ky_amd/csrc/ky_device.hpp ky_amd/csrc/ky_queue.hpp ky_amd/csrc/ky_smallpt.hpp ky_amd/csrc/ky_measure.hpp include/kyhip.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ ky_amd/csrc/kyhip.hip
 

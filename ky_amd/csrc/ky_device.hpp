@@ -29,45 +29,12 @@
 
 #define KY_DEV __device__ __forceinline__
 
-// lane-utilisation probes (debug builds with -DKY_PROFILE_LANES): slot k counts active lanes, slot k+16 counts visits
-#ifdef KY_PROFILE_LANES
-__device__ unsigned long long g_lane_probe[32];
-#define KY_PROBE(k)                                                                                          \
-    do {                                                                                                     \
-        const unsigned long long m_ = __ballot(1);                                                           \
-        if ((int)__lane_id() == __ffsll((long long)m_) - 1) {                                                \
-            atomicAdd(&g_lane_probe[k], (unsigned long long)__popcll(m_));                                   \
-            atomicAdd(&g_lane_probe[(k) + 16], 1ull);                                                        \
-        }                                                                                                    \
-    } while (0)
+// KY_PROBE(k) / KY_CLK(k): lane-utilisation probes and phase clocks of measurement builds (ky_measure.hpp); nothing in product builds
+#if defined(KY_PROFILE_LANES) || defined(KY_PROFILE_CLOCKS) || defined(KY_MARKS)
+#include "ky_measure.hpp"
 #else
 #define KY_PROBE(k) do { } while (0)
-#endif
-
-// phase clocks (debug builds with -DKY_PROFILE_CLOCKS): KY_CLK(k) charges the wave's time since its previous mark to bucket k
-#ifdef KY_PROFILE_CLOCKS
-__device__ unsigned long long g_clk[16];
-__device__ __noinline__ void ky_clk_mark(int k) {
-    __shared__ unsigned long long last[16], acc[16][16];
-    const int w = threadIdx.x >> 6;
-    const unsigned long long m = __ballot(1);
-    if ((int)__lane_id() == __ffsll((long long)m) - 1) {
-        const unsigned long long t = __builtin_amdgcn_s_memtime();
-        if (k == -1) { for (int i = 0; i < 16; ++i) acc[w][i] = 0; }
-        else if (k == -2) { for (int i = 0; i < 16; ++i) atomicAdd(&g_clk[i], acc[w][i]); }
-        else acc[w][k] += t - last[w];
-        last[w] = __builtin_amdgcn_s_memtime();
-    }
-}
-#define KY_CLK(k) ky_clk_mark(k)
-#elif defined(KY_MARKS)   // listing aid: a comment in the assembly at every phase boundary (tools/static_profile.py --marks)
-#define KY_CLK(k) asm volatile("; KYMARK " #k)
-#else
 #define KY_CLK(k) do { } while (0)
-#endif
-
-#ifndef KY_ABL
-#define KY_ABL 0
 #endif
 
 namespace kyd {
@@ -176,7 +143,7 @@ struct DHit {  // what is needed once the nearest surface is known; gathered per
 struct DMat {  // ky_material, gathered per lane from LDS
     float c0[3];        // lambert albedo | mirror R | glass R; plastic: Kd / P_diff, the Lambert lobe's albedo (2667)
     int32_t kind;
-    float c1[3];        // glass T; plastic: Ks
+    float c1[3];        // glass T; plastic: cs (n + 2) / (n + 1), the Phong lobe's value / pdf per unit |cos| (bsdf_continue)
     float eta;          // glass: eta; plastic: 1 / (exponent + 1), the power of the Phong lobe's cos(theta) = u^(1/(n+1)) (2515)
     float exponent, phong_pdf_norm, p_specular;   // phong_pdf_norm = (exponent + 1) / 2 pi (2549)
     int32_t exp_flags;  // bit 0: exponent is integral, bit 1: it is odd (sign of pow(negative, n))
@@ -605,7 +572,19 @@ KY_DEV f3 to_local(const Frame& f, f3 w) { return {dot(f.s, w), dot(f.t, w), dot
 KY_DEV f3 to_world(const Frame& f, f3 l) { return f.s * l.x + f.t * l.y + f.n * l.z; }
 
 // ---------------------------------------------------------------------------------------------
-// BSDFs (ky.cpp:2092-2555), local shading frame
+// BSDFs (ky.cpp:2092-2555) -- evaluated in WORLD space.
+//
+// The reference carries wo and wi into the shading frame of the hit (bsdf_t::to_local, 2162-2186), works there, and
+// carries the sampled wi back.  Nothing a lobe computes depends on the frame's tangents except the ORIENTATION of the
+// sampled direction around the lobe's axis, so here a vertex keeps, once, the world-space basis its lobe samples in:
+//   Lambert   (a, b, c) = (s, t, n) of frame_t(n):  wi = to_world(frame, cosine_hemisphere_sample(u))   (2176, 737-743)
+//   Phong     the frame around the mirror direction wr (2533-2543), built in the shading frame exactly as the reference
+//             builds it and then carried to world space: a = to_world(frame, fr.s), b = to_world(frame, fr.t),
+//             c = to_world(frame, wr), fr = frame_t(wr)
+// and every sample of either lobe is  wi = a x + b y + c z  with (x, y, z) from the lobe's own mapping: one piece of code for the
+// lanes of both lobes instead of two run one after the other.  Values and pdfs need three cosines: n.wo, n.wi and -- for the Phong
+// lobe -- wr.wi = c.wi (for the Lambert lobe c = n, so c.wi IS n.wi).  The two delta lobes need no basis at all: reflect
+// and refract are frame-independent.  Results agree with the local-space formulation to rounding (tests/test_parity_gpu.py).
 // ---------------------------------------------------------------------------------------------
 enum : int { LOBE_LAMBERT = 0, LOBE_MIRROR = 1, LOBE_GLASS = 2, LOBE_PHONG = 3 };
 enum : int { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16 };
@@ -617,7 +596,6 @@ struct Bsdf {
     const DMat* m;
 };
 KY_DEV bool bsdf_is_delta(const Bsdf& B) { return B.lobe == LOBE_MIRROR || B.lobe == LOBE_GLASS; }
-KY_DEV f3 bsdf_a(const Bsdf& B) { return B.lobe == LOBE_PHONG ? ld3(B.m->cs) : ld3(B.m->c0); }   // lambert albedo | mirror R | glass R | phong Ks
 
 KY_DEV int pick_lobe(const DMat& M, float lobe_random) {
     if (M.kind == KY_MATERIAL_MIRROR) return LOBE_MIRROR;
@@ -636,29 +614,8 @@ KY_DEV float phong_pow(float base, float exponent, int exp_flags) {
     return (exp_flags & 2) ? -m : m;
 }
 
-// bsdf eval_ and pdf_ at one (wo, wi) pair
-KY_DEV void bsdf_eval_pdf(const Bsdf& B, f3 wo, f3 wi, f3& f, float& pdf) {
-    f = mk3(0, 0, 0);
-    pdf = 0.f;
-    const bool same = wo.z * wi.z > 0;  // same_hemisphere, 1921
-    if (B.lobe == LOBE_LAMBERT) {       // 2227-2240
-        if (same) { f = ld3(B.m->c0) * K_INV_PI; pdf = fabsf(wi.z) * K_INV_PI; }
-    } else if (B.lobe == LOBE_PHONG) {  // 2489-2508, 2545-2550; wr = reflect(wo, z) = (-wo.x, -wo.y, wo.z)
-        const float cos_alpha = wo.z * wi.z - wo.x * wi.x - wo.y * wi.y;
-        // eval: cos_alpha is not clamped (a negative base with an even integral exponent is positive);
-        // pdf: clamped at 0, no hemisphere test (quirk 6)
-        const float exponent = B.m->exponent;
-        const float pe = phong_pow(cos_alpha, exponent, B.m->exp_flags);
-        const float p0 = exponent == 0.f ? 1.f : (exponent > 0.f ? 0.f : K_INF);
-        const float pp = cos_alpha > 0.f ? pe : p0;
-        if (same) f = (ld3(B.m->cs) * B.m->inv_eta) * pe;   // (exponent + 2) / 2 pi
-        pdf = pp * B.m->phong_pdf_norm;                      // (exponent + 1) / 2 pi
-    }
-    // mirror / glass: eval 0, pdf 0 (2289-2290, 2352-2353)
-}
-
 struct BsdfSample {
-    f3 f, wi;
+    f3 f, wi;   // wi in world space
     float pdf;
     int flags;
 };
@@ -675,18 +632,105 @@ KY_DEV void concentric_disk(float u0, float u1, float& px, float& py) {
     py = origin ? 0.f : sin_rev(rev) * radius;
 }
 
-// The direction half of sample_ for the two non-delta lobes (their value and pdf are eval_ / pdf_ of that direction:
-// 2253-2254, 2526-2527), so that a caller that rarely needs the value can defer it (estimate_by_bsdf).
-KY_DEV f3 bsdf_sample_dir_nondelta(const Bsdf& B, f3 wo, float u0, float u1) {
-    // Both lobes place a point (rad cos, rad sin) on a circle and lift it: the cosine lobe by the concentric disk mapping (710-743), the
-    // Phong lobe by cos(theta) = u1^(1/(n+1)) around the mirror direction (2510-2524).  A wavefront holds vertices of both kinds, so the
-    // angle and the radius are computed per lobe and the two quarter-rate sin / cos are issued once for both.
-    const bool phong = B.lobe == LOBE_PHONG;
-    float ang, rad, ct = 0.f;
+// ---------------------------------------------------------------------------------------------
+// path vertex (isect_t, 642-690)
+// ---------------------------------------------------------------------------------------------
+struct LobeBasis {
+    f3 a, b, c;
+};
+// The lane engine keeps a vertex's lobe basis in LDS (read back where a direction is sampled or a Phong value is needed)
+// instead of in nine registers that would be live -- in practice: spilled to scratch memory -- across the whole lights loop.
+struct VertexLds {
+    float a[3][256], b[3][256], c[3][256];   // [component][thread of the workgroup]
+};
+__shared__ VertexLds g_vertex_lds;   // allocated only in kernels that set Vertex::in_lds
+struct Vertex {
+    float t;      // distance along the ray that found the vertex
+    f3 position, normal;
+    LobeBasis basis;   // used when !in_lds
+    Bsdf bsdf;
+    int surface;
+    bool in_lds = false;
+};
+KY_DEV void vertex_set_basis(Vertex& v, const LobeBasis& L) {
+    if (v.in_lds) {
+        const int i = threadIdx.x;
+        g_vertex_lds.a[0][i] = L.a.x; g_vertex_lds.a[1][i] = L.a.y; g_vertex_lds.a[2][i] = L.a.z;
+        g_vertex_lds.b[0][i] = L.b.x; g_vertex_lds.b[1][i] = L.b.y; g_vertex_lds.b[2][i] = L.b.z;
+        g_vertex_lds.c[0][i] = L.c.x; g_vertex_lds.c[1][i] = L.c.y; g_vertex_lds.c[2][i] = L.c.z;
+    } else {
+        v.basis = L;
+    }
+}
+KY_DEV LobeBasis vertex_basis(const Vertex& v) {
+    if (!v.in_lds) return v.basis;
+    const int i = threadIdx.x;
+    LobeBasis L;
+    L.a = mk3(g_vertex_lds.a[0][i], g_vertex_lds.a[1][i], g_vertex_lds.a[2][i]);
+    L.b = mk3(g_vertex_lds.b[0][i], g_vertex_lds.b[1][i], g_vertex_lds.b[2][i]);
+    L.c = mk3(g_vertex_lds.c[0][i], g_vertex_lds.c[1][i], g_vertex_lds.c[2][i]);
+    return L;
+}
+KY_DEV f3 vertex_basis_c(const Vertex& v) {
+    if (!v.in_lds) return v.basis.c;
+    const int i = threadIdx.x;
+    return mk3(g_vertex_lds.c[0][i], g_vertex_lds.c[1][i], g_vertex_lds.c[2][i]);
+}
+
+// The basis of a non-delta vertex (see the section comment).  wo = -ray.direction (3125), unit.
+KY_DEV LobeBasis make_lobe_basis(const Bsdf& B, f3 n, f3 wo) {
+    const Frame fr = make_frame(n);   // frame_t(isect.normal), 2100
+    LobeBasis L{fr.s, fr.t, n};
+    if (B.lobe == LOBE_PHONG) {       // 2533-2536: wr = reflect(wo, z) in the shading frame, frame_t(wr) there
+        const f3 wo_l = to_local(fr, wo);
+        const f3 wr = mk3(-wo_l.x, -wo_l.y, wo_l.z);   // unit because wo is
+        const Frame fl = make_frame(wr);
+        L.a = to_world(fr, fl.s); L.b = to_world(fr, fl.t); L.c = to_world(fr, wr);
+    }
+    return L;
+}
+// scattering + the vertex's basis: what an (active) lane does once per vertex after v.bsdf is known
+KY_DEV void vertex_prepare(Vertex& v, f3 wo) {
+    if (!bsdf_is_delta(v.bsdf)) vertex_set_basis(v, make_lobe_basis(v.bsdf, v.normal, wo));
+}
+
+// eval_ and pdf_ of the two non-delta lobes at one (wo, wi) pair, world space (2227-2240, 2489-2508, 2545-2550); the delta
+// lobes evaluate to 0 / 0 (2289-2290, 2352-2353).  abs_cos_i = |dot(wi, isect.normal)|, the factor every caller multiplies f by.
+KY_DEV void bsdf_eval_pdf(const Vertex& v, f3 wo, f3 wi, f3& f, float& pdf, float& abs_cos_i) {
+    const Bsdf& B = v.bsdf;
+    const float cos_o = dot(v.normal, wo), cos_i = dot(v.normal, wi);   // wo.z, wi.z of the shading frame
+    abs_cos_i = fabsf(cos_i);
+    f = mk3(0, 0, 0);
+    pdf = 0.f;
+    const bool same = cos_o * cos_i > 0;  // same_hemisphere, 1921
+    if (B.lobe == LOBE_LAMBERT) {
+        if (same) { f = ld3(B.m->c0) * K_INV_PI; pdf = abs_cos_i * K_INV_PI; }
+    } else if (B.lobe == LOBE_PHONG) {
+        const float cos_alpha = dot(vertex_basis_c(v), wi);   // dot(wr, wi), 2497
+        // eval: cos_alpha is not clamped (a negative base with an even integral exponent is positive);
+        // pdf: clamped at 0, no hemisphere test (quirk 6)
+        const float exponent = B.m->exponent;
+        const float pe = phong_pow(cos_alpha, exponent, B.m->exp_flags);
+        const float p0 = exponent == 0.f ? 1.f : (exponent > 0.f ? 0.f : K_INF);
+        const float pp = cos_alpha > 0.f ? pe : p0;
+        if (same) f = (ld3(B.m->cs) * B.m->inv_eta) * pe;   // (exponent + 2) / 2 pi
+        pdf = pp * B.m->phong_pdf_norm;                      // (exponent + 1) / 2 pi
+    }
+}
+
+// The direction half of sample_ for the two non-delta lobes, world space (their value and pdf are eval_ / pdf_ of that
+// direction: 2253-2254, 2526-2527), so that a caller that rarely needs the value can defer it (estimate_by_bsdf).
+// Both lobes place a point (rad cos, rad sin) on a circle and lift it: the cosine lobe by the concentric disk mapping (710-743), the
+// Phong lobe by cos(theta) = u1^(1/(n+1)) around the mirror direction (2510-2524).  A wavefront holds vertices of both kinds: the angle,
+// the radius and the height are computed per lobe, the two quarter-rate sin / cos and the combination with the basis are issued once.
+KY_DEV f3 bsdf_sample_dir_nondelta(const Vertex& v, f3 wo, float u0, float u1) {
+    const bool phong = v.bsdf.lobe == LOBE_PHONG;
+    const float cos_o = dot(v.normal, wo);
+    float ang, rad, z = any_f();
     bool origin = false;
     if (phong) {
-        ct = pow_nonneg(u1, B.m->eta);                                     // 1 / (exponent + 1)
-        rad = fsqrt(1.f - ct * ct);
+        z = pow_nonneg(u1, v.bsdf.m->eta);                                 // 1 / (exponent + 1)
+        rad = fsqrt(1.f - z * z);
         ang = u0;                                                          // phi = 2 pi u0, in revolutions
     } else {   // concentric_disk_sample, 710-733 (angles in revolutions: theta / 2 pi)
         const float rx = 2.f * u0 - 1, ry = 2.f * u1 - 1;
@@ -697,115 +741,104 @@ KY_DEV f3 bsdf_sample_dir_nondelta(const Bsdf& B, f3 wo, float u0, float u1) {
         origin = (rx == 0 && ry == 0);
     }
     float px = cos_rev(ang) * rad, py = sin_rev(ang) * rad;
-    if (phong) {   // 2533-2543
-        const Frame fr = make_frame(mk3(-wo.x, -wo.y, wo.z));              // frame_t(wr): wr is unit because wo is
-        f3 wi = to_world(fr, mk3(px, py, ct));
-        if (wo.z < 0) wi.z = -wi.z;
-        return wi;
+    if (!phong) {   // cosine_hemisphere_sample 737-743, flipped into wo's hemisphere (2247-2249)
+        if (origin) { px = 0.f; py = 0.f; }
+        z = fsqrt(fmaxf(0.f, 1 - px * px - py * py));
+        if (cos_o < 0) z = -z;
     }
-    // cosine_hemisphere_sample 737-743, flipped into wo's hemisphere (2247-2249)
-    if (origin) { px = 0.f; py = 0.f; }
-    float z = fsqrt(fmaxf(0.f, 1 - px * px - py * py));
-    if (wo.z < 0) z = -z;
-    return mk3(px, py, z);
+    const LobeBasis L = vertex_basis(v);
+    f3 wi = L.a * px + L.b * py + L.c * z;
+    if (phong && cos_o < 0) wi = wi - (2.f * dot(v.normal, wi)) * v.normal;   // `if (wo.z < 0) wi.z *= -1` (2539) in world space
+    return wi;
 }
 
-// bsdf sample_ x4
-KY_DEV BsdfSample bsdf_sample_local(const Bsdf& B, f3 wo, float u0, float u1) {
+// The two delta lobes in one pass: perfect_specular_reflection_t (2292-2307) is the reflection branch of
+// fresnel_specular_scattering_t (2355-2412) taken with probability 1, so the lanes of both run the same code.  Glass:
+// fresnel_dielectric(wo.z, 1, eta) (1963-1996) and refract (1931-1957) in one pass -- both start from the same cos(theta_i),
+// sin^2(theta_i) and index ratio, and the Fresnel term's cos(theta_t) is the refracted direction's (the reference computes it
+// twice, as sqrt(1 - (r sin)^2) and as sqrt(1 - r^2 sin^2)).  reflect = 2 (n.wo) n - wo is (-wo.x, -wo.y, wo.z) of the shading frame.
+struct DeltaSample {
+    f3 wi;
+    float percent;    // the branch's probability = its pdf: 1 (mirror), F or 1 - F (glass)
+    float abs_cos;    // |wi.z| of the shading frame
+    bool reflected;
+};
+KY_DEV DeltaSample bsdf_sample_delta(const Vertex& v, f3 wo, float u0) {
+    const DMat& M = *v.bsdf.m;
+    const bool glass = v.bsdf.lobe == LOBE_GLASS;
+    const float cos_o = dot(v.normal, wo);
+    const float eta_t = M.eta;
+    const bool into = cos_o > 0;
+    const float nz = into ? 1.f : -1.f;
+    const float ratio = into ? M.inv_eta : eta_t;                    // eta_i / eta_t seen from wo's side
+    const float ei = into ? 1.f : eta_t, et = into ? eta_t : 1.f;
+    const float cos_theta_i = fminf(fabsf(cos_o), 1.f);
+    const float sin_theta_i_sq = fmaxf(0.f, 1 - cos_theta_i * cos_theta_i);
+    const float sin_theta_t = ratio * fsqrt(sin_theta_i_sq);
+    const bool tir = sin_theta_t >= 1;
+    const float cos_theta_t = fsqrt(fmaxf(0.f, 1 - sin_theta_t * sin_theta_t));
+    const float r_para = ((et * cos_theta_i) - (ei * cos_theta_t)) * rcp((et * cos_theta_i) + (ei * cos_theta_t));
+    const float r_perp = ((ei * cos_theta_i) - (et * cos_theta_t)) * rcp((ei * cos_theta_i) + (et * cos_theta_t));
+    const float reflect_percent = (!glass || tir) ? 1.f : (r_para * r_para + r_perp * r_perp) * 0.5f;
+    DeltaSample s;
+    s.reflected = !glass || u0 < reflect_percent;   // (glass with u0 >= 1 cannot happen: total internal reflection always reflects)
+    const float k = ratio * cos_theta_i - cos_theta_t;
+    const float sw = s.reflected ? -1.f : -ratio, sn = s.reflected ? 2.f * cos_o : k * nz;
+    s.wi = wo * sw + v.normal * sn;
+    s.percent = s.reflected ? reflect_percent : 1 - reflect_percent;
+    s.abs_cos = fabsf(s.reflected ? cos_o : -ratio * cos_o + k * nz);
+    return s;
+}
+
+// bsdf sample_ x4 with the reference's own value and pdf (KAT entry points, vertex traces, the recursive integrators' roulette on
+// the BSDF value, the BSDF-sampling estimators' slow path); the iterative integrator continues its path with bsdf_continue.
+KY_DEV BsdfSample bsdf_sample(const Vertex& v, f3 wo, float u0, float u1) {
     BsdfSample s;
-    s.f = mk3(0, 0, 0);
-    s.wi = any3();   // read only where f and pdf are non-zero, and every such path sets it
-    s.pdf = 0.f;
-    s.flags = 0;
-    if (B.lobe == LOBE_LAMBERT) {  // 2242-2257
-        s.wi = bsdf_sample_dir_nondelta(B, wo, u0, u1);
-        bsdf_eval_pdf(B, wo, s.wi, s.f, s.pdf);
-        s.flags = BSDF_REFLECTION | BSDF_DIFFUSE;
-    } else if (B.lobe == LOBE_MIRROR) {  // 2292-2307
-        s.wi = mk3(-wo.x, -wo.y, wo.z);
-        s.f = ld3(B.m->c0) * rcp(fabsf(s.wi.z));
-        s.pdf = 1;
-        s.flags = BSDF_REFLECTION | BSDF_SPECULAR;
-    } else if (B.lobe == LOBE_GLASS) {  // 2355-2412: fresnel_dielectric(wo.z, 1, eta) (1963-1996) and refract (1931-1957) in one pass --
-        // both start from the same cos(theta_i), sin^2(theta_i) and index ratio, and the Fresnel term's cos(theta_t) is the refracted
-        // direction's (the reference computes it twice, as sqrt(1 - (r sin)^2) and as sqrt(1 - r^2 sin^2))
-        const float eta_t = B.m->eta;
-        const bool into = wo.z > 0;
-        const float nz = into ? 1.f : -1.f;
-        const float ratio = into ? B.m->inv_eta : eta_t;                 // eta_i / eta_t seen from wo's side
-        const float ei = into ? 1.f : eta_t, et = into ? eta_t : 1.f;
-        const float cos_theta_i = fminf(fabsf(wo.z), 1.f);
-        const float sin_theta_i_sq = fmaxf(0.f, 1 - cos_theta_i * cos_theta_i);
-        const float sin_theta_t = ratio * fsqrt(sin_theta_i_sq);
-        const bool tir = sin_theta_t >= 1;
-        const float cos_theta_t = fsqrt(fmaxf(0.f, 1 - sin_theta_t * sin_theta_t));
-        const float r_para = ((et * cos_theta_i) - (ei * cos_theta_t)) * rcp((et * cos_theta_i) + (ei * cos_theta_t));
-        const float r_perp = ((ei * cos_theta_i) - (et * cos_theta_t)) * rcp((ei * cos_theta_i) + (et * cos_theta_t));
-        const float reflect_percent = tir ? 1.f : (r_para * r_para + r_perp * r_perp) * 0.5f;
-        const float refract_percent = 1 - reflect_percent;
-        if (u0 < reflect_percent) {
-            s.wi = mk3(-wo.x, -wo.y, wo.z);
-            s.pdf = reflect_percent;
-            s.f = (ld3(B.m->c0) * reflect_percent) * rcp(fabsf(s.wi.z));
-            s.flags = BSDF_REFLECTION | BSDF_SPECULAR;
-        } else if (!tir) {   // (u0 >= 1 cannot happen: total internal reflection always takes the branch above)
-            const float k = ratio * cos_theta_i - cos_theta_t;
-            s.wi = mk3(ratio * -wo.x, ratio * -wo.y, ratio * -wo.z + k * nz);
-            s.pdf = refract_percent;
-            s.f = (ld3(B.m->c1) * refract_percent) * rcp(fabsf(s.wi.z));
-            s.flags = BSDF_TRANSMISSION | BSDF_SPECULAR;
-        }
-        // else total internal reflection in the refraction branch: f = 0, pdf = 0 (2407) -- unreachable, kept for clarity
-    } else {  // phong, 2510-2529
-        s.wi = bsdf_sample_dir_nondelta(B, wo, u0, u1);
-        bsdf_eval_pdf(B, wo, s.wi, s.f, s.pdf);
-        s.flags = BSDF_REFLECTION | BSDF_GLOSSY;
+    if (bsdf_is_delta(v.bsdf)) {
+        const DeltaSample d = bsdf_sample_delta(v, wo, u0);
+        s.wi = d.wi;
+        s.pdf = d.percent;
+        s.f = (ld3(d.reflected ? v.bsdf.m->c0 : v.bsdf.m->c1) * d.percent) * rcp(d.abs_cos);   // 2301, 2384, 2402
+        s.flags = (d.reflected ? BSDF_REFLECTION : BSDF_TRANSMISSION) | BSDF_SPECULAR;
+    } else {
+        float abs_cos_i;
+        s.wi = bsdf_sample_dir_nondelta(v, wo, u0, u1);
+        bsdf_eval_pdf(v, wo, s.wi, s.f, s.pdf, abs_cos_i);
+        s.flags = BSDF_REFLECTION | (v.bsdf.lobe == LOBE_PHONG ? BSDF_GLOSSY : BSDF_DIFFUSE);
     }
     return s;
 }
 
-// ---------------------------------------------------------------------------------------------
-// path vertex (isect_t, 642-690)
-// ---------------------------------------------------------------------------------------------
-// The lane engine keeps a vertex's shading frame and local wo in LDS (read back where a direction changes space) instead
-// of in nine registers that would be live -- in practice: spilled to scratch memory -- across the whole lights loop.
-struct VertexLds {
-    float s[3][256], t[3][256], wo[3][256];   // [component][thread of the workgroup]
+// What path_tracing_iteration_t does with its BSDF sample (4586-4597): the direction, whether the path goes on, and the factor
+// beta is multiplied by, bs.f |dot(wi, n)| / bs.pdf -- written out per lobe, where most of it cancels:
+//   Lambert  (albedo / pi) |cos| / (|cos| / pi) = albedo                     the path ends when wi leaves wo's hemisphere (f = 0, pdf = 0)
+//   Phong    Ks' (n+2)/2pi cos_a^n |cos| / ((n+1)/2pi cos_a^n) = Ks' (n+2)/(n+1) |cos|   (DMat::c1); ends when wi leaves the hemisphere
+//            (f = 0) or cos_a^n = 0: with cos_a = u1^(1/(n+1)) that is u1 = 0
+//   mirror   (R / |cos|) |cos| / 1 = R;   glass  (R F / |cos|) |cos| / F = R,  (T (1 - F) / |cos|) |cos| / (1 - F) = T
+// and a black factor ends the path like the reference's is_black(bs.f) (4588).  The quotient is exact here where the reference's
+// rounds twice (1e-7 relative); its inf x 0 = NaN at exactly grazing mirror incidence (a local cosine of 0 against a world one that is
+// not, 2301 / 4592: about one sample in 5e7) has no counterpart -- the two cosines are one number here.
+struct BsdfContinue {
+    f3 wi, weight;
+    bool ok, specular;
 };
-__shared__ VertexLds g_vertex_lds;   // allocated only in kernels that set Vertex::in_lds
-struct Vertex {
-    float t;      // distance along the ray that found the vertex
-    f3 position, normal;
-    f3 wo_l;      // wo = -ray.direction (3125) in the shading frame   } used when !in_lds
-    Frame frame;  //                                                    }
-    Bsdf bsdf;
-    int surface;
-    bool in_lds = false;
-};
-KY_DEV void vertex_set_frame(Vertex& v, const Frame& f, f3 wo_l) {
-    if (v.in_lds) {
-        const int i = threadIdx.x;
-        g_vertex_lds.s[0][i] = f.s.x; g_vertex_lds.s[1][i] = f.s.y; g_vertex_lds.s[2][i] = f.s.z;
-        g_vertex_lds.t[0][i] = f.t.x; g_vertex_lds.t[1][i] = f.t.y; g_vertex_lds.t[2][i] = f.t.z;
-        g_vertex_lds.wo[0][i] = wo_l.x; g_vertex_lds.wo[1][i] = wo_l.y; g_vertex_lds.wo[2][i] = wo_l.z;
+KY_DEV BsdfContinue bsdf_continue(const Vertex& v, f3 wo, float u0, float u1) {
+    BsdfContinue c;
+    c.specular = bsdf_is_delta(v.bsdf);
+    if (c.specular) {
+        const DeltaSample d = bsdf_sample_delta(v, wo, u0);
+        c.wi = d.wi;
+        c.weight = ld3(d.reflected ? v.bsdf.m->c0 : v.bsdf.m->c1);
+        c.ok = !is_black(c.weight) && d.percent != 0.f;
     } else {
-        v.frame = f;
-        v.wo_l = wo_l;
+        c.wi = bsdf_sample_dir_nondelta(v, wo, u0, u1);
+        const float cos_o = dot(v.normal, wo), cos_i = dot(v.normal, c.wi);
+        const bool phong = v.bsdf.lobe == LOBE_PHONG;
+        const f3 col = ld3(phong ? v.bsdf.m->c1 : v.bsdf.m->c0);
+        c.weight = phong ? col * fabsf(cos_i) : col;
+        c.ok = (cos_o * cos_i > 0) && !is_black(col) && !(phong && !(u1 > 0.f) && v.bsdf.m->exponent > 0.f);
     }
-}
-KY_DEV Frame vertex_frame(const Vertex& v) {
-    if (!v.in_lds) return v.frame;
-    const int i = threadIdx.x;
-    Frame f;
-    f.s = mk3(g_vertex_lds.s[0][i], g_vertex_lds.s[1][i], g_vertex_lds.s[2][i]);
-    f.t = mk3(g_vertex_lds.t[0][i], g_vertex_lds.t[1][i], g_vertex_lds.t[2][i]);
-    f.n = v.normal;
-    return f;
-}
-KY_DEV f3 vertex_wo(const Vertex& v) {
-    if (!v.in_lds) return v.wo_l;
-    const int i = threadIdx.x;
-    return mk3(g_vertex_lds.wo[0][i], g_vertex_lds.wo[1][i], g_vertex_lds.wo[2][i]);
+    return c;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -983,13 +1016,10 @@ KY_DEV f3 surface_emission(const LdsScene& Lds, int surface, f3 normal, f3 wo) {
 // one ballot per query.  With more than KY_TRANSPOSE_MAX queries in the wave, or for scenes the fast path does not
 // cover (general quads / triangles / disks, environment lights, many carriers), the ordinary traversal runs instead.
 template <bool MIS>
-KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, int li, float u0, float u1, bool active) {
+KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, int li, float u0, float u1, bool active) {
     const DLight& L = S->light[li];
     f3 Ld = mk3(0, 0, 0);
     if (!S.single_area() && (L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION)) return Ld;  // light.is_delta(), 3894 / 3977 (wave-uniform)
-#if KY_ABL == 1 || KY_ABL == 7   // measurement builds only (tools/ablate_pmc.sh): this estimator's instructions removed
-    return Ld;
-#endif
     BsdfSample bs;
     // what `live` guards: read at the end only for lanes whose sample counts (and, in the query loop, through __shfl from such lanes)
     f3 f_cos = any3(), o = any3(), Li = mk3(0, 0, 0);
@@ -1003,10 +1033,8 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, int
         // lanes whose ray reaches a carrier that emits towards it -- for all other lanes Li = 0 decides the estimate (3996-4003).
         // (Delta lobes never get here: sample_all_light runs for non-delta vertices only, 4571.)
         const bool act = active && !bsdf_is_delta(v.bsdf);
-        f3 wi_l = any3();
         if (act) {
-            wi_l = bsdf_sample_dir_nondelta(v.bsdf, vertex_wo(v), u0, u1);
-            bs.wi = to_world(vertex_frame(v), wi_l);  // 2176
+            bs.wi = bsdf_sample_dir_nondelta(v, wo, u0, u1);
             o = offset_ray_origin(v.position, v.normal, bs.wi);  // isect.spawn_ray, 665-668
         }
         // (a) nearest carrier surface along the ray, and what it emits towards the ray (3084, 2957-2960)
@@ -1025,8 +1053,9 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, int
             pending = !is_black(Li);
         }
         if (pending) {  // rare: now the sample's value and pdf (3979-3987)
-            bsdf_eval_pdf(v.bsdf, vertex_wo(v), wi_l, bs.f, bs.pdf);
-            f_cos = bs.f * fabsf(dot(bs.wi, v.normal));
+            float abs_cos_i;
+            bsdf_eval_pdf(v, wo, bs.wi, bs.f, bs.pdf, abs_cos_i);
+            f_cos = bs.f * abs_cos_i;
             live = !(is_black(f_cos) || (MIS ? (bs.pdf <= 0) : (bs.pdf == 0)));
             pending = live;
         }
@@ -1060,8 +1089,7 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, int
         if (blocked) Li = mk3(0, 0, 0);
     } else {
         if (active) {
-            bs = bsdf_sample_local(v.bsdf, vertex_wo(v), u0, u1);
-            bs.wi = to_world(vertex_frame(v), bs.wi);  // 2176
+            bs = bsdf_sample(v, wo, u0, u1);
             f_cos = bs.f * fabsf(dot(bs.wi, v.normal));
             live = !(is_black(f_cos) || (MIS ? (bs.pdf <= 0) : (bs.pdf == 0)));
             o = offset_ray_origin(v.position, v.normal, bs.wi);  // isect.spawn_ray, 665-668
@@ -1095,112 +1123,136 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, int
 // scene_t::occluded (3187-3201) is the most expensive step of the light-sampling estimators and the one with the fewest
 // lanes that need it: many light samples are dead before it (back side of the light, zero BSDF value -- a Phong lobe away
 // from its peak) or die on the sampled light's own shape (quirk 1).  Instead of tracing each light's shadow rays at once with
-// whatever lanes have one, a lane that has a live sample evaluates everything else first (BSDF value, MIS weight), pushes
-// {ray, contribution, destination pixel} on a per-wavefront stack in global memory, and goes on.  Whenever 64 rays have
-// piled up the wave traces them with all 64 lanes busy and adds the unoccluded contributions to their pixels' sums.
-// The stack is private to the wave (no synchronisation), SoA so that pushes and pops are coalesced dword accesses, and it
-// stays L2-resident (a few KB per wave are live at any time).  Contributions are added in 32.32 fixed point, so the image
-// does not depend on when a ray is resolved.
+// whatever lanes have one, a lane that has a live sample evaluates everything else first (BSDF value, MIS weight) and hands
+// {ray, contribution, destination pixel} to sq_push.  Rays wait on a small per-wavefront stack in global memory until a push
+// brings the total to 64; that push does not store its rays at all: as many of the new rays as are needed stay in their lanes'
+// registers, the other lanes pop the stack, and the wave traces 64 rays with every lane busy, then adds the unoccluded
+// contributions to their pixels' sums.  The stack is private to the wave (no synchronisation), an array of 48-byte entries so
+// that a push of k rays writes one contiguous run of 48 k bytes (stores leave the L2 on this chip whatever one does: full lines cost
+// what they carry, partial ones a whole line each), and at most 127 entries deep (6 KB per wave: the stacks of an XCD's 768
+// wavefronts stay in its 4 MB L2, so pops are L2 hits).  Contributions are added in 32.32 fixed point, so the image does not
+// depend on when a ray is resolved.
 // ---------------------------------------------------------------------------------------------
-constexpr int KY_SQ_FIELDS = 11;                              // origin 3, direction 3, tmax, contribution 3, tag
-constexpr int KY_SQ_CAP = 64 * (KYHIP_MAX_LIGHTS + 1);        // a turn pushes at most 64 rays per light on top of < 64 left over
+constexpr int KY_SQ_ENTRY = 3;                                // float4 per ray: (origin, tmax) (direction, tag) (contribution, -)
+constexpr int KY_SQ_CAP = 128;                                // < 64 waiting + < 64 of a push that did not fit the wave being traced
 struct ShadowQueue {
-    float* base;   // this wave's block: KY_SQ_FIELDS rows of KY_SQ_CAP floats
-    int n;         // rays on the stack (wave-uniform)
+    float4* base;   // this wave's block: KY_SQ_CAP entries
+    int n;          // rays on the stack (wave-uniform), < 64 between calls
+    // where contributions go
+    const int* c_pix;               // LDS: the pixel every lane of the workgroup is working on (-1: none)
+    unsigned long long* c_def;      // LDS: [3][256] fixed-point sums of resolved contributions, per lane
+    unsigned long long* accum;      // global fixed-point accumulators of the shard
+    unsigned* flags;                // global NaN / inf flags of the shard
 };
-// wave-uniform call
-KY_DEV void sq_push(ShadowQueue& q, bool push, f3 o, f3 d, float tmax, f3 c, unsigned tag) {
+struct SqRay {
+    f3 o, d, c;
+    float tmax;
+    unsigned tag;   // destination pixel << 6 | lane that pushed it
+};
+KY_DEV void sq_store(float4* e, const SqRay& r) {
+    e[0] = make_float4(r.o.x, r.o.y, r.o.z, r.tmax);
+    e[1] = make_float4(r.d.x, r.d.y, r.d.z, __uint_as_float(r.tag));
+    e[2] = make_float4(r.c.x, r.c.y, r.c.z, 0.f);
+}
+KY_DEV SqRay sq_load(const float4* e) {
+    const float4 a = e[0], b = e[1], c = e[2];
+    return SqRay{mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), a.w, __float_as_uint(b.w)};
+}
+// traces this lane's ray (any hit occludes) and adds an unoccluded contribution to its pixel
+KY_DEV void sq_trace(SceneRef S, const ShadowQueue& q, const SqRay& r) {
+    if (trace_any(S, S->occ_deferred_ok ? S->occ : S->trav, r.o, r.d, r.tmax)) return;   // rays of all lights share the stack
+    const float c[3] = {r.c.x, r.c.y, r.c.z};
+    const int pix = (int)(r.tag >> 6), owner = (int)((threadIdx.x & ~63u) | (r.tag & 63u));
+    const bool local = q.c_pix[owner] == pix;   // the lane that pushed the ray is still on that pixel: its LDS sum takes it
+    unsigned fl = 0;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float a = c[ch];
+        if (a != a) fl |= 1u << ch;
+        else if (a > 2.0e9f) fl |= 8u << ch;
+        else if (a < -2.0e9f) fl |= 64u << ch;
+        else if (a != 0.f) {
+            const unsigned long long fx = (unsigned long long)__double2ll_rn((double)a * 4294967296.0);
+            if (local) atomicAdd(&q.c_def[ch * 256 + owner], fx);
+            else atomicAdd(&q.accum[(size_t)pix * 3 + ch], fx);
+        }
+    }
+    if (fl) atomicOr(&q.flags[pix], fl);
+}
+// wave-uniform call: lanes with `push` hand over the ray r
+KY_DEV void sq_push(SceneRef S, ShadowQueue& q, bool push, SqRay r) {
     const unsigned long long m = __ballot(push);
     if (!m) return;
-    if (push) {
-        const int slot = q.n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        float* p = q.base + slot;
-        p[0 * KY_SQ_CAP] = o.x; p[1 * KY_SQ_CAP] = o.y; p[2 * KY_SQ_CAP] = o.z;
-        p[3 * KY_SQ_CAP] = d.x; p[4 * KY_SQ_CAP] = d.y; p[5 * KY_SQ_CAP] = d.z;
-        p[6 * KY_SQ_CAP] = tmax;
-        p[7 * KY_SQ_CAP] = c.x; p[8 * KY_SQ_CAP] = c.y; p[9 * KY_SQ_CAP] = c.z;
-        p[10 * KY_SQ_CAP] = __uint_as_float(tag);
+    const int k = __popcll(m);
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));   // pushing lanes below this one
+    if (q.n + k < 64) {   // not yet a wavefront's worth: the rays wait
+        if (push) sq_store(q.base + (q.n + rank) * KY_SQ_ENTRY, r);
+        q.n += k;
+        return;
     }
-    q.n += __popcll(m);
+    // 64 or more: the first `take` new rays are traced from the registers they are in, the rest wait; the q.n lanes without a ray to
+    // trace pop the top of the stack (which may hold rays stored a moment ago: same wavefront, same address -> in order)
+    const int take = 64 - q.n;
+    const bool keep = push && rank < take;
+    if (push && !keep) sq_store(q.base + (q.n + rank - take) * KY_SQ_ENTRY, r);
+    const int n1 = q.n + k - take;
+#ifdef KY_SQ_FENCE
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#else
+    asm volatile("" ::: "memory");   // the compiler must keep the order; the hardware keeps a wavefront's accesses to one address in order by itself
+#endif
+    const unsigned long long others = __ballot(!keep);
+    if (!keep) {
+        const int j = n1 - 1 - (int)__builtin_amdgcn_mbcnt_hi((unsigned)(others >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)others, 0u));
+        r = sq_load(q.base + j * KY_SQ_ENTRY);
+    }
+    q.n = k - take;
+    sq_trace(S, q, r);
+}
+// end of the kernel: what is left on the stack (wave-uniform call)
+KY_DEV void sq_drain(SceneRef S, ShadowQueue& q) {
+    const int lane = (int)__lane_id();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane < q.n) sq_trace(S, q, sq_load(q.base + lane * KY_SQ_ENTRY));
+    q.n = 0;
 }
 
 // light-sampling half with the occlusion test deferred: by_emitter_mis (4035-4074) in the order sample -> BSDF value ->
 // weight -> [sampled shape's own hit] -> push; the reference's order (occlusion before the BSDF value) gives the same sum
 // because every factor is computed from the same inputs and a zero factor zeroes the term either way.
 // Wave-uniform call.  beta x weight = throughput x strategy weight x 1 / spp: what multiplies this estimate in the pixel's sum.
-KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, int li, float u0, float u1, bool active, f3 beta, float weight,
+KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, f3 wo, int li, float u0, float u1, bool active, f3 beta, float weight,
                                          unsigned tag, ShadowQueue& q) {
     const DLight& L = S->light[li];
     bool push = false;
-    f3 o = any3(), dir = any3(), C = any3();   // read by sq_push only for lanes that push
-    float tmax = any_f();
+    SqRay r{any3(), any3(), any3(), any_f(), tag};   // read by sq_push only for lanes that push
     if (active) {
         // Straight-line from here: every lane runs every instruction and `push` says whether its values mean anything.  (Skipping the
         // work of a dead sample would need ALL lanes of the wave dead; the nested version paid for its structure with defaults and
         // exec-mask bookkeeping at every level instead.)
         const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1, S.feat);
         f3 f;
-        float bsdf_pdf;
-        bsdf_eval_pdf(v.bsdf, vertex_wo(v), to_local(vertex_frame(v), ls.wi), f, bsdf_pdf);
-        const f3 f_cos = f * fabsf(dot(ls.wi, v.normal));
+        float bsdf_pdf, abs_cos_i;
+        bsdf_eval_pdf(v, wo, ls.wi, f, bsdf_pdf, abs_cos_i);
+        const f3 f_cos = f * abs_cos_i;
         const bool delta_light = L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION;
         const f3 Ld = delta_light ? (f_cos * ls.Li) * rcp(ls.pdf) : (f_cos * ls.Li) * (2.f * rcp(ls.pdf + bsdf_pdf));   // 4057 / 4070
-        C = (Ld * beta) * weight;   // the product beta x weight is not kept in registers across the lights loop: three multiplies per light instead
+        r.c = (Ld * beta) * weight;   // the product beta x weight is not kept in registers across the lights loop: three multiplies per light instead
         // scene_t::occluded(isect, ls.position), 3187-3201: the ray
         const f3 to = ls.position - v.position;
         const float d2 = length_sq(to);
         const float inv_d = rsq(d2);
-        dir = to * inv_d;
-        tmax = d2 * inv_d - 2e-3f;
-        o = offset_ray_origin(v.position, v.normal, dir);
-        push = !(is_black(ls.Li) || ls.pdf <= 0) && !is_black(f_cos) && !(C.x == 0.f && C.y == 0.f && C.z == 0.f);
+        r.d = to * inv_d;
+        r.tmax = d2 * inv_d - 2e-3f;
+        r.o = offset_ray_origin(v.position, v.normal, r.d);
+        push = !(is_black(ls.Li) || ls.pdf <= 0) && !is_black(f_cos) && !(r.c.x == 0.f && r.c.y == 0.f && r.c.z == 0.f);
         // the sampled shape itself is the likeliest occluder (quirk 1): one test here saves the ray a full traversal
         if (L.kind == KY_LIGHT_AREA && L.sampled_is_surface) {   // wave-uniform
             float t;
-            if (surf_hit(L.isect, S->full, o, dir, tmax, t, S.general)) push = false;
+            if (surf_hit(L.isect, S->full, r.o, r.d, r.tmax, t, S.general)) push = false;
         }
     }
-    sq_push(q, push, o, dir, tmax, C, tag);
-}
-
-// what sq_resolve needs besides the queue: where contributions go
-struct SqSink {
-    const int* c_pix;               // LDS: the pixel every lane of the workgroup is working on (-1: none)
-    unsigned long long* c_def;      // LDS: [3][256] fixed-point sums of resolved contributions, per lane
-    unsigned long long* accum;      // global fixed-point accumulators of the shard
-    unsigned* flags;                // global NaN / inf flags of the shard
-};
-// Pops the top `k` (<= 64) rays, traces them (any hit occludes) and adds the unoccluded contributions to their pixels.
-// Wave-uniform call.
-KY_DEV void sq_resolve(SceneRef S, ShadowQueue& q, int k, const SqSink& sink) {
-    const int lane = (int)__lane_id();
-    q.n -= k;
-    if (lane < k) {
-        const float* p = q.base + q.n + lane;
-        const f3 o = mk3(p[0 * KY_SQ_CAP], p[1 * KY_SQ_CAP], p[2 * KY_SQ_CAP]);
-        const f3 d = mk3(p[3 * KY_SQ_CAP], p[4 * KY_SQ_CAP], p[5 * KY_SQ_CAP]);
-        const float tmax = p[6 * KY_SQ_CAP];
-        if (!trace_any(S, S->occ_deferred_ok ? S->occ : S->trav, o, d, tmax)) {   // rays of all lights share the stack
-            const float c[3] = {p[7 * KY_SQ_CAP], p[8 * KY_SQ_CAP], p[9 * KY_SQ_CAP]};
-            const unsigned tag = __float_as_uint(p[10 * KY_SQ_CAP]);
-            const int pix = (int)(tag >> 6), owner = (int)((threadIdx.x & ~63u) | (tag & 63u));
-            const bool local = sink.c_pix[owner] == pix;   // the lane that pushed the ray is still on that pixel: its LDS sum takes it
-            unsigned fl = 0;
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const float a = c[ch];
-                if (a != a) fl |= 1u << ch;
-                else if (a > 2.0e9f) fl |= 8u << ch;
-                else if (a < -2.0e9f) fl |= 64u << ch;
-                else if (a != 0.f) {
-                    const unsigned long long fx = (unsigned long long)__double2ll_rn((double)a * 4294967296.0);
-                    if (local) atomicAdd(&sink.c_def[ch * 256 + owner], fx);
-                    else atomicAdd(&sink.accum[(size_t)pix * 3 + ch], fx);
-                }
-            }
-            if (fl) atomicOr(&sink.flags[pix], fl);
-        }
-    }
+    sq_push(S, q, push, r);
 }
 
 // light-sampling half: by_emitter (3933-3962, MIS=false) and by_emitter_mis (4035-4074, MIS=true)
@@ -1225,13 +1277,10 @@ KY_DEV bool light_sample_occluded(SceneRef S, int li, f3 o, f3 dir, float tmax) 
 }
 
 template <bool MIS>
-KY_DEV f3 estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, int li, float u0, float u1) {
+KY_DEV f3 estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, int li, float u0, float u1) {
     const DLight& L = S->light[li];
     f3 Ld = mk3(0, 0, 0);
     KY_PROBE(3);
-#if KY_ABL == 2 || KY_ABL == 7
-    return Ld;
-#endif
     const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1, S.feat);
     const bool dead = is_black(ls.Li) || (MIS ? (ls.pdf <= 0) : (ls.pdf == 0));
     KY_CLK(5);
@@ -1244,22 +1293,14 @@ KY_DEV f3 estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, 
         const float dist = d2 * inv_d;
         const f3 o = offset_ray_origin(v.position, v.normal, dir);
         KY_PROBE(4);
-#if KY_ABL == 3
-        const bool occ = o.x == 1e30f;   // never: the traversal's instructions removed, everything after it kept
-#else
         const bool occ = light_sample_occluded(S, li, o, dir, dist - 2e-3f);
-#endif
         KY_CLK(6);
-#if KY_ABL == 4
-        if (!occ) Ld = mk3(1e-30f, 0, 0);
-        return Ld;
-#endif
         if (!occ) {
             KY_PROBE(5);
             f3 f;
-            float bsdf_pdf;
-            bsdf_eval_pdf(v.bsdf, vertex_wo(v), to_local(vertex_frame(v), ls.wi), f, bsdf_pdf);
-            const f3 f_cos = f * fabsf(dot(ls.wi, v.normal));
+            float bsdf_pdf, abs_cos_i;
+            bsdf_eval_pdf(v, wo, ls.wi, f, bsdf_pdf, abs_cos_i);
+            const f3 f_cos = f * abs_cos_i;
             if (!is_black(f_cos)) {
                 const bool delta_light = !S.single_area() && (L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION);
                 if (!MIS || delta_light) Ld = (f_cos * ls.Li) * rcp(ls.pdf);          // 3956 / 4057
@@ -1278,7 +1319,7 @@ KY_DEV f3 estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, 
 // `sq` (the QUEUE instantiation of the lane engine, strategy both_mis): the light-sampling halves are not returned but pushed on
 // the wave's shadow-ray stack with beta x weight x 0.5 as their weight in the pixel's sum.
 template <bool DEBUG_SAMPLER>
-KY_DEV f3 sample_all_light(SceneRef S, const LdsScene& Lds, const Vertex& v, Sampler& smp, int strategy, bool active,
+KY_DEV f3 sample_all_light(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, Sampler& smp, int strategy, bool active,
                            unsigned* decisions = nullptr, ShadowQueue* sq = nullptr, f3 beta = f3{0, 0, 0}, float weight = 0.f, unsigned tag = 0) {
     f3 Ld = mk3(0, 0, 0);
     const int nl = S.single_area() ? 1 : S->n_lights;
@@ -1288,13 +1329,13 @@ KY_DEV f3 sample_all_light(SceneRef S, const LdsScene& Lds, const Vertex& v, Sam
         if (active) { ub0 = sampler_next<DEBUG_SAMPLER>(smp); ub1 = sampler_next<DEBUG_SAMPLER>(smp); }
         if (strategy == KY_DIRECT_BOTH_MIS) {  // 4076-4088
             KY_CLK(3);
-            const f3 Lb = estimate_by_bsdf<true>(S, Lds, v, li, ub0, ub1, active);   // draws nothing itself
+            const f3 Lb = estimate_by_bsdf<true>(S, Lds, v, wo, li, ub0, ub1, active);   // draws nothing itself
             KY_CLK(4);
             f3 Ll = mk3(0, 0, 0);
             // random_light is drawn here, after the BSDF half: same stream position, two registers fewer across it
             if (active) { ul0 = sampler_next<DEBUG_SAMPLER>(smp); ul1 = sampler_next<DEBUG_SAMPLER>(smp); }
-            if (sq) estimate_by_emitter_deferred(S, v, li, ul0, ul1, active, beta, weight * 0.5f, tag, *sq);
-            else if (active) Ll = estimate_by_emitter<true>(S, Lds, v, li, ul0, ul1);
+            if (sq) estimate_by_emitter_deferred(S, v, wo, li, ul0, ul1, active, beta, weight * 0.5f, tag, *sq);
+            else if (active) Ll = estimate_by_emitter<true>(S, Lds, v, wo, li, ul0, ul1);
             Ld = Ld + (0.5f * Lb + 0.5f * Ll);
             if (decisions && li < 16) *decisions |= (is_black(Lb) ? 0u : 1u << li) | (is_black(Ll) ? 0u : 1u << (16 + li));
             continue;
@@ -1303,17 +1344,17 @@ KY_DEV f3 sample_all_light(SceneRef S, const LdsScene& Lds, const Vertex& v, Sam
         KY_CLK(3);
         f3 Lb = mk3(0, 0, 0), Ll = mk3(0, 0, 0);
         if (strategy == KY_DIRECT_BSDF_MIS) {
-            Lb = estimate_by_bsdf<true>(S, Lds, v, li, ub0, ub1, active);
+            Lb = estimate_by_bsdf<true>(S, Lds, v, wo, li, ub0, ub1, active);
         } else if (strategy == KY_DIRECT_LIGHT_MIS) {
-            if (active) Ll = estimate_by_emitter<true>(S, Lds, v, li, ul0, ul1);
+            if (active) Ll = estimate_by_emitter<true>(S, Lds, v, wo, li, ul0, ul1);
         } else if (strategy == KY_DIRECT_LIGHT) {
-            if (active) Ll = estimate_by_emitter<false>(S, Lds, v, li, ul0, ul1);
+            if (active) Ll = estimate_by_emitter<false>(S, Lds, v, wo, li, ul0, ul1);
         } else if (strategy == KY_DIRECT_BSDF) {
             const int lk = S->light[li].kind;
             if (!(lk == KY_LIGHT_POINT || lk == KY_LIGHT_DIRECTION)) {  // the third float2 is drawn after the delta test (3894-3900)
                 float u0 = any_f(), u1 = any_f();
                 if (active) { u0 = sampler_next<DEBUG_SAMPLER>(smp); u1 = sampler_next<DEBUG_SAMPLER>(smp); }
-                Lb = estimate_by_bsdf<false>(S, Lds, v, li, u0, u1, active);
+                Lb = estimate_by_bsdf<false>(S, Lds, v, wo, li, u0, u1, active);
             }
         }
         Ld = Ld + (Lb + Ll);
@@ -1424,17 +1465,17 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, SceneRef S, const LdsScene& Lds
         } else {
             v.bsdf = make_bsdf_for_lobe(M, lobe);
         }
-        const Frame fr = make_frame(v.normal);
-        vertex_set_frame(v, fr, to_local(fr, -ps.d));   // ps.d still holds the direction of the ray that found this vertex
+        vertex_prepare(v, -ps.d);   // ps.d still holds the direction of the ray that found this vertex
     }
+    const f3 wo = -ps.d;   // isect.wo, 3125
 
     if (rc.integrator < KY_INTEGRATOR_DIRECT_LIGHTING) {  // debug_integrator_t, 4110-4118 (wave-uniform)
         if (active) {
             if (rc.integrator == KY_INTEGRATOR_POSITION) ps.Lo = normalize(v.position);
             else if (rc.integrator == KY_INTEGRATOR_NORMAL) ps.Lo = v.normal;
             else {
-                float pdf;
-                bsdf_eval_pdf(v.bsdf, vertex_wo(v), to_local(vertex_frame(v), v.normal), ps.Lo, pdf);
+                float pdf, abs_cos_i;
+                bsdf_eval_pdf(v, wo, v.normal, ps.Lo, pdf, abs_cos_i);
             }
         }
         return false;
@@ -1449,7 +1490,7 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, SceneRef S, const LdsScene& Lds
     KY_PROBE(6);
     unsigned decisions = 0;
     if (!simple) {  // simple_path_tracing_recursion_t samples the BSDF only
-        const f3 Ld = sample_all_light<DEBUG_SAMPLER>(S, Lds, v, ps.smp, rc.strategy, nee, tr ? &decisions : nullptr, sq, ps.beta, rc.inv_spp, tag);  // 4575 / 4337 / 4458
+        const f3 Ld = sample_all_light<DEBUG_SAMPLER>(S, Lds, v, wo, ps.smp, rc.strategy, nee, tr ? &decisions : nullptr, sq, ps.beta, rc.inv_spp, tag);  // 4575 / 4337 / 4458
         if (nee) ps.Lo = ps.Lo + ps.beta * Ld;
     }
     KY_CLK(8);
@@ -1460,8 +1501,7 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, SceneRef S, const LdsScene& Lds
         // path_tracing_recursion_t, specular vertex (4341-4349): look the emitter up along a sampled direction, from the
         // un-offset hit point; the continuation below draws a NEW sample
         const float e0 = sampler_next<DEBUG_SAMPLER>(ps.smp), e1 = sampler_next<DEBUG_SAMPLER>(ps.smp);
-        BsdfSample es = bsdf_sample_local(v.bsdf, vertex_wo(v), e0, e1);
-        es.wi = to_world(vertex_frame(v), es.wi);
+        const BsdfSample es = bsdf_sample(v, wo, e0, e1);
         float t = K_INF;
         const int hs = trace_nearest(S, v.position, es.wi, t);
         f3 Le = S->env_light >= 0 ? ld3(S->light[S->env_light].color) : mk3(0, 0, 0);
@@ -1477,11 +1517,31 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, SceneRef S, const LdsScene& Lds
     // sample BSDF to get the new path direction, 4586 / 4213 / 4383 / 4495
     const float u0 = sampler_next<DEBUG_SAMPLER>(ps.smp), u1 = sampler_next<DEBUG_SAMPLER>(ps.smp);
     KY_PROBE(7);
-    BsdfSample bs = bsdf_sample_local(v.bsdf, vertex_wo(v), u0, u1);
-    bs.wi = to_world(vertex_frame(v), bs.wi);
+    if (rc.integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION && !tr) {
+        // path_tracing_iteration_t, 4586-4616, with the sample's value, cosine and pdf folded into one factor (bsdf_continue).
+        // Straight-line: a path that ends here never reads its ray or throughput again, so every lane updates them and `cont` alone says
+        // whether the path goes on -- no copies of the old state on the ways out, no exec-mask bookkeeping around them.
+        const BsdfContinue c = bsdf_continue(v, wo, u0, u1);
+        bool cont = c.ok;  // 4588
+        ps.beta = ps.beta * c.weight;  // 4592
+        ps.prev_specular = c.specular;  // 4596
+        ps.o = offset_ray_origin(v.position, v.normal, c.wi);  // 4597
+        ps.d = c.wi;
+        if (ps.bounces > 3) {  // Russian roulette, 4601-4612 (the number is drawn by the paths that get here only: the stream of the others must not move)
+            const float q = fmaxf(0.05f, 1 - max3(ps.beta));
+            const float u = sampler_next<DEBUG_SAMPLER>(ps.smp);
+            cont = cont && !(u < q);
+            ps.beta = ps.beta * rcp(1 - q);
+        }
+        ps.bounces += 1;
+        // The vertex at bounces == max_depth can only add emission after a delta bounce (4548, 4563):
+        // when the previous bounce was not specular that last traversal cannot change Lo, so skip it.
+        return cont && !(ps.bounces >= rc.max_path_depth && !ps.prev_specular);
+    }
+    // the reference's own value and pdf: the vertex trace records them, the recursive integrators play roulette on the value
+    BsdfSample bs = bsdf_sample(v, wo, u0, u1);
     if (tr && tr->n < tr->max_rows) {
         float* r = tr->rows + 26 * tr->n++;
-        const f3 wo = -ps.d;
         r[0] = (float)ps.bounces; r[1] = (float)S->orig[v.surface]; r[2] = (float)v.bsdf.lobe;
         r[3] = v.position.x; r[4] = v.position.y; r[5] = v.position.z; r[6] = v.normal.x; r[7] = v.normal.y; r[8] = v.normal.z;
         r[9] = wo.x; r[10] = wo.y; r[11] = wo.z; r[12] = ps.beta.x; r[13] = ps.beta.y; r[14] = ps.beta.z;

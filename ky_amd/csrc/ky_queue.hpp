@@ -212,7 +212,7 @@ KY_DEV unsigned qe_take_units(QeLds& W, int lane, unsigned n, unsigned* __restri
 // The reference tests occlusion first and evaluates the BSDF only for unoccluded samples; evaluating first drops the shadow
 // rays of samples whose f*cos is black (their Ld is 0 either way).
 template <bool MIS>
-KY_DEV bool emitter_sample(SceneRef S, const Vertex& v, int li, float u0, float u1, f3& dir, float& tmax, f3& Ld) {
+KY_DEV bool emitter_sample(SceneRef S, const Vertex& v, f3 wo, int li, float u0, float u1, f3& dir, float& tmax, f3& Ld) {
     const DLight& L = S->light[li];
     const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1);
     const bool dead = is_black(ls.Li) || (MIS ? (ls.pdf <= 0) : (ls.pdf == 0));
@@ -223,9 +223,9 @@ KY_DEV bool emitter_sample(SceneRef S, const Vertex& v, int li, float u0, float 
     dir = to * inv_d;
     tmax = d2 * inv_d - 2e-3f;
     f3 f;
-    float bsdf_pdf;
-    bsdf_eval_pdf(v.bsdf, vertex_wo(v), to_local(vertex_frame(v), ls.wi), f, bsdf_pdf);
-    const f3 f_cos = f * fabsf(dot(ls.wi, v.normal));
+    float bsdf_pdf, abs_cos_i;
+    bsdf_eval_pdf(v, wo, ls.wi, f, bsdf_pdf, abs_cos_i);
+    const f3 f_cos = f * abs_cos_i;
     if (is_black(f_cos)) return false;
     const bool delta_light = L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION;
     if (!MIS || delta_light) Ld = (f_cos * ls.Li) * rcp(ls.pdf);          // 3956 / 4057
@@ -236,7 +236,7 @@ KY_DEV bool emitter_sample(SceneRef S, const Vertex& v, int li, float u0, float 
 // One light of sample_all_light (3834-3872).  Wave-uniform call.  L_now: what the light adds right away (the BSDF-sampling
 // estimator); pending / dir / tmax / L_pending: the light-sampling estimator's shadow ray and its value.
 template <bool DEBUG_SAMPLER>
-KY_DEV void nee_one_light(SceneRef S, const LdsScene& Lds, const Vertex& v, Sampler& smp, int strategy, int li, bool active,
+KY_DEV void nee_one_light(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, Sampler& smp, int strategy, int li, bool active,
                           f3& L_now, bool& pending, f3& dir, float& tmax, f3& L_pending) {
     L_now = mk3(0, 0, 0);
     L_pending = mk3(0, 0, 0);
@@ -250,24 +250,24 @@ KY_DEV void nee_one_light(SceneRef S, const LdsScene& Lds, const Vertex& v, Samp
         ul0 = sampler_next<DEBUG_SAMPLER>(smp); ul1 = sampler_next<DEBUG_SAMPLER>(smp);
     }
     if (strategy == KY_DIRECT_BOTH_MIS) {  // 4076-4088
-        L_now = 0.5f * estimate_by_bsdf<true>(S, Lds, v, li, ub0, ub1, active);
+        L_now = 0.5f * estimate_by_bsdf<true>(S, Lds, v, wo, li, ub0, ub1, active);
         if (active) {
             f3 Ll = mk3(0, 0, 0);
-            pending = emitter_sample<true>(S, v, li, ul0, ul1, dir, tmax, Ll);
+            pending = emitter_sample<true>(S, v, wo, li, ul0, ul1, dir, tmax, Ll);
             L_pending = 0.5f * Ll;
         }
     } else if (strategy == KY_DIRECT_BSDF_MIS) {
-        L_now = estimate_by_bsdf<true>(S, Lds, v, li, ub0, ub1, active);
+        L_now = estimate_by_bsdf<true>(S, Lds, v, wo, li, ub0, ub1, active);
     } else if (strategy == KY_DIRECT_LIGHT_MIS) {
-        if (active) pending = emitter_sample<true>(S, v, li, ul0, ul1, dir, tmax, L_pending);
+        if (active) pending = emitter_sample<true>(S, v, wo, li, ul0, ul1, dir, tmax, L_pending);
     } else if (strategy == KY_DIRECT_LIGHT) {
-        if (active) pending = emitter_sample<false>(S, v, li, ul0, ul1, dir, tmax, L_pending);
+        if (active) pending = emitter_sample<false>(S, v, wo, li, ul0, ul1, dir, tmax, L_pending);
     } else if (strategy == KY_DIRECT_BSDF) {
         const int lk = S->light[li].kind;
         if (!(lk == KY_LIGHT_POINT || lk == KY_LIGHT_DIRECTION)) {  // the third float2 is drawn after the delta test (3894-3900)
             float u0 = 0.f, u1 = 0.f;
             if (active) { u0 = sampler_next<DEBUG_SAMPLER>(smp); u1 = sampler_next<DEBUG_SAMPLER>(smp); }
-            L_now = estimate_by_bsdf<false>(S, Lds, v, li, u0, u1, active);
+            L_now = estimate_by_bsdf<false>(S, Lds, v, wo, li, u0, u1, active);
         }
     }
     if (!pending) L_pending = mk3(0, 0, 0);
@@ -280,8 +280,7 @@ KY_DEV void qe_vertex(Vertex& v, const LdsScene& Lds, f3 position, f3 d, int sur
     v.surface = surface;
     v.normal = hit_normal(Lds.hit[surface], position, d);
     v.bsdf = make_bsdf_for_lobe(Lds.mat[Lds.hit[surface].material], lobe);
-    v.frame = make_frame(v.normal);
-    v.wo_l = to_local(v.frame, -d);
+    vertex_prepare(v, -d);   // the lobe's basis in registers (in_lds is false here)
 }
 
 #ifndef KY_QE_WAVES
@@ -424,7 +423,7 @@ __global__ __launch_bounds__(QE_THREADS, KY_QE_WAVES) void render_kernel_q(const
                 f3 a, b, c;
                 float tm;
                 bool pe;
-                nee_one_light<DEBUG_SAMPLER>(S, Lds, v, smp, rc.strategy, li, mine, a, pe, c, tm, b);
+                nee_one_light<DEBUG_SAMPLER>(S, Lds, v, -d, smp, rc.strategy, li, mine, a, pe, c, tm, b);
                 if (mine) { L_now = a; L_pending = b; sdir = c; stmax = tm; pending = pe; }
             }
             if (active) {
@@ -466,13 +465,12 @@ __global__ __launch_bounds__(QE_THREADS, KY_QE_WAVES) void render_kernel_q(const
                 qe_vertex(v, Lds, mk3(W.ox[sl], W.oy[sl], W.oz[sl]), d, (int)((inf >> 16) & 0xffu), (int)(inf & 3u));
                 Sampler smp{W.rs[sl], W.ri[sl]};
                 const float u0 = sampler_next<DEBUG_SAMPLER>(smp), u1 = sampler_next<DEBUG_SAMPLER>(smp);
-                BsdfSample bs = bsdf_sample_local(v.bsdf, v.wo_l, u0, u1);
-                bs.wi = to_world(v.frame, bs.wi);
-                bool ended = is_black(bs.f) || bs.pdf == 0.f;   // 4588
+                const BsdfContinue bs = bsdf_continue(v, -d, u0, u1);   // direction + f |cos| / pdf in one factor (ky_device.hpp)
+                bool ended = !bs.ok;   // 4588
                 if (!ended) {
                     f3 beta = mk3(W.br[sl], W.bg[sl], W.bb[sl]);
-                    beta = beta * (bs.f * (fabsf(dot(bs.wi, v.normal)) * rcp(bs.pdf)));  // 4592
-                    const bool specular = (bs.flags & BSDF_SPECULAR) != 0;                // 4596
+                    beta = beta * bs.weight;  // 4592
+                    const bool specular = bs.specular;                                    // 4596
                     const f3 o = offset_ray_origin(v.position, v.normal, bs.wi);         // 4597
                     int bounces = (int)((inf >> 8) & 0xffu);
                     if (bounces > 3) {  // Russian roulette, 4601-4612

@@ -163,7 +163,7 @@ static ShardConst make_shard(const ky_render_params* p) {
 #define KY_WAVES_PER_EU 6           // the hot instantiation <false, both_mis>: 80 VGPRs
 #endif
 #ifndef KY_WAVES_PER_EU_QUEUE
-#define KY_WAVES_PER_EU_QUEUE 6     // the instantiation with deferred shadow rays
+#define KY_WAVES_PER_EU_QUEUE 5     // the instantiation with deferred shadow rays: 96 VGPRs (6 spilled) beat 80 (28 spilled) by 3.5 % since round 3
 #endif
 #ifndef KY_WAVES_PER_EU_GENERIC
 #define KY_WAVES_PER_EU_GENERIC 5   // strategy / integrator read at run time: more code alive at once, 96 VGPRs measured best
@@ -184,7 +184,7 @@ struct ItemSlot {  // one fetched work item, decoded once (wave-uniform) and rea
 template <bool DEBUG_SAMPLER, int STRATEGY, bool QUEUE = false, bool GENERAL = false, int FEAT = 0>
 __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? KY_WAVES_PER_EU_QUEUE : KY_WAVES_PER_EU) : KY_WAVES_PER_EU_GENERIC) void render_kernel(const DScene* __restrict__ S_, RenderConst rc, ShardConst sh,
                                                                      unsigned* __restrict__ counter, unsigned long long* __restrict__ accum,
-                                                                     unsigned* __restrict__ flags, float* __restrict__ queue_mem) {
+                                                                     unsigned* __restrict__ flags, float4* __restrict__ queue_mem) {
     static_assert(!QUEUE || STRATEGY == KY_DIRECT_BOTH_MIS, "the deferred shadow rays are built into the both_mis instantiation");
     static_assert(FEAT == 0 || (STRATEGY == KY_DIRECT_BOTH_MIS && !QUEUE && !GENERAL && !DEBUG_SAMPLER), "scene facts are instantiated for the both_mis kernel only");
     const SceneRef S{S_, GENERAL, FEAT};
@@ -212,11 +212,10 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? KY_WAVES_PER_EU_QUEUE
     // per lane: the pixel chunk being worked on
     c_lsum[0][tid] = 0.f; c_lsum[1][tid] = 0.f; c_lsum[2][tid] = 0.f;
     c_pix[tid] = -1;
-    ShadowQueue sq{nullptr, 0};
-    const SqSink sink{c_pix, c_def, accum, flags};
+    ShadowQueue sq{nullptr, 0, c_pix, c_def, accum, flags};
     if (QUEUE) {
         c_def[tid] = 0; c_def[256 + tid] = 0; c_def[512 + tid] = 0;
-        sq.base = queue_mem + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * (KY_SQ_FIELDS * KY_SQ_CAP);
+        sq.base = queue_mem + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * (KY_SQ_ENTRY * KY_SQ_CAP);
     }
     bool open = false;        // the chunk has samples left to start (s < s_end)
     bool has_item = false, done = false, alive = false;
@@ -225,9 +224,6 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? KY_WAVES_PER_EU_QUEUE
     KY_CLK(-1);
     for (;;) {
         KY_CLK(9);   // continuation sampling, roulette, loop overhead
-        if (QUEUE) {  // enough deferred shadow rays for a full wavefront: trace them now (wave-uniform)
-            while (sq.n >= 64) sq_resolve(S, sq, 64, sink);
-        }
         // ---- (1) lanes whose pixel chunk is finished flush it and take the next (item, pixel) pair of the wave's pool.
         // A lane is NOT tied to one pixel position: whichever lane is free takes the next pixel, so lanes never wait
         // for each other and the wave drains within one chunk of the end of the queue.
@@ -345,7 +341,7 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? KY_WAVES_PER_EU_QUEUE
         }
     }
     if (QUEUE) {  // what is left on the stack: the lanes have flushed, so these go to the global accumulators
-        while (sq.n > 0) sq_resolve(S, sq, sq.n < 64 ? sq.n : 64, sink);
+        sq_drain(S, sq);
     }
     KY_CLK(-2);
 }
@@ -428,12 +424,14 @@ __global__ void kat_bsdf_kernel(DMat M, const float* __restrict__ in12, int n, f
     if (i >= n) return;
     const float* r = in12 + 12 * (size_t)i;
     const f3 normal = ld3(r), wo = ld3(r + 3), wi_eval = ld3(r + 8);
-    const Bsdf B = make_bsdf(M, r[11]);
-    const Frame fr = make_frame(normal);
-    BsdfSample bs = bsdf_sample_local(B, to_local(fr, wo), r[6], r[7]);
-    bs.wi = to_world(fr, bs.wi);
-    f3 ev; float pd;
-    bsdf_eval_pdf(B, to_local(fr, wo), to_local(fr, wi_eval), ev, pd);
+    Vertex v;
+    v.normal = normal;
+    v.bsdf = make_bsdf(M, r[11]);
+    const Bsdf& B = v.bsdf;
+    vertex_prepare(v, wo);
+    const BsdfSample bs = bsdf_sample(v, wo, r[6], r[7]);
+    f3 ev; float pd, abs_cos_i;
+    bsdf_eval_pdf(v, wo, wi_eval, ev, pd, abs_cos_i);
     float* q = out13 + 13 * (size_t)i;
     q[0] = bs.f.x; q[1] = bs.f.y; q[2] = bs.f.z; q[3] = bs.wi.x; q[4] = bs.wi.y; q[5] = bs.wi.z; q[6] = bs.pdf;
     q[7] = (float)bs.flags; q[8] = ev.x; q[9] = ev.y; q[10] = ev.z; q[11] = pd; q[12] = bsdf_is_delta(B) ? 1.f : 0.f;
@@ -514,16 +512,16 @@ __global__ void kat_nee_kernel(const DScene* __restrict__ S, int strategy, int l
     for (int j = 0; j < S->n_surfaces; ++j)
         if (S->orig[j] == (int)r[9]) v.surface = j;          // the caller's surface index -> the device's sorted index
     v.bsdf = make_bsdf(Lds.mat[Lds.hit[v.surface].material], r[10]);
-    const Frame fr = make_frame(v.normal);
-    vertex_set_frame(v, fr, to_local(fr, ld3(r + 6)));
+    const f3 wo = ld3(r + 6);
+    vertex_prepare(v, wo);
     f3 Lb = mk3(0, 0, 0), Ll = mk3(0, 0, 0);
     const bool nee = active && !bsdf_is_delta(v.bsdf);        // sample_all_light runs for non-delta vertices only (4571)
     // (wave-uniform calls: every lane makes them, `nee` says whether it takes part)
-    if (strategy == KY_DIRECT_BSDF) Lb = estimate_by_bsdf<false>(S, Lds, v, li, r[11], r[12], nee);
-    else if (strategy == KY_DIRECT_BSDF_MIS || strategy == KY_DIRECT_BOTH_MIS) Lb = estimate_by_bsdf<true>(S, Lds, v, li, r[11], r[12], nee);
+    if (strategy == KY_DIRECT_BSDF) Lb = estimate_by_bsdf<false>(S, Lds, v, wo, li, r[11], r[12], nee);
+    else if (strategy == KY_DIRECT_BSDF_MIS || strategy == KY_DIRECT_BOTH_MIS) Lb = estimate_by_bsdf<true>(S, Lds, v, wo, li, r[11], r[12], nee);
     if (nee) {
-        if (strategy == KY_DIRECT_LIGHT) Ll = estimate_by_emitter<false>(S, Lds, v, li, r[13], r[14]);
-        else if (strategy == KY_DIRECT_LIGHT_MIS || strategy == KY_DIRECT_BOTH_MIS) Ll = estimate_by_emitter<true>(S, Lds, v, li, r[13], r[14]);
+        if (strategy == KY_DIRECT_LIGHT) Ll = estimate_by_emitter<false>(S, Lds, v, wo, li, r[13], r[14]);
+        else if (strategy == KY_DIRECT_LIGHT_MIS || strategy == KY_DIRECT_BOTH_MIS) Ll = estimate_by_emitter<true>(S, Lds, v, wo, li, r[13], r[14]);
     }
     if (active) {
         float* o = out6 + 6 * (size_t)i;
@@ -659,6 +657,8 @@ static void pack_material(const ky_material& m, DMat* d) {
         d->eta = 1.f / (m.exponent + 1.f);
         d->inv_eta = (m.exponent + 2.f) * inv_2pi;
         d->phong_pdf_norm = (m.exponent + 1.f) * inv_2pi;
+        // what a path's throughput is multiplied by (per unit |cos|) when it continues through the Phong lobe: value / pdf, the pow cancels
+        for (int j = 0; j < 3; ++j) d->c1[j] = (d->cs[j] * d->inv_eta) / d->phong_pdf_norm;
     }
     const float e = m.exponent;
     const bool integral = std::isfinite(e) && std::fabs(e) < 16777216.f && std::floor(e) == e;
@@ -1038,7 +1038,7 @@ struct DeviceCtx {
     hipStream_t stream = nullptr;   // the library's own stream on this device (kyhip_render_multi)
     int blocks_per_cu[4] = {0, 0, 0, 0};   // render_kernel <false, both_mis>, <false, -1>, <true, -1>, <false, both_mis, QUEUE>
     int q_blocks_per_cu[3] = {0, 0, 0};
-    float* d_shadow_queue = nullptr;       // the wavefronts' shadow-ray stacks (QUEUE instantiation), allocated on first use
+    float4* d_shadow_queue = nullptr;       // the wavefronts' shadow-ray stacks (QUEUE instantiation), allocated on first use
     bool scene_valid = false;
 };
 static std::mutex g_ctx_mutex;                          // guards g_ctx itself (creation), never held while enqueueing
@@ -1270,7 +1270,7 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
         variant = 3;
         if (!c->d_shadow_queue) {
             const int per_cu = c->blocks_per_cu[3] > 0 ? c->blocks_per_cu[3] : 1;
-            HIP_TRY(hipMalloc(&c->d_shadow_queue, (size_t)c->cus * per_cu * 4 * KY_SQ_FIELDS * KY_SQ_CAP * sizeof(float)));
+            HIP_TRY(hipMalloc(&c->d_shadow_queue, (size_t)c->cus * per_cu * 4 * KY_SQ_ENTRY * KY_SQ_CAP * sizeof(float4)));
         }
     }
     HIP_TRY(hipEventRecord(c->ev0, stream));
@@ -1292,7 +1292,7 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
         const unsigned need_blocks = sh.n_items / 4 + 1;
         if (grid > need_blocks) grid = need_blocks;
         if (grid < 1) grid = 1;
-        float* const no_queue = nullptr;
+        float4* const no_queue = nullptr;
         const int feat = c->h_scene->feat;   // an instantiation may run when the scene has every fact it assumes
         if (variant == 0 && (feat & KY_FEAT_CORNELL) == KY_FEAT_CORNELL) hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);
         else if (variant == 0) hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_BOTH_MIS>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);

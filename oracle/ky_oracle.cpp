@@ -1213,6 +1213,19 @@ int kyo_kat_intersect(const ky_shape* shape, const float* rays7, int n, float* o
     return KY_OK;
 }
 
+// frame_t (526-578): in n x {normal[3], v[3]}; out n x {s[3], t[3], n[3], to_local(v)[3], to_world(v)[3]}
+int kyo_kat_frame(const float* in6, int n, float* out15) {
+    for (int i = 0; i < n; ++i) {
+        const float* r = in6 + 6 * i;
+        const frame_t f{vec3_t(r)};
+        const vec3_t v(r + 3), l = f.to_local(v), w = f.to_world(v);
+        float* o = out15 + 15 * i;
+        o[0] = f.s_.x; o[1] = f.s_.y; o[2] = f.s_.z; o[3] = f.t_.x; o[4] = f.t_.y; o[5] = f.t_.z; o[6] = f.n_.x; o[7] = f.n_.y; o[8] = f.n_.z;
+        o[9] = l.x; o[10] = l.y; o[11] = l.z; o[12] = w.x; o[13] = w.y; o[14] = w.z;
+    }
+    return KY_OK;
+}
+
 int kyo_kat_camera(const ky_camera* camera, const float* p_film2, int n, float* out6) {
     for (int i = 0; i < n; ++i) {
         ray_t ray = generate_ray(*camera, vec2_t{p_film2[2 * i], p_film2[2 * i + 1]});

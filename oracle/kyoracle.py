@@ -34,6 +34,7 @@ def load():
         _lib.kyo_li.argtypes = [A.SP, A.PP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         _lib.kyo_kat_intersect.argtypes = [C.POINTER(A.Shape), C.c_void_p, C.c_int, C.c_void_p]
         _lib.kyo_kat_camera.argtypes = [C.POINTER(A.Camera), C.c_void_p, C.c_int, C.c_void_p]
+        _lib.kyo_kat_frame.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         _lib.kyo_kat_bsdf.argtypes = [C.POINTER(A.Material), C.c_void_p, C.c_int, C.c_void_p]
         _lib.kyo_kat_light.argtypes = [A.SP, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         _lib.kyo_kat_scene_intersect.argtypes = [A.SP, C.c_void_p, C.c_int, C.c_void_p]
@@ -92,6 +93,14 @@ def kat_intersect(shape, rays7):
     rays7 = np.ascontiguousarray(rays7, np.float32)
     out = np.zeros((rays7.shape[0], 8), np.float32)
     load().kyo_kat_intersect(C.byref(shape), _f(rays7), rays7.shape[0], _f(out))
+    return out
+
+
+def kat_frame(in6):
+    """frame_t(normal) and its to_local / to_world of v: n x {normal[3], v[3]} -> n x {s[3], t[3], n[3], local[3], world[3]}"""
+    in6 = np.ascontiguousarray(in6, np.float32)
+    out = np.zeros((in6.shape[0], 15), np.float32)
+    load().kyo_kat_frame(_f(in6), in6.shape[0], _f(out))
     return out
 
 

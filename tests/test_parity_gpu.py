@@ -485,8 +485,10 @@ def test_engines_agree(A, api):
             assert a.max() > 0 or p.direct_sample == A.DIRECT_BSDF, (p.samples_per_pixel, p.direct_sample)
             assert np.array_equal(b, b2)                       # scheduling does not show in the image
             # same arithmetic per sample, but the two kernels inline it into different surroundings (fp contraction can differ
-            # by an ulp per term) and sum a pixel's samples (unclamped, up to the light's radiance) in different orders: ~1e-5 on the clamped mean
-            assert np.abs(a - b).max() <= 2e-5, (p.samples_per_pixel, p.direct_sample, float(np.abs(a - b).max()))
+            # by an ulp per term) and sum a pixel's samples (unclamped, up to the light's radiance) in different orders: ~1e-5 on the clamped mean.
+            # The Veach planks' exponent-5000 lobe turns an ulp of cos(alpha) into 6e-4 of its value: 1e-4 there (measured 6.8e-5)
+            veach = scene.c.light_count == 5
+            assert np.abs(a - b).max() <= (1e-4 if veach else 2e-5), (p.samples_per_pixel, p.direct_sample, float(np.abs(a - b).max()))
             if p.integrator != A.INTEGRATOR_PATH_TRACING_ITERATION:
                 assert np.array_equal(a, b)
     finally:

@@ -3,7 +3,9 @@
 NAME=$1; shift
 BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical -no-hip-rt -fno-slp-vectorize -fno-hip-fp32-correctly-rounded-divide-sqrt -DKY_WAVES_PER_EU=6"
 SRC=${KY_SRC:-ky_amd/csrc/kyhip.hip}
+mkdir -p /tmp/bv build_variants
 hipcc $BASE "$@" -Rpass-analysis=kernel-resource-usage -shared -o build_variants/$NAME.so $SRC 2> /tmp/bv/$NAME.log
-grep -A9 "Function Name: _Z13render_kernel" /tmp/bv/$NAME.log | grep -E "Function Name|VGPRs:|Spill|Occupancy|TotalSGPRs|ScratchSize" | sed 's/.*usage\]//; s/remark: [^ ]* //; s/\[-Rpass.*//' > build_variants/$NAME.txt
+python3 tools/resources.py /tmp/bv/$NAME.log > build_variants/$NAME.txt
 grep -E "error" /tmp/bv/$NAME.log | head -5
-echo "== $NAME: $*"; cat build_variants/$NAME.txt | tr '\n' ' ' | sed 's/Function Name/\n  FN/g'; echo
+if grep -q "error:" /tmp/bv/$NAME.log; then echo "BUILD FAILED: $NAME"; exit 1; fi
+echo "== $NAME: $*"; cat build_variants/$NAME.txt

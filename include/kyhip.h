@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define KYHIP_ABI_VERSION 2
+#define KYHIP_ABI_VERSION 3
 
 /* ------------------------------------------------------------------------------------------
  * Scene description: a flat restatement of what scene_t holds (ky.cpp:3535-3546) and what the
@@ -228,10 +228,12 @@ int kyhip_render(int device, const ky_scene* scene, const ky_render_params* para
  * kyhip_film_add_tiles_device: the de-interleave step after the gather: adds the compact tiles of
  *   shard (tile_first, tile_step) into a DEVICE film (same layout as kyhip_render's film_rgb).
  *
- * Streams: the calls on one device share the library's per-device render state (scene copy, work counter, cached
- *   workspace, timing events).  A call on another stream than the previous call's first waits ON THE DEVICE for that
- *   previous call's kernels (an event), so calls for one device execute one after the other whatever streams they use;
- *   calls for different devices are independent (one lock and one state per device).
+ * Streams: what a launch writes (work counter, accumulator workspace, timing events, shadow-ray stacks) belongs to the STREAM it is
+ *   enqueued on -- the library keeps one such state per (device, stream), up to four per device -- so calls on one stream execute in
+ *   stream order and calls on different streams share nothing and may overlap on the device: a frame's kernel starts on the compute
+ *   units the previous frame's persistent kernel is draining from (ky_amd/dist.py alternates two streams).  The packed scene is cached
+ *   per device by content (eight slots): alternating between a few scenes uploads each once.  Calls for different devices are
+ *   independent (one lock per device).
  *
  * kyhip_film_add_gathered_device: the same de-interleave for ALL shards of a frame in one kernel.  The frame described
  *   by params (tile_first, tile_step) was rendered as `world` shards -- shard r = (tile_first + r * tile_step,
@@ -265,6 +267,10 @@ int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene,
  * kernel.  The stream must have been synchronised.  Negative if no timing is available.
  */
 float kyhip_kernel_ms(int device);
+/* Which render-kernel instantiation that call launched, e.g. "render_kernel<strategy 48, feat 7, integrator 11>" (the library holds one
+   per direct-lighting strategy, integrator and set of scene facts; kyhip.hip, g_variants).  The string stays valid until the next call
+   of this function from the same thread.  "" if nothing was launched. */
+const char* kyhip_last_kernel(int device);
 
 /* ------------------------------------------------------------------------------------------
  * Function-level entry points (known-answer tests).  Each runs the DEVICE implementation of one

@@ -101,6 +101,7 @@ KYHIP_SYMBOLS = {
     "kyhip_film_add_gathered_device": (C.c_int, [C.c_int, PP, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "kyhip_render_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, SP, PP, C.c_void_p, C.c_size_t]),
     "kyhip_kernel_ms": (C.c_float, [C.c_int]),
+    "kyhip_last_kernel": (C.c_char_p, [C.c_int]),
     "kyhip_kat_nee": (C.c_int, [C.c_int, SP, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "kyhip_kat_li_trace": (C.c_int, [C.c_int, SP, PP, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "kyhip_smallpt_scene": (C.c_int, [SSP]),

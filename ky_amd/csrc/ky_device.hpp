@@ -251,9 +251,13 @@ struct DScene {
 enum : int {
     KY_FEAT_SINGLE_AREA = 1,     // the lights are exactly ONE area light, no environment light: no other light kind's code, no environment term, no lights loop
     KY_FEAT_RECT_LIGHTS = 2,     // every area light samples a rectangle (the Cornell lamp): no sphere / triangle / disk light sampling
-    KY_FEAT_CARRIERS = 4         // every area light is carried by at most KY_MAX_CARRIERS surfaces and the scene has no general shapes: the
+    KY_FEAT_CARRIERS = 4,        // every area light is carried by at most KY_MAX_CARRIERS surfaces and the scene has no general shapes: the
                                  // BSDF-sampling estimators always take the carrier test, never the full traversal (estimate_by_bsdf)
+    KY_FEAT_SINGLE_DELTA = 8,    // the lights are exactly ONE point or directional light, no environment light: the BSDF-sampling estimators
+                                 // are gone (they return black for a delta light, 3894 / 3977), and with them every area / environment path
+    KY_FEAT_SINGLE_ENV = 16      // the lights are exactly ONE environment light (which is the scene's environment): no area / delta light code
 };
+constexpr int KY_FEAT_SINGLE_LIGHT = KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_DELTA | KY_FEAT_SINGLE_ENV;   // any of them: no lights loop
 // (Measured and not kept: "every area light samples a sphere" + "no mirror or glass material" for the Veach scene: 11 fewer spilled
 // registers in the instantiation with deferred shadow rays, no change in time.)
 struct SceneRef {
@@ -264,6 +268,18 @@ struct SceneRef {
     __device__ __forceinline__ SceneRef(const DScene* p_, bool general_, int feat_ = 0) : p(p_), general(general_), feat(feat_) {}
     __device__ __forceinline__ const DScene* operator->() const { return p; }
     __device__ __forceinline__ bool single_area() const { return (feat & KY_FEAT_SINGLE_AREA) != 0; }
+    __device__ __forceinline__ bool single_light() const { return (feat & KY_FEAT_SINGLE_LIGHT) != 0; }
+    // light kinds as far as the instantiation's facts decide them (wave-uniform; the rest is read from the light)
+    __device__ __forceinline__ bool is_area(int kind) const {
+        return (feat & KY_FEAT_SINGLE_AREA) ? true : ((feat & (KY_FEAT_SINGLE_DELTA | KY_FEAT_SINGLE_ENV)) ? false : kind == KY_LIGHT_AREA);
+    }
+    __device__ __forceinline__ bool is_delta(int kind) const {
+        return (feat & KY_FEAT_SINGLE_DELTA) ? true : ((feat & (KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_ENV)) ? false : (kind == KY_LIGHT_POINT || kind == KY_LIGHT_DIRECTION));
+    }
+    __device__ __forceinline__ bool is_env(int kind) const {
+        return (feat & KY_FEAT_SINGLE_ENV) ? true : ((feat & (KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_DELTA)) ? false : kind == KY_LIGHT_ENVIRONMENT);
+    }
+    __device__ __forceinline__ bool may_have_env() const { return (feat & (KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_DELTA)) == 0; }
 };
 
 struct LdsScene {  // the per-workgroup LDS copy of the tables that are indexed per lane
@@ -953,7 +969,8 @@ KY_DEV float env_pdf(float wz) {
 // light_t::sample_Li x4 (2825, 2891, 2964, 3026)
 KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0, float u1, int feat = 0) {
     LightSample s;   // every kind (wave-uniform) assigns every field
-    if ((feat & KY_FEAT_SINGLE_AREA) || L.kind == KY_LIGHT_AREA) {
+    const SceneRef K{nullptr, false, feat};   // the kind predicates only
+    if (K.is_area(L.kind)) {
         f3 lposition, lnormal;
         shape_sample_direction(L, p, p_normal, u0, u1, lposition, lnormal, s.pdf, feat);
         s.position = lposition;
@@ -965,7 +982,7 @@ KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0,
         // areal_radiance(light_isect, -wi) with the SAMPLED (stored) normal: one-sided (quirk 5), 2957-2960
         const bool lit = ok && dot(lnormal, wi) < 0;
         s.Li = mk3(lit ? L.color[0] : 0.f, lit ? L.color[1] : 0.f, lit ? L.color[2] : 0.f);
-    } else if (L.kind == KY_LIGHT_POINT) {
+    } else if (K.is_delta(L.kind) && L.kind == KY_LIGHT_POINT) {
         const f3 lp = ld3(L.position);
         const f3 dv = lp - p;
         const float inv_d2 = rcp(length_sq(dv));
@@ -973,7 +990,7 @@ KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0,
         s.wi = dv * fsqrt(inv_d2);
         s.pdf = 1.f;
         s.Li = ld3(L.color) * inv_d2;
-    } else if (L.kind == KY_LIGHT_DIRECTION) {
+    } else if (K.is_delta(L.kind)) {   // directional
         s.wi = -ld3(L.direction);
         s.position = p + s.wi * (2 * L.world_radius);
         s.pdf = 1;
@@ -989,8 +1006,9 @@ KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0,
 
 // light_t::pdf_Li x4 (2855, 2903, 2984, 3043)
 KY_DEV float light_pdf_Li(const DLight& L, const DShapeFull* __restrict__ full, f3 p, f3 p_normal, f3 wi, bool general = true, int feat = 0) {
-    if ((feat & KY_FEAT_SINGLE_AREA) || L.kind == KY_LIGHT_AREA) return shape_pdf_direction(L, full, p, p_normal, wi, general, feat);
-    if (L.kind == KY_LIGHT_ENVIRONMENT) return env_pdf(wi.z);
+    const SceneRef K{nullptr, false, feat};
+    if (K.is_area(L.kind)) return shape_pdf_direction(L, full, p, p_normal, wi, general, feat);
+    if (K.is_env(L.kind)) return env_pdf(wi.z);
     return 0;
 }
 
@@ -1019,7 +1037,7 @@ template <bool MIS>
 KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, int li, float u0, float u1, bool active) {
     const DLight& L = S->light[li];
     f3 Ld = mk3(0, 0, 0);
-    if (!S.single_area() && (L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION)) return Ld;  // light.is_delta(), 3894 / 3977 (wave-uniform)
+    if (S.is_delta(L.kind)) return Ld;  // light.is_delta(), 3894 / 3977 (wave-uniform)
     BsdfSample bs;
     // what `live` guards: read at the end only for lanes whose sample counts (and, in the query loop, through __shfl from such lanes)
     f3 f_cos = any3(), o = any3(), Li = mk3(0, 0, 0);
@@ -1027,7 +1045,7 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 
     bs.f = any3();
     bs.pdf = any_f();
     bool live = false;
-    const bool fast = (S.single_area() || L.kind == KY_LIGHT_AREA) && ((S.feat & KY_FEAT_CARRIERS) || (L.n_carriers >= 0 && S->n_gen == 0));  // wave-uniform
+    const bool fast = S.is_area(L.kind) && ((S.feat & KY_FEAT_CARRIERS) || (L.n_carriers >= 0 && S->n_gen == 0));  // wave-uniform
     if (fast) {
         // Only the DIRECTION is sampled up front; the BSDF value and pdf (a pow for the Phong lobe) are evaluated for the few
         // lanes whose ray reaches a carrier that emits towards it -- for all other lanes Li = 0 decides the estimate (3996-4003).
@@ -1102,7 +1120,7 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 
                 const f3 hp = o + t * bs.wi;
                 Li = surface_emission(Lds, hs, hit_normal(Lds.hit[hs], hp, bs.wi), -bs.wi);
             }
-        } else if (live && !S.single_area() && L.kind == KY_LIGHT_ENVIRONMENT) {
+        } else if (live && S.is_env(L.kind)) {
             Li = ld3(L.color);  // light.environmental_radiance(ray), 3918 / 4000
         }
     }
@@ -1235,7 +1253,7 @@ KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, f3 wo, int
         float bsdf_pdf, abs_cos_i;
         bsdf_eval_pdf(v, wo, ls.wi, f, bsdf_pdf, abs_cos_i);
         const f3 f_cos = f * abs_cos_i;
-        const bool delta_light = L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION;
+        const bool delta_light = S.is_delta(L.kind);
         const f3 Ld = delta_light ? (f_cos * ls.Li) * rcp(ls.pdf) : (f_cos * ls.Li) * (2.f * rcp(ls.pdf + bsdf_pdf));   // 4057 / 4070
         r.c = (Ld * beta) * weight;   // the product beta x weight is not kept in registers across the lights loop: three multiplies per light instead
         // scene_t::occluded(isect, ls.position), 3187-3201: the ray
@@ -1247,7 +1265,7 @@ KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, f3 wo, int
         r.o = offset_ray_origin(v.position, v.normal, r.d);
         push = !(is_black(ls.Li) || ls.pdf <= 0) && !is_black(f_cos) && !(r.c.x == 0.f && r.c.y == 0.f && r.c.z == 0.f);
         // the sampled shape itself is the likeliest occluder (quirk 1): one test here saves the ray a full traversal
-        if (L.kind == KY_LIGHT_AREA && L.sampled_is_surface) {   // wave-uniform
+        if (S.is_area(L.kind) && L.sampled_is_surface) {   // wave-uniform
             float t;
             if (surf_hit(L.isect, S->full, r.o, r.d, r.tmax, t, S.general)) push = false;
         }
@@ -1302,7 +1320,7 @@ KY_DEV f3 estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, 
             bsdf_eval_pdf(v, wo, ls.wi, f, bsdf_pdf, abs_cos_i);
             const f3 f_cos = f * abs_cos_i;
             if (!is_black(f_cos)) {
-                const bool delta_light = !S.single_area() && (L.kind == KY_LIGHT_POINT || L.kind == KY_LIGHT_DIRECTION);
+                const bool delta_light = S.is_delta(L.kind);
                 if (!MIS || delta_light) Ld = (f_cos * ls.Li) * rcp(ls.pdf);          // 3956 / 4057
                 else Ld = (f_cos * ls.Li) * (2.f * rcp(ls.pdf + bsdf_pdf));            // 4070
             }
@@ -1322,7 +1340,7 @@ template <bool DEBUG_SAMPLER>
 KY_DEV f3 sample_all_light(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, Sampler& smp, int strategy, bool active,
                            unsigned* decisions = nullptr, ShadowQueue* sq = nullptr, f3 beta = f3{0, 0, 0}, float weight = 0.f, unsigned tag = 0) {
     f3 Ld = mk3(0, 0, 0);
-    const int nl = S.single_area() ? 1 : S->n_lights;
+    const int nl = S.single_light() ? 1 : S->n_lights;
     for (int li = 0; li < nl; ++li) {
         // the reference's GCC build draws random_bsdf first, then random_light (3866-3868), for every light and strategy
         float ub0 = any_f(), ub1 = any_f(), ul0 = any_f(), ul1 = any_f();   // drawn, and read, by the active lanes only
@@ -1351,7 +1369,7 @@ KY_DEV f3 sample_all_light(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 
             if (active) Ll = estimate_by_emitter<false>(S, Lds, v, wo, li, ul0, ul1);
         } else if (strategy == KY_DIRECT_BSDF) {
             const int lk = S->light[li].kind;
-            if (!(lk == KY_LIGHT_POINT || lk == KY_LIGHT_DIRECTION)) {  // the third float2 is drawn after the delta test (3894-3900)
+            if (!S.is_delta(lk)) {  // the third float2 is drawn after the delta test (3894-3900)
                 float u0 = any_f(), u1 = any_f();
                 if (active) { u0 = sampler_next<DEBUG_SAMPLER>(smp); u1 = sampler_next<DEBUG_SAMPLER>(smp); }
                 Lb = estimate_by_bsdf<false>(S, Lds, v, wo, li, u0, u1, active);
@@ -1414,7 +1432,7 @@ KY_DEV bool path_intersect(PathState& ps, Vertex& v, SceneRef S, const LdsScene&
         emission = surface_emission(Lds, hs, v.normal, -ps.d);
     }
 
-    const f3 env = (!S.single_area() && S->env_light >= 0) ? ld3(S->light[S->env_light].color) : mk3(0, 0, 0);  // environment_lighting, 3231
+    const f3 env = (S.may_have_env() && S->env_light >= 0) ? ld3(S->light[S->env_light].color) : mk3(0, 0, 0);  // environment_lighting, 3231
     if (rc.integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION || rc.integrator == KY_INTEGRATOR_DIRECT_LIGHTING ||
         rc.integrator == KY_INTEGRATOR_PATH_TRACING_RECURSION_DEFERED) {
         if (ps.bounces == 0 || ps.prev_specular) ps.Lo = ps.Lo + ps.beta * (hit ? emission : env);  // 4548-4559 / 4449-4452
@@ -1504,7 +1522,7 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, SceneRef S, const LdsScene& Lds
         const BsdfSample es = bsdf_sample(v, wo, e0, e1);
         float t = K_INF;
         const int hs = trace_nearest(S, v.position, es.wi, t);
-        f3 Le = S->env_light >= 0 ? ld3(S->light[S->env_light].color) : mk3(0, 0, 0);
+        f3 Le = (S.may_have_env() && S->env_light >= 0) ? ld3(S->light[S->env_light].color) : mk3(0, 0, 0);
         if (hs >= 0) {
             const f3 hp = v.position + t * es.wi;
             Le = surface_emission(Lds, hs, hit_normal(Lds.hit[hs], hp, es.wi), -es.wi);

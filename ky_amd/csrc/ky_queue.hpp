@@ -182,8 +182,8 @@ KY_DEV unsigned qe_take_units(QeLds& W, int lane, unsigned n, unsigned* __restri
                 const int bx = inner % sh.blocks_w, by = inner / sh.blocks_w;
                 const int tile = sh.tile_first + k * sh.tile_step;
                 const int trow = tile / sh.tiles_x, tcol = (tile % sh.tiles_x + trow) % sh.tiles_x;   // rotated rows
-                const int s_begin = c < sh.n_big ? c * KY_CHUNK : sh.head + (c - sh.n_big) * KY_CHUNK_SMALL;
-                const int s_end = c < sh.n_big ? s_begin + KY_CHUNK : min(spp, s_begin + KY_CHUNK_SMALL);
+                int s_begin, s_end;
+                chunk_range(chunk_plan(spp), c, s_begin, s_end);
                 const unsigned u0 = lds_load(&W.units_fetched), ni = lds_load(&W.n_items);
                 QeItem* it = &W.items[ni % QE_ITEMS];
                 __hip_atomic_store(&it->n_units, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

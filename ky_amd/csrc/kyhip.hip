@@ -64,33 +64,82 @@ static int fail(int code, const char* fmt, ...) {
 // ------------------------------------------------------------------------------------------------
 // shard geometry (host + device)
 // ------------------------------------------------------------------------------------------------
-// Samples of a pixel are cut into chunks (= work items) by a schedule that depends on spp ONLY (chunk boundaries
-// must not depend on the sharding, or images would differ between GPU counts): KY_CHUNK-sample chunks, except that
-// the last KY_TAIL samples are cut into KY_CHUNK_SMALL-sample chunks.  Items are queued chunk-major, so the small
-// chunks of all blocks come last and the end-of-kernel tail is one small item, not one big one.
+// Samples of a pixel are cut into chunks (= work items) by a schedule that depends on spp ONLY (chunk boundaries must not depend on
+// the sharding, or images would differ between GPU counts: a chunk's samples are summed in float before they enter the fixed-point
+// accumulator).  The bulk is KY_CHUNK-sample chunks; the END of the sample range tapers off -- KY_TAPER_16 samples in 16-sample
+// chunks, then KY_TAPER_8 in 8s, KY_TAPER_4 in 4s, KY_TAPER_2 in 2s -- and items are queued chunk-major, so the small chunks of all
+// blocks come last: the tail of a launch, where wavefronts run out of work one by one, is as long as ONE of the smallest items, while
+// nearly all samples are rendered in chunks large enough to make the per-chunk bookkeeping (flush, refill) invisible.
+// Sizing (tools/shard_scan.py, profiles/r03_taper_scan.txt): a wavefront needs about 1.1 ms for a 32-sample item, and wavefronts
+// finish their last one up to that far apart; the stage that follows evens it out if it holds at least as much work per wavefront,
+// which for a 1/8 shard of configs[1] (7.3 ms per launch) is 256 samples of 16, then 128 of 8, then 64 of 4.  Measured kernel-level
+// efficiency at N = 8: no taper 0.88, 256 samples of 8 (round 2) 0.93, 128/64/32 0.92, 256/128/64 0.96; longer tapers (384/192/96/48)
+// do not make the shard faster and cost the full frame 1-2.5 %.
 #ifndef KY_CHUNK_BIG
 #define KY_CHUNK_BIG 32
 #endif
-#ifndef KY_TAIL_SAMPLES
-#define KY_TAIL_SAMPLES 256
+#ifndef KY_TAPER_16
+#define KY_TAPER_16 256
+#endif
+#ifndef KY_TAPER_8
+#define KY_TAPER_8 128
+#endif
+#ifndef KY_TAPER_4
+#define KY_TAPER_4 64
+#endif
+#ifndef KY_TAPER_2
+#define KY_TAPER_2 0
 #endif
 constexpr int KY_CHUNK = KY_CHUNK_BIG;
 static_assert(KY_CHUNK_BIG <= 127, "the lane's sample cursor keeps the chunk's remaining samples in 7 bits");
-constexpr int KY_CHUNK_SMALL = 8;
-constexpr int KY_TAIL = KY_TAIL_SAMPLES;
 #ifndef KY_RING_SLOTS
 #define KY_RING_SLOTS 4
 #endif
 constexpr int KY_RING = KY_RING_SLOTS;          // fetched-but-not-yet-started items a wave can hold
 constexpr double KY_FIX_SCALE = 4294967296.0;   // 2^32: accumulator resolution 2.3e-10, range +-2.1e9
 
+// The chunk schedule of `spp` samples (host and device; wave-uniform scalar arithmetic on the device, once per fetched item; written
+// without arrays so that nothing of it lives in scratch memory).
+struct ChunkPlan {
+    int n_big, head;            // chunks of KY_CHUNK samples cover [0, head)
+    int b1, b2, b3, b4;         // 16-sample chunks cover [head, b1), 8s [b1, b2), 4s [b2, b3), 2s [b3, b4 = spp)
+    int n16, n8, n4, n2;
+};
+__host__ __device__ inline ChunkPlan chunk_plan(int spp) {
+    ChunkPlan p;
+    p.b4 = spp;
+    p.b3 = p.b4 > KY_TAPER_2 ? p.b4 - KY_TAPER_2 : 0;
+    p.b2 = p.b3 > KY_TAPER_4 ? p.b3 - KY_TAPER_4 : 0;
+    p.b1 = p.b2 > KY_TAPER_8 ? p.b2 - KY_TAPER_8 : 0;
+    const int b0 = p.b1 > KY_TAPER_16 ? p.b1 - KY_TAPER_16 : 0;
+    p.head = (b0 / KY_CHUNK) * KY_CHUNK;   // what is left of the bulk's last chunk goes to the 16-sample segment
+    p.n_big = p.head / KY_CHUNK;
+    p.n16 = (p.b1 - p.head + 15) / 16;
+    p.n8 = (p.b2 - p.b1 + 7) / 8;
+    p.n4 = (p.b3 - p.b2 + 3) / 4;
+    p.n2 = (p.b4 - p.b3 + 1) / 2;
+    return p;
+}
+__host__ __device__ inline int chunk_count(const ChunkPlan& p) { return p.n_big + p.n16 + p.n8 + p.n4 + p.n2; }
+__host__ __device__ inline void chunk_range(const ChunkPlan& p, int c, int& s_begin, int& s_end) {
+    int size = KY_CHUNK, first = 0, limit = p.head;
+    c -= p.n_big;
+    if (c >= 0) { size = 16; first = p.head; limit = p.b1; c -= p.n16; }
+    if (c >= 0) { size = 8; first = p.b1; limit = p.b2; c -= p.n8; }
+    if (c >= 0) { size = 4; first = p.b2; limit = p.b3; c -= p.n4; }
+    if (c >= 0) { size = 2; first = p.b3; limit = p.b4; c -= p.n2; }
+    // c is now (index inside its segment) - (chunks of that segment): count back from the segment's chunk count
+    const int n_seg = size == KY_CHUNK ? p.n_big : (size == 16 ? p.n16 : (size == 8 ? p.n8 : (size == 4 ? p.n4 : p.n2)));
+    s_begin = first + (c + n_seg) * size;
+    s_end = s_begin + size < limit ? s_begin + size : limit;
+}
+
 struct ShardConst {
     int tile_w, tile_h, tile_first, tile_step;
     int tiles_x, tiles_y, n_tiles;     // tiles of the whole film / tiles owned by this shard
     int blocks_w, blocks_per_tile;     // 8x8 pixel blocks inside a tile
     int n_blocks;                      // n_tiles * blocks_per_tile
-    int n_chunks;                      // n_big + number of small chunks
-    int n_big, head;                   // chunks of KY_CHUNK samples covering [0, head); small chunks cover [head, spp)
+    int n_chunks;                      // chunk_count(chunk_plan(spp))
     unsigned n_items;                  // n_blocks * n_chunks
     int n_pix;                         // n_tiles * tile_w * tile_h
 };
@@ -124,10 +173,10 @@ static bool shard_in_range(const ky_render_params* p) {
     const long long n_tiles = p->tile_first >= total ? 0 : (total - p->tile_first + p->tile_step - 1) / p->tile_step;
     const long long n_pix = n_tiles * p->tile_w * p->tile_h;
     const long long n_blocks = n_tiles * (p->tile_w / 8) * (p->tile_h / 8);
-    const long long spp = p->samples_per_pixel, tail = spp < KY_TAIL ? spp : KY_TAIL;
-    const long long head = ((spp - tail) / KY_CHUNK) * KY_CHUNK;
-    const long long n_chunks = head / KY_CHUNK + (spp - head + KY_CHUNK_SMALL - 1) / KY_CHUNK_SMALL;
-    return n_pix * 3 <= 0x7fffffffLL && n_blocks * n_chunks < 0xffffffffLL && total <= 0x7fffffffLL;
+    const long long n_chunks = chunk_count(chunk_plan(p->samples_per_pixel));
+    // a wavefront's fetches run past the end of the queue by at most one per wave plus the first-item offset (4 x grid): keep
+    // every id such a fetch can produce below 2^32, or it would wrap to a small number and a chunk would be rendered twice
+    return n_pix * 3 <= 0x7fffffffLL && n_blocks * n_chunks < 0xffffffffLL - (1 << 20) && total <= 0x7fffffffLL;
 }
 
 static ShardConst make_shard(const ky_render_params* p) {
@@ -141,11 +190,7 @@ static ShardConst make_shard(const ky_render_params* p) {
     s.blocks_per_tile = s.blocks_w * (p->tile_h / 8);
     s.n_blocks = s.n_tiles * s.blocks_per_tile;
     s.n_pix = s.n_tiles * p->tile_w * p->tile_h;
-    const int spp = p->samples_per_pixel;
-    const int tail = spp < KY_TAIL ? spp : KY_TAIL;
-    s.head = ((spp - tail) / KY_CHUNK) * KY_CHUNK;   // a multiple of KY_CHUNK; the rest goes to the small chunks
-    s.n_big = s.head / KY_CHUNK;
-    s.n_chunks = s.n_big + (spp - s.head + KY_CHUNK_SMALL - 1) / KY_CHUNK_SMALL;
+    s.n_chunks = chunk_count(chunk_plan(p->samples_per_pixel));
     s.n_items = (unsigned)s.n_blocks * (unsigned)s.n_chunks;
     return s;
 }
@@ -175,29 +220,35 @@ struct ItemSlot {  // one fetched work item, decoded once (wave-uniform) and rea
     int x0, y0, pix0, s_begin, s_end;
 };
 
-// STRATEGY >= 0 fixes direct_sample_enum at compile time (prunes the other estimators); -1 reads rc.strategy.
+// STRATEGY >= 0 fixes direct_sample_enum AND the integrator at compile time (prunes the other estimators and integrators); -1 reads both
+// from rc.
 // QUEUE (with STRATEGY = both_mis): the light-sampling halves' shadow rays are deferred to the wave's stack `queue_mem`
 // (ky_device.hpp, "deferred shadow rays") and traced 64 at a time.
 // GENERAL: the scene may hold quads that are not parallelograms, triangles or disks (SceneRef::general); no shipped scene does.
-// FEAT: KY_FEAT_* facts the instantiation assumes about the scene (SceneRef::feat).  One set is instantiated, for the both_mis kernel:
-// one rectangle area light (every Cornell-box configuration of BASELINE.json).
-template <bool DEBUG_SAMPLER, int STRATEGY, bool QUEUE = false, bool GENERAL = false, int FEAT = 0>
+// FEAT: KY_FEAT_* facts the instantiation assumes about the scene (SceneRef::feat): one rectangle area light (every Cornell-box
+// configuration of BASELINE.json), one point / directional light, one environment light (the other Cornell variants of ky's drivers).
+// INTEGRATOR (with STRATEGY >= 0): path_tracing_iteration_t, or direct_lighting_t / one of the three recursive integrators
+// (render_multiple_integrator, ky.cpp:4740-4777, runs all five side by side).
+// The host's table of instantiations is g_variants below; kyhip_render_tiles_device launches the first one whose assumptions hold.
+template <bool DEBUG_SAMPLER, int STRATEGY, bool QUEUE = false, bool GENERAL = false, int FEAT = 0, int INTEGRATOR = KY_INTEGRATOR_PATH_TRACING_ITERATION>
 __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? KY_WAVES_PER_EU_QUEUE : KY_WAVES_PER_EU) : KY_WAVES_PER_EU_GENERIC) void render_kernel(const DScene* __restrict__ S_, RenderConst rc, ShardConst sh,
                                                                      unsigned* __restrict__ counter, unsigned long long* __restrict__ accum,
                                                                      unsigned* __restrict__ flags, float4* __restrict__ queue_mem) {
-    static_assert(!QUEUE || STRATEGY == KY_DIRECT_BOTH_MIS, "the deferred shadow rays are built into the both_mis instantiation");
-    static_assert(FEAT == 0 || (STRATEGY == KY_DIRECT_BOTH_MIS && !QUEUE && !GENERAL && !DEBUG_SAMPLER), "scene facts are instantiated for the both_mis kernel only");
+    static_assert(!QUEUE || (STRATEGY == KY_DIRECT_BOTH_MIS && INTEGRATOR == KY_INTEGRATOR_PATH_TRACING_ITERATION), "the deferred shadow rays are built into the iterative both_mis instantiation");
+    static_assert(FEAT == 0 || (STRATEGY >= 0 && !QUEUE && !GENERAL && !DEBUG_SAMPLER), "scene facts are instantiated for kernels with a fixed strategy only");
+    static_assert(STRATEGY >= 0 || INTEGRATOR == KY_INTEGRATOR_PATH_TRACING_ITERATION, "the run-time-dispatched kernel reads the integrator from rc");
     const SceneRef S{S_, GENERAL, FEAT};
     __shared__ LdsScene Lds;
     __shared__ ItemSlot ring[4][KY_RING];
     // the lane's pixel chunk (touched when a path starts or ends, not while a vertex is shaded) lives in LDS, not in registers
     __shared__ float c_lsum[3][256];
-    __shared__ int c_xy[256], c_pix[256], c_se[256];   // c_se = next sample << 7 | samples left in the chunk
+    __shared__ int c_xy[256], c_pix[256];
+    __shared__ unsigned c_se[256];   // next sample << 7 | samples left in the chunk
     __shared__ uint32_t c_key[256];
     __shared__ unsigned long long c_def[QUEUE ? 3 * 256 : 1];   // QUEUE: fixed-point sums of the lane's resolved shadow rays
     const int tid = threadIdx.x;
     stage_scene(Lds, S);
-    if (STRATEGY >= 0) { rc.strategy = STRATEGY; rc.integrator = KY_INTEGRATOR_PATH_TRACING_ITERATION; }  // the hot instantiation
+    if (STRATEGY >= 0) { rc.strategy = STRATEGY; rc.integrator = INTEGRATOR; }  // compile-time constants from here on
     const int nee_weight = (rc.strategy == KY_DIRECT_IDLE || rc.integrator < KY_INTEGRATOR_DIRECT_LIGHTING ||
                             rc.integrator == KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION) ? 0 : S->n_lights;
 
@@ -265,8 +316,7 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? KY_WAVES_PER_EU_QUEUE
                     it.x0 = tcol * sh.tile_w + bx * 8;
                     it.y0 = trow * sh.tile_h + by * 8;
                     it.pix0 = (k * sh.tile_h + by * 8) * sh.tile_w + bx * 8;
-                    it.s_begin = c < sh.n_big ? c * KY_CHUNK : sh.head + (c - sh.n_big) * KY_CHUNK_SMALL;
-                    it.s_end = c < sh.n_big ? it.s_begin + KY_CHUNK : min(rc.spp, it.s_begin + KY_CHUNK_SMALL);
+                    chunk_range(chunk_plan(rc.spp), c, it.s_begin, it.s_end);
                     my_ring[fetched % KY_RING] = it;
                 }
                 ++fetched;
@@ -283,7 +333,7 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? KY_WAVES_PER_EU_QUEUE
                     c_xy[tid] = x | (y << 16);
                     c_pix[tid] = it.pix0 + py * sh.tile_w + px;
                     c_key[tid] = sampler_pixel_key(rc.seed, (uint32_t)(y * rc.width + x));
-                    c_se[tid] = (it.s_begin << 7) | (it.s_end - it.s_begin);
+                    c_se[tid] = ((unsigned)it.s_begin << 7) | (unsigned)(it.s_end - it.s_begin);
                     open = in_range && it.s_begin < it.s_end;
                     has_item = in_range;
                 } else {
@@ -302,8 +352,9 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? KY_WAVES_PER_EU_QUEUE
         bool have_vertex = false;
         for (int attempt = 0;; ++attempt) {
             if (!alive && !done && open) {  // next camera sample of this lane's pixel, 3712-3715
-                const int xy = c_xy[tid], se = c_se[tid];
-                path_begin<DEBUG_SAMPLER>(ps, S, c_key[tid], xy & 0xffff, xy >> 16, se >> 7);
+                const int xy = c_xy[tid];
+                const unsigned se = c_se[tid];
+                path_begin<DEBUG_SAMPLER>(ps, S, c_key[tid], xy & 0xffff, xy >> 16, (int)(se >> 7));
                 c_se[tid] = se + 127;             // next sample + 1, samples left - 1
                 open = (se & 127) > 1;
                 alive = true;
@@ -916,6 +967,9 @@ static int pack_scene(const ky_scene* in, DScene* out) {
     out->feat = 0;
     if (specialisation_enabled()) {   // the KY_FEAT_* facts of this scene
         if (in->light_count == 1 && in->lights[0].kind == KY_LIGHT_AREA && in->environment_light < 0) out->feat |= KY_FEAT_SINGLE_AREA;
+        if (in->light_count == 1 && (in->lights[0].kind == KY_LIGHT_POINT || in->lights[0].kind == KY_LIGHT_DIRECTION) && in->environment_light < 0)
+            out->feat |= KY_FEAT_SINGLE_DELTA;
+        if (in->light_count == 1 && in->lights[0].kind == KY_LIGHT_ENVIRONMENT && in->environment_light == 0) out->feat |= KY_FEAT_SINGLE_ENV;
         bool rect = true;
         for (int i = 0; i < in->light_count; ++i)
             if (in->lights[i].kind == KY_LIGHT_AREA) rect = rect && in->shapes[in->lights[i].shape].kind == KY_SHAPE_RECTANGLE;
@@ -1020,26 +1074,46 @@ struct DevBuf {
 };
 
 // One context per device, created on first use.  Every entry point holds the context's own mutex while it enqueues, so
-// calls for different devices never wait for each other.  The render state that is shared by the calls on one device
-// (scene copy, work counter, cached workspace, timing events) is handed from stream to stream with `busy`: a call on
-// another stream first waits (on the device) for the previous call's last kernel.
+// calls for different devices never wait for each other.
+//
+// What a launch writes -- work counter, accumulator workspace, timing events, the wavefronts' shadow-ray stacks -- belongs to the
+// STREAM it is enqueued on (StreamState): calls on one stream execute in stream order anyway, and calls on different streams share
+// nothing, so a frame's kernel can start on the compute units the previous frame's kernel is draining from (ky_amd/dist.py alternates
+// two streams: a persistent kernel pays its start-up and its tail once per launch, and only another launch can fill them).
+// What a launch only reads -- the packed scene -- is cached by CONTENT (SceneSlot): a workload that alternates between a few scenes
+// (render_multiple_scene, ky.cpp:4819-4876) uploads each once and never synchronises the device again.
+struct StreamState {
+    bool used = false;
+    hipStream_t stream = nullptr;
+    unsigned* d_counter = nullptr;
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing_valid = false;
+    float4* d_shadow_queue = nullptr;      // QUEUE instantiation, allocated on first use
+    unsigned long long last_use = 0;
+};
+struct SceneSlot {
+    bool valid = false;
+    DScene* d = nullptr;                   // device copy
+    DScene* h = nullptr;                   // pinned staging copy = what `d` holds (the key of the cache)
+    hipEvent_t ready = nullptr;            // the upload; launches on other streams than the uploading one wait for it (device side)
+    hipStream_t upload_stream = nullptr;
+    unsigned long long last_use = 0;
+};
+constexpr int KY_STREAM_STATES = 4, KY_SCENE_SLOTS = 8;
 struct DeviceCtx {
     std::mutex m;
     int device = 0;
     int cus = 0;
-    DScene* d_scene = nullptr;
-    DScene* h_scene = nullptr;   // pinned staging
-    unsigned* d_counter = nullptr;
-    void* ws = nullptr;
-    size_t ws_bytes = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, busy = nullptr;
-    bool busy_valid = false, timing_valid = false;
-    hipStream_t last_stream = nullptr;
+    StreamState ss[KY_STREAM_STATES];
+    SceneSlot scenes[KY_SCENE_SLOTS];
+    unsigned long long clock = 0;
+    StreamState* last_launch = nullptr;    // kyhip_kernel_ms reads its event pair
     hipStream_t stream = nullptr;   // the library's own stream on this device (kyhip_render_multi)
-    int blocks_per_cu[4] = {0, 0, 0, 0};   // render_kernel <false, both_mis>, <false, -1>, <true, -1>, <false, both_mis, QUEUE>
+    int variant_blocks[48] = {};           // resident workgroups per CU of g_variants[i] (0: not asked yet)
+    int last_variant = -1;
     int q_blocks_per_cu[3] = {0, 0, 0};
-    float4* d_shadow_queue = nullptr;       // the wavefronts' shadow-ray stacks (QUEUE instantiation), allocated on first use
-    bool scene_valid = false;
 };
 static std::mutex g_ctx_mutex;                          // guards g_ctx itself (creation), never held while enqueueing
 static std::vector<std::unique_ptr<DeviceCtx>> g_ctx;   // index = HIP device ordinal
@@ -1051,27 +1125,7 @@ static int create_ctx(int device, DeviceCtx& c) {
         return fail(KY_ERR_NO_DEVICE, "device %d is %s; libkyhip is built for gfx950 only", device, prop.gcnArchName);
     c.device = device;
     c.cus = prop.multiProcessorCount;
-    HIP_TRY(hipMalloc(&c.d_scene, sizeof(DScene)));
-    HIP_TRY(hipHostMalloc(&c.h_scene, sizeof(DScene)));
-    HIP_TRY(hipMalloc(&c.d_counter, 256));
-    HIP_TRY(hipEventCreate(&c.ev0));
-    HIP_TRY(hipEventCreate(&c.ev1));
-    HIP_TRY(hipEventCreateWithFlags(&c.busy, hipEventDisableTiming));
     HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[0], render_kernel<false, KY_DIRECT_BOTH_MIS>, 256, 0));
-    {   // the Cornell-lamp instantiation and the other strategies' share slot 0: same launch bounds, and the grid must fit all
-        int sa = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&sa, (render_kernel<false, KY_DIRECT_IDLE>), 256, 0)); c.blocks_per_cu[0] = std::min(c.blocks_per_cu[0], sa);
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&sa, (render_kernel<false, KY_DIRECT_BSDF>), 256, 0)); c.blocks_per_cu[0] = std::min(c.blocks_per_cu[0], sa);
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&sa, (render_kernel<false, KY_DIRECT_LIGHT>), 256, 0)); c.blocks_per_cu[0] = std::min(c.blocks_per_cu[0], sa);
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&sa, (render_kernel<false, KY_DIRECT_BSDF_MIS>), 256, 0)); c.blocks_per_cu[0] = std::min(c.blocks_per_cu[0], sa);
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&sa, (render_kernel<false, KY_DIRECT_LIGHT_MIS>), 256, 0)); c.blocks_per_cu[0] = std::min(c.blocks_per_cu[0], sa);
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&sa, (render_kernel<false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL>), 256, 0));
-        c.blocks_per_cu[0] = std::min(c.blocks_per_cu[0], sa);
-    }
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[1], render_kernel<false, -1>, 256, 0));
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[2], render_kernel<true, -1>, 256, 0));
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.blocks_per_cu[3], (render_kernel<false, KY_DIRECT_BOTH_MIS, true>), 256, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.q_blocks_per_cu[0], render_kernel_q<false, KY_DIRECT_BOTH_MIS>, QE_THREADS, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.q_blocks_per_cu[1], render_kernel_q<false, -1>, QE_THREADS, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.q_blocks_per_cu[2], render_kernel_q<true, -1>, QE_THREADS, 0));
@@ -1100,31 +1154,68 @@ static DeviceCtx* find_ctx(int device) {
     return (device >= 0 && device < (int)g_ctx.size()) ? g_ctx[device].get() : nullptr;
 }
 
-// Hands the per-device render state over to `stream`: device-side wait for the previous call's last kernel.
-static int acquire_state(DeviceCtx* c, hipStream_t stream) {
-    if (c->busy_valid && stream != c->last_stream) HIP_TRY(hipStreamWaitEvent(stream, c->busy, 0));
-    return KY_OK;
-}
-static int release_state(DeviceCtx* c, hipStream_t stream) {
-    HIP_TRY(hipEventRecord(c->busy, stream));
-    c->busy_valid = true;
-    c->last_stream = stream;
+// The launch state of `stream` on this device (created on first use; with more than KY_STREAM_STATES streams in use the least
+// recently used state is handed over, after the device has drained).
+static int get_stream_state(DeviceCtx* c, hipStream_t stream, StreamState** out) {
+    StreamState* pick = nullptr;
+    for (StreamState& st : c->ss)
+        if (st.used && st.stream == stream) pick = &st;
+    if (!pick) {
+        for (StreamState& st : c->ss)
+            if (!st.used && !pick) pick = &st;
+        if (!pick) {
+            pick = &c->ss[0];
+            for (StreamState& st : c->ss)
+                if (st.last_use < pick->last_use) pick = &st;
+            HIP_TRY(hipDeviceSynchronize());   // its buffers may still be in use on the stream that owned them
+            pick->timing_valid = false;
+        }
+        if (!pick->d_counter) {
+            HIP_TRY(hipMalloc(&pick->d_counter, 256));
+            HIP_TRY(hipEventCreate(&pick->ev0));
+            HIP_TRY(hipEventCreate(&pick->ev1));
+        }
+        pick->used = true;
+        pick->stream = stream;
+    }
+    pick->last_use = ++c->clock;
+    *out = pick;
     return KY_OK;
 }
 
-static int upload_scene(DeviceCtx* c, const ky_scene* scene, hipStream_t stream) {
-    // pack into a scratch copy first: an unchanged scene (every frame of a bench or of a tile-sharded render) is not
-    // uploaded again, which also avoids a host-side stream synchronisation per call
+// The device copy of `scene`, from the cache or uploaded on `stream`; launches on `stream` may read it when this returns.
+static int upload_scene(DeviceCtx* c, const ky_scene* scene, hipStream_t stream, SceneSlot** out) {
     static thread_local DScene scratch;
     const int rc = pack_scene(scene, &scratch);
     if (rc != KY_OK) return rc;
-    if (c->scene_valid && std::memcmp(&scratch, c->h_scene, sizeof(DScene)) == 0) return KY_OK;
-    // the pinned staging copy and the device copy must not change under a kernel or copy that is still in flight
-    HIP_TRY(hipDeviceSynchronize());
-    std::memcpy(c->h_scene, &scratch, sizeof(DScene));
-    HIP_TRY(hipMemcpyAsync(c->d_scene, c->h_scene, sizeof(DScene), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipStreamSynchronize(stream));   // later launches may come on other streams
-    c->scene_valid = true;
+    SceneSlot* pick = nullptr;
+    for (SceneSlot& sl : c->scenes)
+        if (sl.valid && std::memcmp(&scratch, sl.h, sizeof(DScene)) == 0) pick = &sl;
+    if (pick) {
+        if (pick->upload_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, pick->ready, 0));
+    } else {
+        for (SceneSlot& sl : c->scenes)
+            if (!sl.valid && !pick) pick = &sl;
+        if (!pick) {   // every slot holds a scene: replace the least recently used one, which launches in flight may still read
+            pick = &c->scenes[0];
+            for (SceneSlot& sl : c->scenes)
+                if (sl.last_use < pick->last_use) pick = &sl;
+            HIP_TRY(hipDeviceSynchronize());
+            pick->valid = false;
+        }
+        if (!pick->d) {
+            HIP_TRY(hipMalloc(&pick->d, sizeof(DScene)));
+            HIP_TRY(hipHostMalloc(&pick->h, sizeof(DScene)));
+            HIP_TRY(hipEventCreateWithFlags(&pick->ready, hipEventDisableTiming));
+        }
+        std::memcpy(pick->h, &scratch, sizeof(DScene));
+        HIP_TRY(hipMemcpyAsync(pick->d, pick->h, sizeof(DScene), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(pick->ready, stream));
+        pick->upload_stream = stream;
+        pick->valid = true;
+    }
+    pick->last_use = ++c->clock;
+    *out = pick;
     return KY_OK;
 }
 
@@ -1220,6 +1311,80 @@ size_t kyhip_workspace_bytes(const ky_render_params* p) {
     return workspace_bytes_for(make_shard(p));
 }
 
+// The render-kernel instantiations of the lane engine, most specific first; a launch takes the first whose assumptions hold.
+//   sampler   debug_sampler_t or random_sampler_t
+//   strategy  -1: direct_sample_enum_t and integrator are read at run time (11 000 instructions, five waves per SIMD); otherwise both are
+//             compile-time constants of the instantiation
+//   queue     deferred shadow rays (scenes with two or more lights)
+//   general   carries the reference's own formulations for quads that are not parallelograms, triangles and disks
+//   feat      the KY_FEAT_* facts of the scene the instantiation assumes
+using RenderFn = void (*)(const DScene*, RenderConst, ShardConst, unsigned*, unsigned long long*, unsigned*, float4*);
+struct Variant {
+    bool dbg;
+    int strategy;
+    bool queue, general;
+    int feat, integrator;
+    RenderFn fn;
+};
+#define KY_VARIANT(D, S, Q, G, F, I) Variant{D, S, Q, G, F, I, render_kernel<D, S, Q, G, F, I>}
+constexpr int IT = KY_INTEGRATOR_PATH_TRACING_ITERATION;
+static const Variant g_variants[] = {
+    // the iterative integrator, both_mis: by scene facts
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL, IT),                  // one rectangle area light: configs[1], [4]
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_DELTA, IT),             // one point / directional light
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_ENV, IT),               // one environment light
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, 0, IT),                                 // several lights: deferred shadow rays (configs[2])
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, 0, IT),
+    // the iterative integrator, the other five strategies (render_direct_sample_enum 4779, render_mis_scene 4878)
+    KY_VARIANT(false, KY_DIRECT_BSDF, false, false, KY_FEAT_CORNELL, IT),
+    KY_VARIANT(false, KY_DIRECT_BSDF_MIS, false, false, KY_FEAT_CORNELL, IT),
+    KY_VARIANT(false, KY_DIRECT_IDLE, false, false, 0, IT),
+    KY_VARIANT(false, KY_DIRECT_BSDF, false, false, 0, IT),
+    KY_VARIANT(false, KY_DIRECT_LIGHT, false, false, 0, IT),
+    KY_VARIANT(false, KY_DIRECT_BSDF_MIS, false, false, 0, IT),
+    KY_VARIANT(false, KY_DIRECT_LIGHT_MIS, false, false, 0, IT),
+    // direct_lighting_t and the three recursive integrators with both_mis (render_multiple_integrator 4740-4777)
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL, KY_INTEGRATOR_PATH_TRACING_RECURSION),
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_ENV, KY_INTEGRATOR_PATH_TRACING_RECURSION),
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL, KY_INTEGRATOR_PATH_TRACING_RECURSION_DEFERED),
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_ENV, KY_INTEGRATOR_PATH_TRACING_RECURSION_DEFERED),
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_DELTA, KY_INTEGRATOR_PATH_TRACING_RECURSION),
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_DELTA, KY_INTEGRATOR_PATH_TRACING_RECURSION_DEFERED),
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL, KY_INTEGRATOR_DIRECT_LIGHTING),
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_DELTA, KY_INTEGRATOR_DIRECT_LIGHTING),
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_ENV, KY_INTEGRATOR_DIRECT_LIGHTING),
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, 0, KY_INTEGRATOR_DIRECT_LIGHTING),
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, 0, KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION),
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, 0, KY_INTEGRATOR_PATH_TRACING_RECURSION),
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, 0, KY_INTEGRATOR_PATH_TRACING_RECURSION_DEFERED),
+    // everything else: strategy and integrator at run time; the debug sampler; scenes with general shapes
+    KY_VARIANT(false, -1, false, false, 0, IT),
+    KY_VARIANT(true, -1, false, false, 0, IT),
+    KY_VARIANT(false, -1, false, true, 0, IT),
+    KY_VARIANT(true, -1, false, true, 0, IT),
+};
+constexpr int KY_N_VARIANTS = (int)(sizeof g_variants / sizeof g_variants[0]);
+static_assert(KY_N_VARIANTS <= 48, "DeviceCtx::variant_blocks");
+
+static const Variant* pick_variant(const ky_render_params* p, const DScene* packed, int light_count, int n_pix) {
+    const bool dbg = p->sampler == KY_SAMPLER_DEBUG;
+    const bool general = packed->general != 0;
+    for (const Variant& v : g_variants) {
+        if (v.dbg != dbg) continue;
+        if (general && !v.general) continue;
+        if (v.strategy >= 0) {
+            if (!specialisation_enabled() && !(v.strategy == KY_DIRECT_BOTH_MIS && v.feat == 0 && v.integrator == IT)) continue;   // KYHIP_SPECIALISE=0 keeps both_mis (and its queue form)
+            if (v.strategy != p->direct_sample || v.integrator != p->integrator) continue;
+        }
+        if ((v.feat & packed->feat) != v.feat) continue;
+        // deferred shadow rays pay when a vertex has several light samples to resolve (ky_device.hpp); KYHIP_SHADOW_QUEUE=0 / 1 forces.
+        // The ray's destination tag holds the pixel in 26 bits.
+        if (v.queue && !(n_pix < (1 << 26) && shadow_queue_wanted(light_count))) continue;
+        return &v;
+    }
+    return nullptr;   // not reached: the last four entries accept everything
+}
+
 int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render_params* p, float* d_tiles, void* d_workspace,
                               size_t workspace_bytes, void* stream_) {
     if (!valid_params(p)) return fail(KY_ERR_INVALID_VALUE, "invalid render params (integrator %d, direct_sample %d)", p ? p->integrator : -1, p ? p->direct_sample : -1);
@@ -1230,105 +1395,103 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
     if (rcode != KY_OK) return rcode;
     std::lock_guard<std::mutex> lock(c->m);
     hipStream_t stream = (hipStream_t)stream_;
-    rcode = upload_scene(c, scene, stream);
+    SceneSlot* sc;
+    rcode = upload_scene(c, scene, stream, &sc);
     if (rcode != KY_OK) return rcode;
 
     const ShardConst sh = make_shard(p);
     if (sh.n_tiles == 0) return KY_OK;
     const RenderConst rc = make_rc(p);
-    const bool dbg = p->sampler == KY_SAMPLER_DEBUG;
+    StreamState* st;
+    rcode = get_stream_state(c, stream, &st);
+    if (rcode != KY_OK) return rcode;
 
     const size_t need = workspace_bytes_for(sh);
     void* ws = d_workspace;
     if (!(d_workspace && workspace_bytes >= need)) {
-        if (c->ws_bytes < need) {
-            if (c->busy_valid) HIP_TRY(hipEventSynchronize(c->busy));   // the previous call's kernels still use the old block
-            if (c->ws) HIP_TRY(hipFree(c->ws));
-            c->ws = nullptr; c->ws_bytes = 0;
-            HIP_TRY(hipMalloc(&c->ws, need));
-            c->ws_bytes = need;
+        if (st->ws_bytes < need) {
+            HIP_TRY(hipStreamSynchronize(stream));   // the previous call's kernels on this stream still use the old block
+            if (st->ws) HIP_TRY(hipFree(st->ws));
+            st->ws = nullptr; st->ws_bytes = 0;
+            HIP_TRY(hipMalloc(&st->ws, need));
+            st->ws_bytes = need;
         }
-        ws = c->ws;
+        ws = st->ws;
     }
-    rcode = acquire_state(c, stream);   // counter, cached workspace and timing events are shared by the calls on this device
-    if (rcode != KY_OK) return rcode;
     unsigned long long* accum = (unsigned long long*)ws;
     unsigned* flags = (unsigned*)(accum + (size_t)sh.n_pix * 3);
     HIP_TRY(hipMemsetAsync(ws, 0, need, stream));
-    HIP_TRY(hipMemsetAsync(c->d_counter, 0, sizeof(unsigned), stream));
+    HIP_TRY(hipMemsetAsync(st->d_counter, 0, sizeof(unsigned), stream));
 
-    // c->h_scene is the packed scene upload_scene has just compared / uploaded.  Scenes of parallelograms and spheres (every scene
-    // ky ships) run on instantiations without the general-shape code; among those each direct-lighting strategy of the iterative
-    // integrator has its own (the run-time-dispatched kernel carries all six and the four other integrators: 11 000 instructions against
-    // 4 000-5 000, and one wave per SIMD fewer).
-    const bool general = c->h_scene->general != 0;
-    // variant: 0 both_mis, 1 run-time dispatch, 2 debug sampler, 3 both_mis with deferred shadow rays, 4 one of the other five strategies (compiled in)
-    const bool iterative = p->integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION && !general && !dbg;
-    int variant = dbg ? 2 : (iterative ? (p->direct_sample == KY_DIRECT_BOTH_MIS ? 0 : (specialisation_enabled() ? 4 : 1)) : 1);
-    // deferred shadow rays pay when a vertex has several light samples to resolve (ky_device.hpp); KYHIP_SHADOW_QUEUE=0 / 1 forces
-    if (variant == 0 && current_engine() == KY_ENGINE_LANE && sh.n_pix < (1 << 26) && shadow_queue_wanted(scene->light_count)) {
-        variant = 3;
-        if (!c->d_shadow_queue) {
-            const int per_cu = c->blocks_per_cu[3] > 0 ? c->blocks_per_cu[3] : 1;
-            HIP_TRY(hipMalloc(&c->d_shadow_queue, (size_t)c->cus * per_cu * 4 * KY_SQ_ENTRY * KY_SQ_CAP * sizeof(float4)));
-        }
-    }
-    HIP_TRY(hipEventRecord(c->ev0, stream));
     // the queue engine implements path_tracing_iteration_t; every other integrator runs on the lane engine
     if (current_engine() == KY_ENGINE_QUEUE && p->integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION) {
-        if (variant == 4) variant = 1;   // the queue engine has its own three instantiations: both_mis, run-time dispatch, debug sampler
+        const int variant = p->sampler == KY_SAMPLER_DEBUG ? 2 : (p->direct_sample == KY_DIRECT_BOTH_MIS ? 0 : 1);
         const int per_cu = c->q_blocks_per_cu[variant] > 0 ? c->q_blocks_per_cu[variant] : 1;
         unsigned grid = (unsigned)(c->cus * per_cu);
         const unsigned need_blocks = (unsigned)(((unsigned long long)sh.n_items * 64u + QE_SLOTS - 1) / QE_SLOTS);
         if (grid > need_blocks) grid = need_blocks;
         if (grid < 1) grid = 1;
-        if (variant == 0) hipLaunchKernelGGL((render_kernel_q<false, KY_DIRECT_BOTH_MIS>), dim3(grid), dim3(QE_THREADS), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags);
-        else if (variant == 1) hipLaunchKernelGGL((render_kernel_q<false, -1>), dim3(grid), dim3(QE_THREADS), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags);
-        else hipLaunchKernelGGL((render_kernel_q<true, -1>), dim3(grid), dim3(QE_THREADS), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags);
+        HIP_TRY(hipEventRecord(st->ev0, stream));
+        if (variant == 0) hipLaunchKernelGGL((render_kernel_q<false, KY_DIRECT_BOTH_MIS>), dim3(grid), dim3(QE_THREADS), 0, stream, sc->d, rc, sh, st->d_counter, accum, flags);
+        else if (variant == 1) hipLaunchKernelGGL((render_kernel_q<false, -1>), dim3(grid), dim3(QE_THREADS), 0, stream, sc->d, rc, sh, st->d_counter, accum, flags);
+        else hipLaunchKernelGGL((render_kernel_q<true, -1>), dim3(grid), dim3(QE_THREADS), 0, stream, sc->d, rc, sh, st->d_counter, accum, flags);
+        c->last_variant = -2;
     } else {
-        const int slot = variant == 4 ? 0 : variant;   // the strategy instantiations share the both_mis kernel's launch bounds (and its slot)
-        const int per_cu = c->blocks_per_cu[slot] > 0 ? c->blocks_per_cu[slot] : 1;
+        const Variant* v = pick_variant(p, sc->h, scene->light_count, sh.n_pix);
+        if (!v) return fail(KY_ERR_DEVICE, "internal: no render kernel for these parameters");
+        const int vi = (int)(v - g_variants);
+        if (c->variant_blocks[vi] == 0) {
+            int per_cu = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v->fn, 256, 0));
+            c->variant_blocks[vi] = per_cu > 0 ? per_cu : 1;
+        }
+        const int per_cu = c->variant_blocks[vi];
+        if (v->queue && !st->d_shadow_queue)   // the wavefronts' shadow-ray stacks of this stream's launches
+            HIP_TRY(hipMalloc(&st->d_shadow_queue, (size_t)c->cus * per_cu * 4 * KY_SQ_ENTRY * KY_SQ_CAP * sizeof(float4)));
         unsigned grid = (unsigned)(c->cus * per_cu);
         const unsigned need_blocks = sh.n_items / 4 + 1;
         if (grid > need_blocks) grid = need_blocks;
         if (grid < 1) grid = 1;
-        float4* const no_queue = nullptr;
-        const int feat = c->h_scene->feat;   // an instantiation may run when the scene has every fact it assumes
-        if (variant == 0 && (feat & KY_FEAT_CORNELL) == KY_FEAT_CORNELL) hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);
-        else if (variant == 0) hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_BOTH_MIS>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);
-        else if (variant == 4) {
-            switch (p->direct_sample) {   // valid_params has checked the value
-            case KY_DIRECT_IDLE: hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_IDLE>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue); break;
-            case KY_DIRECT_BSDF: hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_BSDF>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue); break;
-            case KY_DIRECT_LIGHT: hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_LIGHT>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue); break;
-            case KY_DIRECT_BSDF_MIS: hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_BSDF_MIS>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue); break;
-            default: hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_LIGHT_MIS>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue); break;
-            }
-        }
-        else if (variant == 1 && !general) hipLaunchKernelGGL((render_kernel<false, -1>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);
-        else if (variant == 1) hipLaunchKernelGGL((render_kernel<false, -1, false, true>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);
-        else if (variant == 2 && !general) hipLaunchKernelGGL((render_kernel<true, -1>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);
-        else if (variant == 2) hipLaunchKernelGGL((render_kernel<true, -1, false, true>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, no_queue);
-        else hipLaunchKernelGGL((render_kernel<false, KY_DIRECT_BOTH_MIS, true>), dim3(grid), dim3(256), 0, stream, c->d_scene, rc, sh, c->d_counter, accum, flags, c->d_shadow_queue);
+        HIP_TRY(hipEventRecord(st->ev0, stream));
+        hipLaunchKernelGGL(v->fn, dim3(grid), dim3(256), 0, stream, (const DScene*)sc->d, rc, sh, st->d_counter, accum, flags, v->queue ? st->d_shadow_queue : (float4*)nullptr);
+        c->last_variant = vi;
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev1, stream));
-    c->timing_valid = true;
+    HIP_TRY(hipEventRecord(st->ev1, stream));
+    st->timing_valid = true;
+    c->last_launch = st;
     const int nf = sh.n_pix * 3;
     hipLaunchKernelGGL(resolve_kernel, dim3((nf + 255) / 256), dim3(256), 0, stream, accum, flags, d_tiles, nf);
     HIP_TRY(hipGetLastError());
-    return release_state(c, stream);
+    return KY_OK;
 }
 
-// resolves the event pair of the last launch on `device`; the stream must have been synchronised
+// resolves the event pair of the last launch on `device`; its stream must have been synchronised
 float kyhip_kernel_ms(int device) {
     DeviceCtx* c = find_ctx(device);
     if (!c) return -1.f;
     std::lock_guard<std::mutex> lock(c->m);
-    if (!c->timing_valid) return -1.f;
+    if (!c->last_launch || !c->last_launch->timing_valid) return -1.f;
     float ms = -1.f;
-    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&ms, c->last_launch->ev0, c->last_launch->ev1) != hipSuccess) return -1.f;
     return ms;
+}
+
+const char* kyhip_last_kernel(int device) {
+    static thread_local std::string name;
+    name.clear();
+    DeviceCtx* c = find_ctx(device);
+    if (!c) return name.c_str();
+    std::lock_guard<std::mutex> lock(c->m);
+    if (c->last_variant == -2) name = "render_kernel_q (queue engine)";
+    else if (c->last_variant >= 0) {
+        const Variant& v = g_variants[c->last_variant];
+        char buf[160];
+        snprintf(buf, sizeof buf, "render_kernel<%sstrategy %d%s%s, feat %d, integrator %d>", v.dbg ? "debug sampler, " : "", v.strategy, v.queue ? ", deferred shadow rays" : "",
+                 v.general ? ", general shapes" : "", v.feat, v.integrator);
+        name = buf;
+    }
+    return name.c_str();
 }
 
 int kyhip_film_add_tiles_device(int device, const ky_render_params* p, const float* d_tiles, float* d_film, size_t stride_px, void* stream_) {
@@ -1399,17 +1562,23 @@ int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene,
         ~EventGuard() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); }
     } event_guard{done};
 
-    // 1. every shard is enqueued before anything is waited for: the devices render concurrently
+    // 1. every shard is enqueued before anything is waited for: the devices render concurrently.  From here on a failure must not
+    // return before the streams are drained (step 3): shards already launched write into buffers this function owns.
+#define HIP_CHECK_BREAK(expr)                                                                                         \
+    {                                                                                                               \
+        const hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) { rcode = fail(KY_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); break; } \
+    }
     int rcode = KY_OK;
     for (int i = 0; i < n_devices && rcode == KY_OK; ++i) {
         float* dst = d_gather.as<float>() + rank_stride * i;
         if (devices[i] != root) {
-            HIP_TRY(hipSetDevice(devices[i]));
-            HIP_TRY(remote[i].alloc(rank_stride * sizeof(float)));
+            HIP_CHECK_BREAK(hipSetDevice(devices[i]));
+            HIP_CHECK_BREAK(remote[i].alloc(rank_stride * sizeof(float)));
             dst = remote[i].as<float>();
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, root, devices[i]) == hipSuccess && can) {   // direct xGMI copies; staged otherwise
-                HIP_TRY(hipSetDevice(root));
+                HIP_CHECK_BREAK(hipSetDevice(root));
                 (void)hipDeviceEnablePeerAccess(devices[i], 0);
                 (void)hipGetLastError();   // "already enabled" is not an error here
             }
@@ -1417,28 +1586,32 @@ int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene,
         rcode = kyhip_render_tiles_device(devices[i], scene, &shard[i], dst, nullptr, 0, ctx[i]->stream);
         if (rcode != KY_OK) break;
         if (devices[i] != root) {
-            HIP_TRY(hipSetDevice(devices[i]));
-            HIP_TRY(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
-            HIP_TRY(hipEventRecord(done[i], ctx[i]->stream));
+            HIP_CHECK_BREAK(hipSetDevice(devices[i]));
+            HIP_CHECK_BREAK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+            HIP_CHECK_BREAK(hipEventRecord(done[i], ctx[i]->stream));
         }
     }
     // 2. the gather: one peer copy per remote shard, ordered behind that shard's kernels; then one add into the film
-    if (rcode == KY_OK) {
-        HIP_TRY(hipSetDevice(root));
-        for (int i = 0; i < n_devices; ++i) {
+    for (int once = 0; once < 1 && rcode == KY_OK; ++once) {
+        HIP_CHECK_BREAK(hipSetDevice(root));
+        bool failed = false;
+        for (int i = 0; i < n_devices && !failed; ++i) {
             if (devices[i] == root) continue;
-            HIP_TRY(hipStreamWaitEvent(root_stream, done[i], 0));
+            hipError_t e = hipStreamWaitEvent(root_stream, done[i], 0);
             const size_t bytes = (size_t)make_shard(&shard[i]).n_pix * 3 * sizeof(float);
-            if (bytes) HIP_TRY(hipMemcpyPeerAsync(d_gather.as<float>() + rank_stride * i, root, remote[i].p, devices[i], bytes, root_stream));
+            if (e == hipSuccess && bytes) e = hipMemcpyPeerAsync(d_gather.as<float>() + rank_stride * i, root, remote[i].p, devices[i], bytes, root_stream);
+            if (e != hipSuccess) { rcode = fail(KY_ERR_DEVICE, "gathering shard %d failed: %s", i, hipGetErrorString(e)); failed = true; }
         }
+        if (failed) break;
         rcode = kyhip_film_add_gathered_device(root, p, n_devices, d_gather.as<float>(), rank_stride, d_film.as<float>(), (size_t)p->width, root_stream);
     }
     std::vector<float> host;
-    if (rcode == KY_OK) {
+    for (int once = 0; once < 1 && rcode == KY_OK; ++once) {
         host.resize(film_floats);
-        HIP_TRY(hipMemcpyAsync(host.data(), d_film.p, film_floats * sizeof(float), hipMemcpyDeviceToHost, root_stream));
+        HIP_CHECK_BREAK(hipMemcpyAsync(host.data(), d_film.p, film_floats * sizeof(float), hipMemcpyDeviceToHost, root_stream));
     }
-    // every stream that may still use a buffer of this call is drained before the buffers go away (also on errors)
+#undef HIP_CHECK_BREAK
+    // 3. every stream that may still use a buffer of this call is drained before the buffers go away (also on errors)
     hipError_t sync_err = hipSuccess;
     for (int i = 0; i < n_devices; ++i) {
         if (hipSetDevice(devices[i]) != hipSuccess) continue;
@@ -1482,9 +1655,9 @@ int kyhip_kat_camera(int device, const ky_camera* camera, const float* p_film2, 
     sc.camera = *camera;
     if (!(camera->resolution[0] > 0) || !(camera->resolution[1] > 0)) return fail(KY_ERR_INVALID_VALUE, "bad camera resolution");
     return kat_run(device, p_film2, (size_t)n * 2 * 4, out6, (size_t)n * 6 * 4, [&](DeviceCtx* c, const float* d_in, float* d_out) {
-        int r = upload_scene(c, &sc, 0);
+        SceneSlot* slot; int r = upload_scene(c, &sc, 0, &slot);
         if (r != KY_OK) return r;
-        hipLaunchKernelGGL(kat_camera_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, c->d_scene, d_in, n, d_out);
+        hipLaunchKernelGGL(kat_camera_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, (const DScene*)slot->d, d_in, n, d_out);
         return (int)KY_OK;
     });
 }
@@ -1503,9 +1676,9 @@ int kyhip_kat_bsdf(int device, const ky_material* m, const float* in12, int n, f
 int kyhip_kat_light(int device, const ky_scene* scene, int light, const float* in11, int n, float* out11) {
     if (!scene || !in11 || !out11 || n <= 0 || light < 0 || light >= scene->light_count) return fail(KY_ERR_INVALID_VALUE, "bad KAT arguments");
     return kat_run(device, in11, (size_t)n * 11 * 4, out11, (size_t)n * 11 * 4, [&](DeviceCtx* c, const float* d_in, float* d_out) {
-        int r = upload_scene(c, scene, 0);
+        SceneSlot* sc; int r = upload_scene(c, scene, 0, &sc);
         if (r != KY_OK) return r;
-        hipLaunchKernelGGL(kat_light_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, c->d_scene, light, d_in, n, d_out);
+        hipLaunchKernelGGL(kat_light_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, (const DScene*)sc->d, light, d_in, n, d_out);
         return (int)KY_OK;
     });
 }
@@ -1513,9 +1686,9 @@ int kyhip_kat_light(int device, const ky_scene* scene, int light, const float* i
 int kyhip_kat_scene_intersect(int device, const ky_scene* scene, const float* rays7, int n, float* out9) {
     if (!scene || !rays7 || !out9 || n <= 0) return fail(KY_ERR_INVALID_VALUE, "bad KAT arguments");
     return kat_run(device, rays7, (size_t)n * 7 * 4, out9, (size_t)n * 9 * 4, [&](DeviceCtx* c, const float* d_in, float* d_out) {
-        int r = upload_scene(c, scene, 0);
+        SceneSlot* sc; int r = upload_scene(c, scene, 0, &sc);
         if (r != KY_OK) return r;
-        hipLaunchKernelGGL(kat_scene_intersect_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, c->d_scene, d_in, n, d_out);
+        hipLaunchKernelGGL(kat_scene_intersect_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, (const DScene*)sc->d, d_in, n, d_out);
         return (int)KY_OK;
     });
 }
@@ -1524,9 +1697,9 @@ static int kat_occluded_impl(int device, const ky_scene* scene, const float* in9
     if (!scene || !in9 || !out1 || n <= 0) return fail(KY_ERR_INVALID_VALUE, "bad KAT arguments");
     if (table >= scene->light_count) return fail(KY_ERR_INVALID_VALUE, "light %d out of range", table);
     return kat_run(device, in9, (size_t)n * 9 * 4, out1, (size_t)n * 4, [&](DeviceCtx* c, const float* d_in, float* d_out) {
-        int r = upload_scene(c, scene, 0);
+        SceneSlot* sc; int r = upload_scene(c, scene, 0, &sc);
         if (r != KY_OK) return r;
-        hipLaunchKernelGGL(kat_occluded_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, c->d_scene, d_in, n, d_out, table);
+        hipLaunchKernelGGL(kat_occluded_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, (const DScene*)sc->d, d_in, n, d_out, table);
         return (int)KY_OK;
     });
 }
@@ -1567,10 +1740,10 @@ int kyhip_kat_li(int device, const ky_scene* scene, const ky_render_params* p, i
     const bool dbg = p->sampler == KY_SAMPLER_DEBUG;
     float dummy = 0.f;
     return kat_run(device, &dummy, 4, out3, (size_t)n * 3 * 4, [&](DeviceCtx* c, const float*, float* d_out) {
-        int r = upload_scene(c, scene, 0);
+        SceneSlot* sc; int r = upload_scene(c, scene, 0, &sc);
         if (r != KY_OK) return r;
-        if (dbg) hipLaunchKernelGGL(kat_li_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, 0, c->d_scene, rc, x, y, s0, n, d_out);
-        else hipLaunchKernelGGL(kat_li_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, 0, c->d_scene, rc, x, y, s0, n, d_out);
+        if (dbg) hipLaunchKernelGGL(kat_li_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, 0, (const DScene*)sc->d, rc, x, y, s0, n, d_out);
+        else hipLaunchKernelGGL(kat_li_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, 0, (const DScene*)sc->d, rc, x, y, s0, n, d_out);
         return (int)KY_OK;
     });
 }
@@ -1585,9 +1758,9 @@ int kyhip_kat_nee(int device, const ky_scene* scene, int direct_sample, int ligh
         if (!(sf >= 0 && sf < scene->surface_count)) return fail(KY_ERR_INVALID_VALUE, "row %d: surface out of range", i);
     }
     return kat_run(device, in15, (size_t)n * 15 * 4, out6, (size_t)n * 6 * 4, [&](DeviceCtx* c, const float* d_in, float* d_out) {
-        int r = upload_scene(c, scene, 0);
+        SceneSlot* sc; int r = upload_scene(c, scene, 0, &sc);
         if (r != KY_OK) return r;
-        hipLaunchKernelGGL(kat_nee_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, c->d_scene, direct_sample, light, d_in, n, d_out);
+        hipLaunchKernelGGL(kat_nee_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, (const DScene*)sc->d, direct_sample, light, d_in, n, d_out);
         return (int)KY_OK;
     });
 }
@@ -1601,10 +1774,10 @@ int kyhip_kat_li_trace(int device, const ky_scene* scene, const ky_render_params
     std::vector<float> host((size_t)4 + (size_t)max_rows * 26, 0.f);
     float dummy = 0.f;
     const int rcode = kat_run(device, &dummy, 4, host.data(), host.size() * 4, [&](DeviceCtx* c, const float*, float* d_out) {
-        int r = upload_scene(c, scene, 0);
+        SceneSlot* sc; int r = upload_scene(c, scene, 0, &sc);
         if (r != KY_OK) return r;
-        if (dbg) hipLaunchKernelGGL(kat_li_trace_kernel<true>, dim3(1), dim3(64), 0, 0, c->d_scene, rc, x, y, s, max_rows, d_out);
-        else hipLaunchKernelGGL(kat_li_trace_kernel<false>, dim3(1), dim3(64), 0, 0, c->d_scene, rc, x, y, s, max_rows, d_out);
+        if (dbg) hipLaunchKernelGGL(kat_li_trace_kernel<true>, dim3(1), dim3(64), 0, 0, (const DScene*)sc->d, rc, x, y, s, max_rows, d_out);
+        else hipLaunchKernelGGL(kat_li_trace_kernel<false>, dim3(1), dim3(64), 0, 0, (const DScene*)sc->d, rc, x, y, s, max_rows, d_out);
         return (int)KY_OK;
     });
     if (rcode != KY_OK) return rcode;
@@ -1675,11 +1848,15 @@ int kyhip_smallpt_render(int device, const ky_smallpt_sphere* spheres, int n, co
     HIP_TRY(d_img.alloc(n_px * 3 * sizeof(double)));
     HIP_TRY(hipMemcpy(d_sph.p, packed, sizeof(packed), hipMemcpyHostToDevice));
     const int blocks = ((p->width + 7) / 8) * ((p->height + 7) / 8);
-    HIP_TRY(hipEventRecord(c->ev0, 0));
+    StreamState* st;
+    rcode = get_stream_state(c, 0, &st);
+    if (rcode != KY_OK) return rcode;
+    HIP_TRY(hipEventRecord(st->ev0, 0));
     hipLaunchKernelGGL(kysp::smallpt_kernel, dim3(blocks), dim3(256), 0, 0, d_sph.as<kysp::SpSphere>(), k, d_sub.as<double>());
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev1, 0));
-    c->timing_valid = true;
+    HIP_TRY(hipEventRecord(st->ev1, 0));
+    st->timing_valid = true;
+    c->last_launch = st;
     hipLaunchKernelGGL(kysp::smallpt_resolve_kernel, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, 0, d_sub.as<double>(), d_img.as<double>(), p->width, p->height, p->variant);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(image_rgb, d_img.p, n_px * 3 * sizeof(double), hipMemcpyDeviceToHost));

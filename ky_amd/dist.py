@@ -18,10 +18,12 @@ from . import api
 
 
 def shard_params(params, rank, world):
-    """This rank's shard of `params`: tiles rank, rank+world, ... (a copy; the input is not modified)."""
+    """This rank's shard of the frame `params` describes (a copy; the input is not modified).  `params` may itself be a shard
+    (tile_first, tile_step) of a larger job: rank r takes every world-th of ITS tiles, exactly the split
+    kyhip_film_add_gathered_device undoes."""
     p = A.RenderParams.from_buffer_copy(params)
-    p.tile_first = rank
-    p.tile_step = world
+    p.tile_first = params.tile_first + rank * params.tile_step
+    p.tile_step = params.tile_step * world
     return p
 
 
@@ -40,8 +42,10 @@ def tile_origin(params, t):
 
 
 def shard_tile_count(params, rank, world):
+    """Tiles of shard `rank` of `world` of the frame `params` describes (tile_first / tile_step of `params` honoured)."""
     total = tiles_total(params)
-    return 0 if rank >= total else (total - rank + world - 1) // world
+    first, step = params.tile_first + rank * params.tile_step, params.tile_step * world
+    return 0 if first >= total else (total - first + step - 1) // step
 
 
 class FrameBuffers:
@@ -51,8 +55,8 @@ class FrameBuffers:
     directly.  Nothing is allocated, stacked or copied per frame."""
 
     def __init__(self, params, rank, world, device):
-        self.key = (params.width, params.height, params.tile_w, params.tile_h, rank, world, str(device))
         self.max_tiles = shard_tile_count(params, 0, world)
+        self.free = None   # pipelined frames: the event after which the main stream no longer reads these buffers
         shape = (self.max_tiles, params.tile_h, params.tile_w, 3)
         self.tiles = torch.zeros(shape, dtype=torch.float32, device=device)
         self.gathered = None
@@ -64,8 +68,8 @@ class FrameBuffers:
 _buffers = {}
 
 
-def frame_buffers(params, rank, world, device):
-    key = (params.width, params.height, params.tile_w, params.tile_h, rank, world, str(device))
+def frame_buffers(params, rank, world, device, slot=0):
+    key = (params.width, params.height, params.tile_w, params.tile_h, params.tile_first, params.tile_step, rank, world, str(device), slot)
     fb = _buffers.get(key)
     if fb is None:
         fb = _buffers[key] = FrameBuffers(params, rank, world, device)
@@ -107,7 +111,7 @@ def gather_tiles(tiles, rank, world, group=None, out=None, out_list=None):
 
 
 def add_tiles_to_film(film, gathered, params, world, device_index=0):
-    """De-interleave gathered[r, k] (tile r + k*world) and ADD into film [H, W, 3] (rank 0 only).
+    """De-interleave gathered[r, k] (tile k of shard r: shard_params) and ADD into film [H, W, 3] (rank 0 only).
 
     CUDA tensors go through kyhip_film_add_gathered_device (one kernel for all shards); CPU tensors (the gloo tests) use
     index arithmetic.
@@ -127,7 +131,7 @@ def add_tiles_to_film(film, gathered, params, world, device_index=0):
         return film
     for r in range(world):
         for k in range(shard_tile_count(params, r, world)):
-            t = r + k * world
+            t = params.tile_first + (r + k * world) * params.tile_step   # tile k of shard r of the frame `params` describes
             assert t < total
             x0, y0 = tile_origin(params, t)
             w, h = min(tw, W - x0), min(th, H - y0)
@@ -135,14 +139,51 @@ def add_tiles_to_film(film, gathered, params, world, device_index=0):
     return film
 
 
-def render_distributed(scene, params, rank, world, device_index=0, film=None, group=None):
+class _Pipeline:
+    """Two side streams per device, used alternately by consecutive frames (render_distributed(pipeline=True))."""
+
+    def __init__(self, device):
+        self.streams = [torch.cuda.Stream(device), torch.cuda.Stream(device)]
+        self.turn = 0
+
+
+_pipelines = {}
+
+
+def render_distributed(scene, params, rank, world, device_index=0, film=None, group=None, pipeline=False):
     """integrator_t::render over `world` GPUs.  Returns the film (a CUDA tensor) on rank 0, None elsewhere.
-    Per frame: one render launch per rank, ONE gather, one add kernel on rank 0; the buffers are cached (FrameBuffers)."""
-    fb = frame_buffers(params, rank, world, torch.device("cuda", device_index))
-    render_shard(scene, params, rank, world, device_index, out=fb.tiles)
+    Per frame: one render launch per rank, ONE gather, one add kernel on rank 0; the buffers are cached (FrameBuffers).
+
+    pipeline=True: consecutive frames render on two alternating side streams (libkyhip keeps its launch state per stream), so the
+    next frame's kernel starts on the compute units the current frame's persistent kernel drains from; gather and add stay on the
+    caller's stream, ordered behind the frame's render by an event.  Images are the same; only the overlap differs."""
+    dev = torch.device("cuda", device_index)
+    if not pipeline:
+        fb = frame_buffers(params, rank, world, dev)
+        render_shard(scene, params, rank, world, device_index, out=fb.tiles)
+    else:
+        pl = _pipelines.get(device_index)
+        if pl is None:
+            pl = _pipelines[device_index] = _Pipeline(dev)
+        slot = pl.turn
+        pl.turn ^= 1
+        fb = frame_buffers(params, rank, world, dev, slot=1 + slot)
+        main, side = torch.cuda.current_stream(dev), pl.streams[slot]
+        if fb.free is not None:
+            side.wait_event(fb.free)          # the frame before last (same buffers) has been gathered and added
+        with torch.cuda.stream(side):
+            render_shard(scene, params, rank, world, device_index, out=fb.tiles)
+            done = side.record_event()
+        main.wait_event(done)
     gathered = gather_tiles(fb.tiles, rank, world, group, out=fb.gathered, out_list=getattr(fb, "gather_list", None))
+    if pipeline:
+        if rank != 0:
+            fb.free = torch.cuda.current_stream(dev).record_event()
     if rank != 0:
         return None
     if film is None:
         film = torch.zeros((params.height, params.width, 3), dtype=torch.float32, device=fb.tiles.device)
-    return add_tiles_to_film(film, gathered, params, world, device_index)
+    add_tiles_to_film(film, gathered, params, world, device_index)
+    if pipeline:
+        fb.free = torch.cuda.current_stream(dev).record_event()
+    return film

@@ -20,14 +20,14 @@ def _tiles_from_film(film, params, rank, world, dist):
     tw, th = params.tile_w, params.tile_h
     out = torch.zeros((dist.shard_tile_count(params, 0, world), th, tw, 3), dtype=torch.float32)
     for k in range(dist.shard_tile_count(params, rank, world)):
-        t = rank + k * world
+        t = params.tile_first + (rank + k * world) * params.tile_step
         x0, y0 = dist.tile_origin(params, t)
         w, h = min(tw, params.width - x0), min(th, params.height - y0)
         out[k, :h, :w] = torch.from_numpy(film[y0:y0 + h, x0:x0 + w].copy())
     return out
 
 
-def _worker(rank, world, port, W, H, spp, tile, q):
+def _worker(rank, world, port, W, H, spp, tile, q, tile_first=0, tile_step=1):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -35,7 +35,7 @@ def _worker(rank, world, port, W, H, spp, tile, q):
     from ky_amd import _abi as A, api, dist
     from oracle import kyoracle as O
     scene = api.cornell_box_scene(A.CB_DEFAULT_SCENE, W, H)
-    params = api.make_params(W, H, spp, tile_w=tile[0], tile_h=tile[1])
+    params = api.make_params(W, H, spp, tile_w=tile[0], tile_h=tile[1], tile_first=tile_first, tile_step=tile_step)
     mine = O.render(scene, dist.shard_params(params, rank, world), threads=2)
     tiles = _tiles_from_film(mine, params, rank, world, dist)
     gathered = dist.gather_tiles(tiles, rank, world)
@@ -48,12 +48,13 @@ def _worker(rank, world, port, W, H, spp, tile, q):
     tdist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,size,tile", [(2, (40, 24), (16, 8)), (2, (33, 17), (8, 8)), (3, (40, 24), (16, 16))])
-def test_sharded_render_gather_deinterleave(world, size, tile):
+@pytest.mark.parametrize("world,size,tile,first,step", [(2, (40, 24), (16, 8), 0, 1), (2, (33, 17), (8, 8), 0, 1), (3, (40, 24), (16, 16), 0, 1),
+                                                        (2, (40, 24), (8, 8), 1, 3)])   # the last: the frame is itself a shard (every third tile from 1)
+def test_sharded_render_gather_deinterleave(world, size, tile, first, step):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, size[0], size[1], 2, tile, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, size[0], size[1], 2, tile, q, first, step)) for r in range(world)]
     for p in procs:
         p.start()
     same, maxdiff = q.get(timeout=180)
@@ -73,3 +74,10 @@ def test_shard_ownership_is_a_partition():
         assert max(counts) == counts[0] and max(counts) - min(counts) <= 1
         sp = dist.shard_params(p, world - 1, world)
         assert (sp.tile_first, sp.tile_step) == (world - 1, world) and (p.tile_first, p.tile_step) == (0, 1)
+    # a frame that is itself a shard: the ranks split ITS tiles (tile_first + r * tile_step, tile_step * world)
+    q = api.make_params(100, 70, 4, tile_w=16, tile_h=16, tile_first=2, tile_step=3)   # 7 x 5 = 35 tiles, 11 of them in the frame
+    for world in (1, 2, 4):
+        counts = [dist.shard_tile_count(q, r, world) for r in range(world)]
+        assert sum(counts) == 11 and max(counts) == counts[0]
+        sp = dist.shard_params(q, world - 1, world)
+        assert (sp.tile_first, sp.tile_step) == (2 + (world - 1) * 3, 3 * world)

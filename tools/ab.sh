@@ -3,7 +3,7 @@
 ARGS="$1"; shift
 for v in "$@"; do
   echo "== $v"
-  KYHIP_LIB=$PWD/build_variants/$v.so python bench.py $ARGS --no-cpu-baseline 2>/dev/null | python -c "
+  KYHIP_LIB=$PWD/build_variants/$v.so python bench.py $ARGS --no-cpu-baseline --no-extra 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

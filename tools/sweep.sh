@@ -2,7 +2,7 @@
 # tools/sweep.sh name1 name2 ...  : Cornell (C2) + Veach (C3, 512 spp) bench of each build_variants/<name>.so
 for v in "$@"; do
   for wl in "cornell" "veach --spp 512"; do
-    KYHIP_LIB=$PWD/build_variants/$v.so python3 bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python3 -c "
+    KYHIP_LIB=$PWD/build_variants/$v.so python3 bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-extra 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

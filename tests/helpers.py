@@ -80,3 +80,58 @@ def make_light(A, kind, color, shape=-1, position=(0, 0, 0), direction=(0, 0, -1
         l.color[j], l.position[j], l.direction[j] = color[j], position[j], direction[j]
     l.world_radius = world_radius
     return l
+
+
+# ---- vertex traces (kyhip_kat_li_trace / kyo_trace_li rows of 26 floats): what makes two traces of one camera sample differ ----
+T_GEOM = slice(3, 12)      # position, normal, wo
+T_BETA = slice(12, 15)
+T_LO = slice(15, 18)
+T_DECISIONS = (1, 2, 23, 24, 25)   # surface, lobe, sampled lobe flags, which BSDF-sampling / light-sampling estimates were non-black
+
+
+def trace_close(a, b, tol):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return bool(np.all(np.abs(a - b) <= tol * np.maximum(1.0, np.maximum(np.abs(a), np.abs(b)))))
+
+
+def explain_sample(g_rows, c_rows):
+    """Why do the two traces of one camera sample differ?  -> "decision" (a recorded discrete decision differs first: nearest hit, lobe,
+    glass branch, an estimate's zero / non-zero outcome, termination), "specular" (the first continuous difference lies at or after a
+    vertex on a mirror / glass surface: a curved specular surface amplifies the rounding of a grazing hit 10-50x), "phong" (at or
+    after a vertex whose lobe is the Phong lobe: pow amplifies the rounding of its base by the exponent), or None: a continuous
+    difference with nothing to amplify it -- which no test accepts."""
+    specular = phong = False
+    for k in range(min(len(g_rows), len(c_rows))):
+        g, c = g_rows[k], c_rows[k]
+        if any(g[j] != c[j] for j in T_DECISIONS):
+            return "decision"
+        same = trace_close(g[T_GEOM], c[T_GEOM], 1e-4) and trace_close(g[T_BETA], c[T_BETA], 2e-4)
+        lobe = int(c[2])
+        if same:   # this vertex's own radiance so far: continuous in equal inputs, but a Phong value here is already amplified
+            same = trace_close(g[T_LO], c[T_LO], 2e-4)
+            if not same and lobe == 3:
+                phong = True
+        if not same:
+            return "specular" if specular else ("phong" if phong else None)
+        specular = specular or lobe in (1, 2)
+        phong = phong or lobe == 3
+    if len(g_rows) != len(c_rows):
+        return "decision"   # one path went on: roulette, the depth cap or the last traversal decided differently
+    return "specular" if specular else ("phong" if phong else "decision")   # equal vertices: the final traversal (hit / miss, emission side) differs
+
+
+def explain_pixel(api, O, scene, params, x, y):
+    """All differing samples of one pixel, classified (explain_sample); asserts that none is unexplained.  -> {kind: count}"""
+    n = params.samples_per_pixel
+    g, c = api.kat_li(scene, params, x, y, 0, n), O.li(scene, params, x, y, 0, n)
+    fin = np.isfinite(c).all(1)
+    d = np.abs(g - c).max(axis=1)
+    sc = np.maximum(1e-3, np.abs(c).max(axis=1))
+    kinds = {}
+    for s in np.flatnonzero(fin & (d / sc > 1e-3)):
+        g_rows, _ = api.kat_li_trace(scene, params, x, y, int(s))
+        c_rows = O.trace_li(scene, params, x, y, int(s))
+        kind = explain_sample(g_rows, c_rows)
+        assert kind is not None, ("sample differs continuously with nothing that amplifies rounding", x, y, int(s), g[s], c[s])
+        kinds[kind] = kinds.get(kind, 0) + 1
+    return kinds

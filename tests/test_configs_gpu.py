@@ -13,6 +13,7 @@ import subprocess
 import numpy as np
 import pytest
 
+from helpers import explain_pixel
 from oracle import film_writers as FW
 
 pytestmark = pytest.mark.gpu
@@ -50,13 +51,19 @@ def _tile_parity(A, api, O, scene, params, tiles, tol=1e-3):
         rmse = float(np.sqrt(np.mean(d ** 2)))
         # A 16 x 16 tile is a small sample: ONE camera sample that takes another decision than the oracle's (a path through the glass
         # sphere that ends on the light in one arithmetic and next to it in the other: 25 / spp in one pixel) is worth 9e-4 of tile RMSE
-        # at 1024 spp, while whole frames sit at 2e-6 ... 2.5e-4.  So: the north star's 1e-3 for the tile without its two worst pixels
-        # (isolated decision flips, explained sample by sample in tests/test_mismatch_gpu.py), and 2e-3 with them.
+        # at 1024 spp, while whole frames sit at 2e-6 ... 2.5e-4.  So the north star's 1e-3 holds for the tile without its (at most two)
+        # pixels that are off by more than 5e-3 -- and each pixel exempted that way is examined right here, sample by sample: every
+        # differing sample of it must differ first in a discrete decision, or at / after a vertex on a specular or Phong surface
+        # (helpers.explain_sample); a pixel that is merely wrong fails.  With those pixels the tile must still meet 2e-3.
         m = np.abs(d).max(axis=1)
         keep = np.ones(d.shape[0], bool)
+        ys, xs = np.nonzero(fin)
         for i in np.argsort(m)[-2:]:
             if m[i] > 5e-3:
                 keep[i] = False
+                kinds = explain_pixel(api, O, scene, params, x0 + int(xs[i]), y0 + int(ys[i]))
+                assert sum(kinds.values()) > 0, ("exempted pixel without a differing sample", (tx, ty), int(xs[i]), int(ys[i]))
+                print("tile", (tx, ty), "pixel", (x0 + int(xs[i]), y0 + int(ys[i])), "off by %.1e:" % m[i], kinds)
         assert float(np.sqrt(np.mean(d[keep] ** 2))) < tol and rmse < 2 * tol, ((tx, ty), rmse, int((~keep).sum()))
         out.append(rmse)
     return out

@@ -153,6 +153,22 @@ def test_kat_scene_intersect_and_occluded(which, A, api, O, rng):
     g, c = api.kat_scene_intersect(scene, rays), O.kat_scene_intersect(scene, rays)
     agree = (g[:, 0] == c[:, 0]) & (g[:, 8] == c[:, 8])
     assert agree.mean() > 0.998
+    # Every disagreement must be a TIE: the oracle itself gives the GPU's answer when the ray is moved by 3e-5 of the scene's size
+    # (a rectangle's edge, a sphere's silhouette, two surfaces at nearly one distance, a hit at tmax) -- nothing else may differ.
+    eps = 3e-5
+    for i in np.flatnonzero(~agree):
+        found = False
+        for _ in range(64):
+            r = rays[i].copy()
+            r[0:3] += (eps * box) * rng.uniform(-1, 1, 3).astype(np.float32)
+            r[3:6] = unit(r[3:6] + eps * rng.uniform(-1, 1, 3)).astype(np.float32)
+            if np.isfinite(r[6]):
+                r[6] *= 1 + eps * rng.uniform(-1, 1)
+            cc = O.kat_scene_intersect(scene, r[None])[0]
+            if cc[0] == g[i, 0] and cc[8] == g[i, 8]:
+                found = True
+                break
+        assert found, ("nearest hit differs away from any tie", rays[i], g[i], c[i])
     hit = agree & (c[:, 0] == 1)
     assert_close_q(g[hit, 1:8], c[hit, 1:8], 3e-5)
     # occlusion between points on surfaces (first hits) and random targets, incl. the light (quirk 1)
@@ -163,6 +179,16 @@ def test_kat_scene_intersect_and_occluded(which, A, api, O, rng):
     x = np.concatenate([P, N, T], 1).astype(np.float32)
     go, co = api.kat_occluded(scene, x), O.kat_occluded(scene, x)
     assert (go != co).mean() < 3e-3
+    for i in np.flatnonzero(go != co):   # the same for occlusion flips: the oracle's answer flips within 3e-5 of this segment
+        found = False
+        for _ in range(64):
+            r = x[i].copy()
+            r[0:3] += (eps * box) * rng.uniform(-1, 1, 3).astype(np.float32)
+            r[6:9] += (eps * box) * rng.uniform(-1, 1, 3).astype(np.float32)
+            if O.kat_occluded(scene, r[None])[0] == go[i]:
+                found = True
+                break
+        assert found, ("occlusion differs away from any threshold", x[i], go[i], co[i])
     assert 0.05 < co.mean() < 0.999
 
 
@@ -205,9 +231,9 @@ def test_li_per_sample_veach(strategy, depth, A, api, O):
     params = api.make_params(96, 54, 128, direct_sample=strategy, max_path_depth=depth)
     pixels = [(48, 27), (5, 5), (30, 40), (70, 30), (48, 50), (20, 20), (80, 45), (60, 8)]
     bad, tot, sg, sc = li_agreement(api, O, scene, params, pixels)
-    # measured: 9 of 1024 samples differ for the strategies with a light-sampling half (shadow rays at the sphere lights'
-    # self-occlusion threshold, quirk 1: tests/test_mismatch_gpu.py), 0 for the others; sums agree to 2e-3
-    assert bad <= 0.015 * tot, (bad, tot)
+    # measured: 9 of 1024 samples (0.9 %) differ for the strategies with a light-sampling half (shadow rays at the sphere lights'
+    # self-occlusion threshold, quirk 1: tests/test_mismatch_gpu.py), 0 for the others; sums agree to 2e-3.  Bound: measured + 0.2 %.
+    assert bad <= 0.011 * tot, (bad, tot)
     assert abs(sg - sc) <= 5e-3 * max(sc, 1.0)
 
 

@@ -113,9 +113,9 @@ typedef struct ky_scene {
 } ky_scene;
 
 /* Hard limits of the device path (the scene lives in on-chip memory). */
-#define KYHIP_MAX_SHAPES    64
-#define KYHIP_MAX_SURFACES  64
-#define KYHIP_MAX_MATERIALS 32
+#define KYHIP_MAX_SHAPES    256
+#define KYHIP_MAX_SURFACES  256
+#define KYHIP_MAX_MATERIALS 64
 #define KYHIP_MAX_LIGHTS    16
 
 /* ------------------------------------------------------------------------------------------

@@ -21,6 +21,8 @@ DIRECT_IDLE, DIRECT_BSDF, DIRECT_LIGHT, DIRECT_BSDF_MIS, DIRECT_LIGHT_MIS, DIREC
 SAMPLER_DEBUG, SAMPLER_RANDOM = 0, 1
 SP_VARIANT_SMALLPT, SP_VARIANT_REWRITE = 0, 1
 KY_OK, KY_ERR_INVALID_VALUE, KY_ERR_LIMIT, KY_ERR_DEVICE, KY_ERR_NO_DEVICE = 0, -1, -2, -3, -4
+# hard limits of the device path (include/kyhip.h)
+MAX_SHAPES, MAX_SURFACES, MAX_MATERIALS, MAX_LIGHTS = 256, 256, 64, 16
 
 # cornell_box_enum_t (ky.cpp:3121-3145)
 CB_LIGHT_AREA, CB_LIGHT_DIRECTION, CB_LIGHT_POINT, CB_LIGHT_ENVIRONMENT = 1, 2, 4, 8

@@ -264,8 +264,9 @@ struct SceneRef {
     const DScene* p;
     bool general;
     int feat;
-    __device__ __forceinline__ SceneRef(const DScene* p_) : p(p_), general(true), feat(0) {}
-    __device__ __forceinline__ SceneRef(const DScene* p_, bool general_, int feat_ = 0) : p(p_), general(general_), feat(feat_) {}
+    bool large;   // the scene may hold more than 64 surfaces (LARGE instantiations; everything that converts from the bare pointer)
+    __device__ __forceinline__ SceneRef(const DScene* p_) : p(p_), general(true), feat(0), large(true) {}
+    __device__ __forceinline__ SceneRef(const DScene* p_, bool general_, int feat_ = 0, bool large_ = false) : p(p_), general(general_), feat(feat_), large(large_) {}
     __device__ __forceinline__ const DScene* operator->() const { return p; }
     __device__ __forceinline__ bool single_area() const { return (feat & KY_FEAT_SINGLE_AREA) != 0; }
     __device__ __forceinline__ bool single_light() const { return (feat & KY_FEAT_SINGLE_LIGHT) != 0; }
@@ -282,30 +283,59 @@ struct SceneRef {
     __device__ __forceinline__ bool may_have_env() const { return (feat & (KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_DELTA)) == 0; }
 };
 
-struct LdsScene {  // the per-workgroup LDS copy of the tables that are indexed per lane
-    DHit hit[KYHIP_MAX_SURFACES];
-    DMat mat[KYHIP_MAX_MATERIALS];
+// The per-workgroup LDS copy of the tables that are indexed per lane: hit[n_surfaces], mat[n_materials], light_color[n_lights][4].
+// Two homes.  The standard kernels keep a STATIC block for scenes of up to KY_LDS_SURFACES surfaces and KY_LDS_MATERIALS materials
+// (every scene ky ships has 11-13 and 4-8): its addresses are compile-time constants that fold into the ds_read offsets.  Larger
+// scenes (up to the ABI's KYHIP_MAX_*) run on the LARGE instantiations, which size the block by the scene in dynamic shared memory
+// (lds_scene_bytes() at launch) and pay an add per table access for it -- measured on the kernels that do not need it: Veach -2.2 %,
+// Cornell -0.5 %, which is why they keep the static block.
+constexpr int KY_LDS_SURFACES = 64, KY_LDS_MATERIALS = 32;
+struct LdsScene {
+    const DHit* hit;
+    const DMat* mat;
+    const float (*light_color)[4];
+};
+struct LdsSceneStatic {
+    DHit hit[KY_LDS_SURFACES];
+    DMat mat[KY_LDS_MATERIALS];
     float light_color[KYHIP_MAX_LIGHTS][4];
 };
+extern __shared__ __attribute__((aligned(16))) unsigned char g_lds_scene[];
+__host__ __device__ inline int lds_scene_mat_offset(int n_surfaces) { return (n_surfaces * (int)sizeof(DHit) + 15) & ~15; }
+__host__ __device__ inline int lds_scene_light_offset(int n_surfaces, int n_materials) { return lds_scene_mat_offset(n_surfaces) + n_materials * (int)sizeof(DMat); }
+__host__ __device__ inline int lds_scene_bytes(int n_surfaces, int n_materials, int n_lights) { return lds_scene_light_offset(n_surfaces, n_materials) + n_lights * 16; }
 
 KY_DEV f3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
 
-// cooperative copy global -> LDS, whole workgroup
-KY_DEV void stage_scene(LdsScene& L, SceneRef S) {
+// cooperative copy global -> LDS, whole workgroup; ends with a barrier
+template <bool LARGE>
+KY_DEV LdsScene stage_scene(SceneRef S) {
     const int tid = threadIdx.x, nt = blockDim.x;
+    const int ns = S->n_surfaces, nm = S->n_materials, nl = S->n_lights;
+    uint32_t *dst_h, *dst_m;
+    float* dst_l;
+    if (LARGE) {
+        dst_h = reinterpret_cast<uint32_t*>(g_lds_scene);
+        dst_m = reinterpret_cast<uint32_t*>(g_lds_scene + lds_scene_mat_offset(ns));
+        dst_l = reinterpret_cast<float*>(g_lds_scene + lds_scene_light_offset(ns, nm));
+    } else {
+        __shared__ LdsSceneStatic L;
+        dst_h = reinterpret_cast<uint32_t*>(L.hit);
+        dst_m = reinterpret_cast<uint32_t*>(L.mat);
+        dst_l = &L.light_color[0][0];
+    }
     const uint32_t* src_h = reinterpret_cast<const uint32_t*>(S->hit);
-    uint32_t* dst_h = reinterpret_cast<uint32_t*>(L.hit);
-    for (int i = tid; i < S->n_surfaces * (int)(sizeof(DHit) / 4); i += nt) dst_h[i] = src_h[i];
+    for (int i = tid; i < ns * (int)(sizeof(DHit) / 4); i += nt) dst_h[i] = src_h[i];
     const uint32_t* src_m = reinterpret_cast<const uint32_t*>(S->mat);
-    uint32_t* dst_m = reinterpret_cast<uint32_t*>(L.mat);
-    for (int i = tid; i < S->n_materials * (int)(sizeof(DMat) / 4); i += nt) dst_m[i] = src_m[i];
-    for (int i = tid; i < S->n_lights; i += nt) {
-        L.light_color[i][0] = S->light[i].color[0];
-        L.light_color[i][1] = S->light[i].color[1];
-        L.light_color[i][2] = S->light[i].color[2];
-        L.light_color[i][3] = 0.f;
+    for (int i = tid; i < nm * (int)(sizeof(DMat) / 4); i += nt) dst_m[i] = src_m[i];
+    for (int i = tid; i < nl; i += nt) {
+        dst_l[4 * i + 0] = S->light[i].color[0];
+        dst_l[4 * i + 1] = S->light[i].color[1];
+        dst_l[4 * i + 2] = S->light[i].color[2];
+        dst_l[4 * i + 3] = 0.f;
     }
     __syncthreads();
+    return LdsScene{reinterpret_cast<const DHit*>(dst_h), reinterpret_cast<const DMat*>(dst_m), reinterpret_cast<const float (*)[4]>(dst_l)};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1080,7 +1110,7 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 
         // (b) is any surface in front of the carrier?  (the carrier itself reproduces t_l exactly, and t < t_l is strict)
         unsigned long long queries = __ballot(pending);
         bool blocked = false;
-        if (__popcll(queries) > KY_TRANSPOSE_MAX) {
+        if (__popcll(queries) > KY_TRANSPOSE_MAX || (S.large && S->n_surfaces > 64)) {   // (lane j tests surface j: scenes of up to 64 surfaces)
             KY_PROBE(2);
             // the traversal may test the carrier with another formulation than (a) did (aar_hit vs par_hit): keep its own
             // hit, a few ulp around t_l, out of the interval

@@ -292,7 +292,6 @@ template <bool DEBUG_SAMPLER, int STRATEGY>
 __global__ __launch_bounds__(QE_THREADS, KY_QE_WAVES) void render_kernel_q(const DScene* __restrict__ S, RenderConst rc, ShardConst sh,
                                                                             unsigned* __restrict__ counter, unsigned long long* __restrict__ accum,
                                                                             unsigned* __restrict__ flags) {
-    __shared__ LdsScene Lds;
     __shared__ QeLds W;
     if (STRATEGY >= 0) rc.strategy = STRATEGY;
     const int tid = threadIdx.x;
@@ -304,7 +303,7 @@ __global__ __launch_bounds__(QE_THREADS, KY_QE_WAVES) void render_kernel_q(const
     if (tid < QS_COUNT) { W.head[tid] = 0; W.tail[tid] = tid == QS_REGEN ? QE_SLOTS : 0; }
     if (tid < QE_ITEMS) { W.items[tid].n_units = 0; W.items[tid].u0 = 0; }
     if (tid == 0) { W.busy = 0; W.n_items = 0; W.units_fetched = 0; W.unit_cursor = 0; W.exhausted = 0; W.fetch_lock = 0; }
-    stage_scene(Lds, S);   // ends with a barrier
+    const LdsScene Lds = stage_scene<false>(S);   // ends with a barrier (static block: the queue engine takes scenes of up to 64 surfaces)
 
     const int n_lights = S->n_lights;
     const bool nee_on = n_lights > 0;   // estimate_direct_lighting_idle (3880) still consumes its four numbers per light

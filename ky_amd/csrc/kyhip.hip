@@ -230,15 +230,16 @@ struct ItemSlot {  // one fetched work item, decoded once (wave-uniform) and rea
 // INTEGRATOR (with STRATEGY >= 0): path_tracing_iteration_t, or direct_lighting_t / one of the three recursive integrators
 // (render_multiple_integrator, ky.cpp:4740-4777, runs all five side by side).
 // The host's table of instantiations is g_variants below; kyhip_render_tiles_device launches the first one whose assumptions hold.
-template <bool DEBUG_SAMPLER, int STRATEGY, bool QUEUE = false, bool GENERAL = false, int FEAT = 0, int INTEGRATOR = KY_INTEGRATOR_PATH_TRACING_ITERATION>
+// LARGE: the scene's per-lane tables live in dynamic shared memory sized by the scene (more than KY_LDS_SURFACES surfaces or
+// KY_LDS_MATERIALS materials; ky_device.hpp, LdsScene).
+template <bool DEBUG_SAMPLER, int STRATEGY, bool QUEUE = false, bool GENERAL = false, int FEAT = 0, int INTEGRATOR = KY_INTEGRATOR_PATH_TRACING_ITERATION, bool LARGE = false>
 __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? KY_WAVES_PER_EU_QUEUE : KY_WAVES_PER_EU) : KY_WAVES_PER_EU_GENERIC) void render_kernel(const DScene* __restrict__ S_, RenderConst rc, ShardConst sh,
                                                                      unsigned* __restrict__ counter, unsigned long long* __restrict__ accum,
                                                                      unsigned* __restrict__ flags, float4* __restrict__ queue_mem) {
     static_assert(!QUEUE || (STRATEGY == KY_DIRECT_BOTH_MIS && INTEGRATOR == KY_INTEGRATOR_PATH_TRACING_ITERATION), "the deferred shadow rays are built into the iterative both_mis instantiation");
     static_assert(FEAT == 0 || (STRATEGY >= 0 && !QUEUE && !GENERAL && !DEBUG_SAMPLER), "scene facts are instantiated for kernels with a fixed strategy only");
     static_assert(STRATEGY >= 0 || INTEGRATOR == KY_INTEGRATOR_PATH_TRACING_ITERATION, "the run-time-dispatched kernel reads the integrator from rc");
-    const SceneRef S{S_, GENERAL, FEAT};
-    __shared__ LdsScene Lds;
+    const SceneRef S{S_, GENERAL, FEAT, LARGE};
     __shared__ ItemSlot ring[4][KY_RING];
     // the lane's pixel chunk (touched when a path starts or ends, not while a vertex is shaded) lives in LDS, not in registers
     __shared__ float c_lsum[3][256];
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? KY_WAVES_PER_EU_QUEUE
     __shared__ uint32_t c_key[256];
     __shared__ unsigned long long c_def[QUEUE ? 3 * 256 : 1];   // QUEUE: fixed-point sums of the lane's resolved shadow rays
     const int tid = threadIdx.x;
-    stage_scene(Lds, S);
+    const LdsScene Lds = stage_scene<LARGE>(S);
     if (STRATEGY >= 0) { rc.strategy = STRATEGY; rc.integrator = INTEGRATOR; }  // compile-time constants from here on
     const int nee_weight = (rc.strategy == KY_DIRECT_IDLE || rc.integrator < KY_INTEGRATOR_DIRECT_LIGHTING ||
                             rc.integrator == KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION) ? 0 : S->n_lights;
@@ -501,8 +502,7 @@ __global__ void kat_light_kernel(const DScene* __restrict__ S, int li, const flo
 }
 
 __global__ void kat_scene_intersect_kernel(const DScene* __restrict__ S, const float* __restrict__ rays7, int n, float* __restrict__ out9) {
-    __shared__ LdsScene Lds;
-    stage_scene(Lds, S);
+    const LdsScene Lds = stage_scene<true>(S);   // KAT kernels: always the scene-sized dynamic block
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* r = rays7 + 7 * (size_t)i;
@@ -533,8 +533,7 @@ __global__ void kat_occluded_kernel(const DScene* __restrict__ S, const float* _
 
 template <bool DEBUG_SAMPLER>
 __global__ void kat_li_kernel(const DScene* __restrict__ S, RenderConst rc, int x, int y, int s0, int n, float* __restrict__ out3) {
-    __shared__ LdsScene Lds;
-    stage_scene(Lds, S);
+    const LdsScene Lds = stage_scene<true>(S);   // KAT kernels: always the scene-sized dynamic block
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     PathState ps;
     bool alive = i < n;
@@ -551,8 +550,7 @@ __global__ void kat_li_kernel(const DScene* __restrict__ S, RenderConst rc, int 
 
 // one light's direct-lighting estimate at given vertices with given random numbers (estimate_direct_lighting_*, 3889-4088)
 __global__ void kat_nee_kernel(const DScene* __restrict__ S, int strategy, int li, const float* __restrict__ in15, int n, float* __restrict__ out6) {
-    __shared__ LdsScene Lds;
-    stage_scene(Lds, S);
+    const LdsScene Lds = stage_scene<true>(S);   // KAT kernels: always the scene-sized dynamic block
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < n;
     const float* r = in15 + 15 * (size_t)(active ? i : 0);
@@ -583,8 +581,7 @@ __global__ void kat_nee_kernel(const DScene* __restrict__ S, int strategy, int l
 // one camera sample, traced vertex by vertex (lane 0 walks the path; the other lanes only keep the wave-uniform calls company)
 template <bool DEBUG_SAMPLER>
 __global__ void kat_li_trace_kernel(const DScene* __restrict__ S, RenderConst rc, int x, int y, int s, int max_rows, float* __restrict__ out) {
-    __shared__ LdsScene Lds;
-    stage_scene(Lds, S);
+    const LdsScene Lds = stage_scene<true>(S);   // KAT kernels: always the scene-sized dynamic block
     PathState ps;
     bool alive = threadIdx.x == 0;
     VertexTrace tr{out + 4, max_rows, 0};
@@ -1111,7 +1108,8 @@ struct DeviceCtx {
     unsigned long long clock = 0;
     StreamState* last_launch = nullptr;    // kyhip_kernel_ms reads its event pair
     hipStream_t stream = nullptr;   // the library's own stream on this device (kyhip_render_multi)
-    int variant_blocks[48] = {};           // resident workgroups per CU of g_variants[i] (0: not asked yet)
+    int variant_blocks[48] = {};           // resident workgroups per CU of g_variants[i] (0: not asked yet) ...
+    size_t variant_lds[48] = {};           // ... for a scene block of this many bytes
     int last_variant = -1;
     int q_blocks_per_cu[3] = {0, 0, 0};
 };
@@ -1324,9 +1322,11 @@ struct Variant {
     int strategy;
     bool queue, general;
     int feat, integrator;
+    bool large;
     RenderFn fn;
 };
-#define KY_VARIANT(D, S, Q, G, F, I) Variant{D, S, Q, G, F, I, render_kernel<D, S, Q, G, F, I>}
+#define KY_VARIANT(D, S, Q, G, F, I) Variant{D, S, Q, G, F, I, false, render_kernel<D, S, Q, G, F, I>}
+#define KY_VARIANT_LARGE(D, S, Q, G, F, I) Variant{D, S, Q, G, F, I, true, render_kernel<D, S, Q, G, F, I, true>}
 constexpr int IT = KY_INTEGRATOR_PATH_TRACING_ITERATION;
 static const Variant g_variants[] = {
     // the iterative integrator, both_mis: by scene facts
@@ -1362,6 +1362,9 @@ static const Variant g_variants[] = {
     KY_VARIANT(true, -1, false, false, 0, IT),
     KY_VARIANT(false, -1, false, true, 0, IT),
     KY_VARIANT(true, -1, false, true, 0, IT),
+    // scenes beyond the static LDS block (more than 64 surfaces or 32 materials): the run-time-dispatched kernels with a scene-sized block
+    KY_VARIANT_LARGE(false, -1, false, true, 0, IT),
+    KY_VARIANT_LARGE(true, -1, false, true, 0, IT),
 };
 constexpr int KY_N_VARIANTS = (int)(sizeof g_variants / sizeof g_variants[0]);
 static_assert(KY_N_VARIANTS <= 48, "DeviceCtx::variant_blocks");
@@ -1369,8 +1372,9 @@ static_assert(KY_N_VARIANTS <= 48, "DeviceCtx::variant_blocks");
 static const Variant* pick_variant(const ky_render_params* p, const DScene* packed, int light_count, int n_pix) {
     const bool dbg = p->sampler == KY_SAMPLER_DEBUG;
     const bool general = packed->general != 0;
+    const bool large = packed->n_surfaces > KY_LDS_SURFACES || packed->n_materials > KY_LDS_MATERIALS;
     for (const Variant& v : g_variants) {
-        if (v.dbg != dbg) continue;
+        if (v.dbg != dbg || v.large != large) continue;
         if (general && !v.general) continue;
         if (v.strategy >= 0) {
             if (!specialisation_enabled() && !(v.strategy == KY_DIRECT_BOTH_MIS && v.feat == 0 && v.integrator == IT)) continue;   // KYHIP_SPECIALISE=0 keeps both_mis (and its queue form)
@@ -1382,7 +1386,7 @@ static const Variant* pick_variant(const ky_render_params* p, const DScene* pack
         if (v.queue && !(n_pix < (1 << 26) && shadow_queue_wanted(light_count))) continue;
         return &v;
     }
-    return nullptr;   // not reached: the last four entries accept everything
+    return nullptr;   // not reached: the last entries accept everything
 }
 
 int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render_params* p, float* d_tiles, void* d_workspace,
@@ -1420,11 +1424,13 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
     }
     unsigned long long* accum = (unsigned long long*)ws;
     unsigned* flags = (unsigned*)(accum + (size_t)sh.n_pix * 3);
+    const bool large_scene = scene->surface_count > KY_LDS_SURFACES || scene->material_count > KY_LDS_MATERIALS;
+    const size_t lds_bytes = large_scene ? (size_t)lds_scene_bytes(scene->surface_count, scene->material_count, scene->light_count) : 0;   // LARGE kernels' LdsScene
     HIP_TRY(hipMemsetAsync(ws, 0, need, stream));
     HIP_TRY(hipMemsetAsync(st->d_counter, 0, sizeof(unsigned), stream));
 
     // the queue engine implements path_tracing_iteration_t; every other integrator runs on the lane engine
-    if (current_engine() == KY_ENGINE_QUEUE && p->integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION) {
+    if (current_engine() == KY_ENGINE_QUEUE && p->integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION && !large_scene) {
         const int variant = p->sampler == KY_SAMPLER_DEBUG ? 2 : (p->direct_sample == KY_DIRECT_BOTH_MIS ? 0 : 1);
         const int per_cu = c->q_blocks_per_cu[variant] > 0 ? c->q_blocks_per_cu[variant] : 1;
         unsigned grid = (unsigned)(c->cus * per_cu);
@@ -1440,10 +1446,11 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
         const Variant* v = pick_variant(p, sc->h, scene->light_count, sh.n_pix);
         if (!v) return fail(KY_ERR_DEVICE, "internal: no render kernel for these parameters");
         const int vi = (int)(v - g_variants);
-        if (c->variant_blocks[vi] == 0) {
+        if (c->variant_blocks[vi] == 0 || c->variant_lds[vi] != lds_bytes) {   // resident workgroups per CU: depends on the scene's LDS block
             int per_cu = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v->fn, 256, 0));
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v->fn, 256, lds_bytes));
             c->variant_blocks[vi] = per_cu > 0 ? per_cu : 1;
+            c->variant_lds[vi] = lds_bytes;
         }
         const int per_cu = c->variant_blocks[vi];
         if (v->queue && !st->d_shadow_queue)   // the wavefronts' shadow-ray stacks of this stream's launches
@@ -1453,7 +1460,7 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
         if (grid > need_blocks) grid = need_blocks;
         if (grid < 1) grid = 1;
         HIP_TRY(hipEventRecord(st->ev0, stream));
-        hipLaunchKernelGGL(v->fn, dim3(grid), dim3(256), 0, stream, (const DScene*)sc->d, rc, sh, st->d_counter, accum, flags, v->queue ? st->d_shadow_queue : (float4*)nullptr);
+        hipLaunchKernelGGL(v->fn, dim3(grid), dim3(256), lds_bytes, stream, (const DScene*)sc->d, rc, sh, st->d_counter, accum, flags, v->queue ? st->d_shadow_queue : (float4*)nullptr);
         c->last_variant = vi;
     }
     HIP_TRY(hipGetLastError());
@@ -1487,8 +1494,8 @@ const char* kyhip_last_kernel(int device) {
     else if (c->last_variant >= 0) {
         const Variant& v = g_variants[c->last_variant];
         char buf[160];
-        snprintf(buf, sizeof buf, "render_kernel<%sstrategy %d%s%s, feat %d, integrator %d>", v.dbg ? "debug sampler, " : "", v.strategy, v.queue ? ", deferred shadow rays" : "",
-                 v.general ? ", general shapes" : "", v.feat, v.integrator);
+        snprintf(buf, sizeof buf, "render_kernel<%sstrategy %d%s%s%s, feat %d, integrator %d>", v.dbg ? "debug sampler, " : "", v.strategy, v.queue ? ", deferred shadow rays" : "",
+                 v.general ? ", general shapes" : "", v.large ? ", scene-sized LDS block" : "", v.feat, v.integrator);
         name = buf;
     }
     return name.c_str();
@@ -1688,7 +1695,7 @@ int kyhip_kat_scene_intersect(int device, const ky_scene* scene, const float* ra
     return kat_run(device, rays7, (size_t)n * 7 * 4, out9, (size_t)n * 9 * 4, [&](DeviceCtx* c, const float* d_in, float* d_out) {
         SceneSlot* sc; int r = upload_scene(c, scene, 0, &sc);
         if (r != KY_OK) return r;
-        hipLaunchKernelGGL(kat_scene_intersect_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, (const DScene*)sc->d, d_in, n, d_out);
+        hipLaunchKernelGGL(kat_scene_intersect_kernel, dim3((n + 255) / 256), dim3(256), lds_scene_bytes(scene->surface_count, scene->material_count, scene->light_count), 0, (const DScene*)sc->d, d_in, n, d_out);
         return (int)KY_OK;
     });
 }
@@ -1742,8 +1749,8 @@ int kyhip_kat_li(int device, const ky_scene* scene, const ky_render_params* p, i
     return kat_run(device, &dummy, 4, out3, (size_t)n * 3 * 4, [&](DeviceCtx* c, const float*, float* d_out) {
         SceneSlot* sc; int r = upload_scene(c, scene, 0, &sc);
         if (r != KY_OK) return r;
-        if (dbg) hipLaunchKernelGGL(kat_li_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, 0, (const DScene*)sc->d, rc, x, y, s0, n, d_out);
-        else hipLaunchKernelGGL(kat_li_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, 0, (const DScene*)sc->d, rc, x, y, s0, n, d_out);
+        if (dbg) hipLaunchKernelGGL(kat_li_kernel<true>, dim3((n + 255) / 256), dim3(256), lds_scene_bytes(scene->surface_count, scene->material_count, scene->light_count), 0, (const DScene*)sc->d, rc, x, y, s0, n, d_out);
+        else hipLaunchKernelGGL(kat_li_kernel<false>, dim3((n + 255) / 256), dim3(256), lds_scene_bytes(scene->surface_count, scene->material_count, scene->light_count), 0, (const DScene*)sc->d, rc, x, y, s0, n, d_out);
         return (int)KY_OK;
     });
 }
@@ -1760,7 +1767,7 @@ int kyhip_kat_nee(int device, const ky_scene* scene, int direct_sample, int ligh
     return kat_run(device, in15, (size_t)n * 15 * 4, out6, (size_t)n * 6 * 4, [&](DeviceCtx* c, const float* d_in, float* d_out) {
         SceneSlot* sc; int r = upload_scene(c, scene, 0, &sc);
         if (r != KY_OK) return r;
-        hipLaunchKernelGGL(kat_nee_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, (const DScene*)sc->d, direct_sample, light, d_in, n, d_out);
+        hipLaunchKernelGGL(kat_nee_kernel, dim3((n + 255) / 256), dim3(256), lds_scene_bytes(scene->surface_count, scene->material_count, scene->light_count), 0, (const DScene*)sc->d, direct_sample, light, d_in, n, d_out);
         return (int)KY_OK;
     });
 }
@@ -1776,8 +1783,8 @@ int kyhip_kat_li_trace(int device, const ky_scene* scene, const ky_render_params
     const int rcode = kat_run(device, &dummy, 4, host.data(), host.size() * 4, [&](DeviceCtx* c, const float*, float* d_out) {
         SceneSlot* sc; int r = upload_scene(c, scene, 0, &sc);
         if (r != KY_OK) return r;
-        if (dbg) hipLaunchKernelGGL(kat_li_trace_kernel<true>, dim3(1), dim3(64), 0, 0, (const DScene*)sc->d, rc, x, y, s, max_rows, d_out);
-        else hipLaunchKernelGGL(kat_li_trace_kernel<false>, dim3(1), dim3(64), 0, 0, (const DScene*)sc->d, rc, x, y, s, max_rows, d_out);
+        if (dbg) hipLaunchKernelGGL(kat_li_trace_kernel<true>, dim3(1), dim3(64), lds_scene_bytes(scene->surface_count, scene->material_count, scene->light_count), 0, (const DScene*)sc->d, rc, x, y, s, max_rows, d_out);
+        else hipLaunchKernelGGL(kat_li_trace_kernel<false>, dim3(1), dim3(64), lds_scene_bytes(scene->surface_count, scene->material_count, scene->light_count), 0, (const DScene*)sc->d, rc, x, y, s, max_rows, d_out);
         return (int)KY_OK;
     });
     if (rcode != KY_OK) return rcode;

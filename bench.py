@@ -77,7 +77,8 @@ def parse():
                     help="direct_sample_enum_t of the path integrator frames (profiling the run-time-dispatched kernel; the metric's configs use 48)")
     ap.add_argument("--integrator", type=int, default=A.INTEGRATOR_PATH_TRACING_ITERATION, choices=[6, 8, 9, 10, 11],
                     help="integrator_enum_t of the path frames (profiling direct_lighting_t = 6 and the recursive integrators 8 / 9 / 10; the metric's configs use 11)")
-    ap.add_argument("--no-pipeline", action="store_true", help="render the timed steps on one stream (no overlap of a frame's start with the previous frame's tail)")
+    ap.add_argument("--no-pipeline", action="store_true", help="render the timed steps on one stream even with N > 1 (no overlap of a frame's start with the previous frame's tail)")
+    ap.add_argument("--pipeline", action="store_true", help="overlap consecutive frames on two streams at N = 1 too (default: only with N > 1)")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_workloads and projected_scaling (they run for the default N = 1 cornell line only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
@@ -277,7 +278,11 @@ def main():
             tdist.barrier()
         torch.cuda.synchronize(dev)
 
-    pipeline = not args.no_pipeline and not one_gpu_test
+    # Launch overlap: with N > 1 every rank renders 1/N of the frame and the per-launch start-up and tail of the persistent kernel
+    # (0.3 ms against 7 ms at N = 8) are what limit scaling, so consecutive frames go to two alternating streams and the next frame's
+    # kernel fills them (ky_amd/dist.py).  At N = 1 the gain is 0.4 % and the overlap would blur rocprofv3's per-kernel durations of
+    # this very command, so the single-GPU line renders on one stream; --pipeline forces it on (projected_scaling measures its effect).
+    pipeline = (world > 1 or args.pipeline) and not args.no_pipeline
 
     def run_workload(wargs, steps, warmup):
         """-> dict(frames, name, elapsed, kernel_ms per frame, film_mean): `warmup` untimed and `steps` timed steps of the workload, then an

@@ -249,10 +249,15 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(29700 + os.getpid() % 200), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args,
                          capture_output=True, text=True, env=env, cwd=tmp_path, check=True)
+    piped = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pipeline"] + args, capture_output=True, text=True, env=env, cwd=tmp_path, check=True)
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    j3 = json.loads([l for l in piped.stdout.splitlines() if l.startswith("{")][-1])
     assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["scaling"] == "strong"
     assert j1["film_mean"] == j2["film_mean"] and j1["film_mean"] > 0.01
+    # launches pipelined on two streams (the default with N > 1, forced here at N = 1 as well): the same film
+    assert "pipelined" in j2["config"]["parallelism"] and "pipelined" in j3["config"]["parallelism"] and "one stream" in j1["config"]["parallelism"]
+    assert j3["film_mean"] == j1["film_mean"]
     for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in j2
     assert j2["roofline"]["bound"] == "valu" and j2["roofline"]["contract_bound"] == "hbm" and len(j2["config"]["frames"]) == 6

@@ -1,8 +1,9 @@
 #!/bin/bash
 # Regenerates the judged profile set of a round on the GPU box: tools/final_profiles.sh <prefix, e.g. r02_c>   (after `make all ubench` here)
-# For each of four kernels -- the both_mis instantiation for one rectangle light (Cornell, configs[1]), the one with deferred shadow
-# rays (Veach, configs[2]), the light_mis instantiation and the run-time-dispatched render_kernel<false,-1> (both Cornell, light_mis) -- five summaries: kernel trace +
-# stats, SQ issue counters, SQ instruction mix, FETCH_SIZE and WRITE_SIZE in separate pmc passes.  Then the bench lines.
+# For each of five kernels -- the both_mis instantiation for one rectangle light (Cornell, configs[1]), the one with deferred shadow
+# rays (Veach, configs[2]), the light_mis instantiation, the run-time-dispatched render_kernel<false,-1> (both Cornell, light_mis) and
+# path_tracing_recursion_t's instantiation (Cornell) -- five summaries: kernel trace + stats, SQ issue counters, SQ instruction mix,
+# FETCH_SIZE and WRITE_SIZE in separate pmc passes.  Then the per-cell rates of ky's experiment grids, the shard scan and the bench lines.
 P=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
@@ -25,12 +26,15 @@ run light_mis --workload cornell --direct-sample 32
 export KYHIP_SPECIALISE=0   # the run-time-dispatched kernel (what the recursive integrators and general scenes run on), on the same workload
 run generic --workload cornell --direct-sample 32
 unset KYHIP_SPECIALISE
+run recursion --workload cornell --integrator 9   # one of the recursive integrators on its own instantiation (render_multiple_integrator's cells)
 ./build_variants/valu_peak > gpurun_out/final/${P}_valu_peak_ubench.txt 2>&1
 ./build_variants/valu_pk > gpurun_out/final/${P}_valu_pk_ubench.txt 2>&1
 ./build_variants/salu_mix > gpurun_out/final/${P}_salu_mix_ubench.txt 2>&1
-python3 bench.py 2>/dev/null | tail -1 > gpurun_out/final/${P}_bench_line_cornell.json
-python3 bench.py --workload veach 2>/dev/null | tail -1 > gpurun_out/final/${P}_bench_line_veach.json
-python3 bench.py --workload batch 2>/dev/null | tail -1 > gpurun_out/final/${P}_bench_line_batch.json
+python3 tools/grid_rates.py 256 2>/dev/null > gpurun_out/final/${P}_grid_rates.txt
+python3 tools/shard_scan.py 2>/dev/null > gpurun_out/final/${P}_shard_scan.txt
+python3 bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/final/${P}_bench_line_cornell.json
+python3 bench.py --workload veach --no-extra 2>/dev/null | tail -1 > gpurun_out/final/${P}_bench_line_veach.json
+python3 bench.py --workload batch --no-extra 2>/dev/null | tail -1 > gpurun_out/final/${P}_bench_line_batch.json
 python3 bench.py --workload stress --steps 1 --warmup 0 2>/dev/null | tail -1 > gpurun_out/final/${P}_bench_line_stress.json
 python3 bench.py --workload cornell --direct-sample 32 2>/dev/null | tail -1 > gpurun_out/final/${P}_bench_line_cornell_light_mis.json
 ls -la gpurun_out/final | tail -40

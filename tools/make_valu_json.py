@@ -23,10 +23,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
-SAMPLES = {"cornell": 1024 * 768 * 1024, "veach": 1280 * 720 * 1024, "light_mis": 1024 * 768 * 1024, "generic": 1024 * 768 * 1024}
-LABEL = {"cornell": "render_kernel<false,48,false,false,KY_FEAT_CORNELL> (one rectangle area light) on BASELINE configs[1] (Cornell 1024x768x1024)",
-         "veach": "render_kernel<false,48,QUEUE> on configs[2]'s scene at 1024 spp (Veach 1280x720)",
-         "light_mis": "render_kernel<false,32> (the light_mis instantiation) on configs[1]'s scene",
+SAMPLES = {"cornell": 1024 * 768 * 1024, "veach": 1280 * 720 * 1024, "light_mis": 1024 * 768 * 1024, "generic": 1024 * 768 * 1024, "recursion": 1024 * 768 * 1024}
+LABEL = {"cornell": "render_kernel<strategy 48, feat 7 (one rectangle area light), integrator 11> on BASELINE configs[1] (Cornell 1024x768x1024)",
+         "veach": "render_kernel<strategy 48, deferred shadow rays> on configs[2]'s scene at 1024 spp (Veach 1280x720)",
+         "light_mis": "render_kernel<strategy 32> (the light_mis instantiation) on configs[1]'s scene",
+         "recursion": "render_kernel<strategy 48, feat 7, integrator 9> (path_tracing_recursion_t) on configs[1]'s scene",
          "generic": "render_kernel<false,-1> (strategy read at run time; KYHIP_SPECIALISE=0) on configs[1]'s scene with direct_sample light_mis"}
 
 
@@ -81,7 +82,9 @@ def main():
     curve = salu_curve(os.path.join(PROF, prefix + "_salu_mix_ubench.txt"))
     plain, trans = ub["v_fmac_f32_e32 (VOP2, 3 vgpr)"], ub["v_rcp_f32"]
     valu, traffic = {}, None
-    for wl in ("cornell", "veach", "light_mis", "generic"):
+    for wl in ("cornell", "veach", "light_mis", "generic", "recursion"):
+        if not os.path.exists(os.path.join(PROF, "%s_%s_pmc_sq_issue.txt" % (prefix, wl))):
+            continue
         base = os.path.join(PROF, "%s_%s_" % (prefix, wl))
         issue, _, scratch = counters(base + "pmc_sq_issue.txt")
         mix, _, _ = counters(base + "pmc_sq_mix.txt")

@@ -730,8 +730,23 @@ KY_DEV LobeBasis make_lobe_basis(const Bsdf& B, f3 n, f3 wo) {
     if (B.lobe == LOBE_PHONG) {       // 2533-2536: wr = reflect(wo, z) in the shading frame, frame_t(wr) there
         const f3 wo_l = to_local(fr, wo);
         const f3 wr = mk3(-wo_l.x, -wo_l.y, wo_l.z);   // unit because wo is
+#ifdef KY_PHONG_BASIS_FRAMES   // the reference's operations one by one (A/B measurements)
         const Frame fl = make_frame(wr);
         L.a = to_world(fr, fl.s); L.b = to_world(fr, fl.t); L.c = to_world(fr, wr);
+#else
+        // frame_t(wr): t = normalize(cross(wr, X or Y)), s = cross(t, wr).  t has a zero component, and the shading frame is a rotation
+        // (s x t = n), so cross products may be taken in world space: b = to_world(t), c = to_world(wr), a = cross(b, c) -- one frame
+        // transform of a vector with a zero component, one of wr, one cross product instead of a frame build and three transforms.
+        L.c = to_world(fr, wr);
+        if (fabsf(wr.x) > 0.99f) {
+            const float k = rsq(wr.z * wr.z + wr.x * wr.x);
+            L.b = fr.s * (-wr.z * k) + fr.n * (wr.x * k);       // t = (-wr.z, 0, wr.x) k
+        } else {
+            const float k = rsq(wr.z * wr.z + wr.y * wr.y);
+            L.b = fr.t * (wr.z * k) + fr.n * (-wr.y * k);       // t = (0, wr.z, -wr.y) k
+        }
+        L.a = cross(L.b, L.c);
+#endif
     }
     return L;
 }

@@ -202,7 +202,7 @@ static ShardConst make_shard(const ky_render_params* p) {
 #define KY_MAX_RETRACE 1
 #endif
 #ifndef KY_RETRACE_THRESHOLD
-#define KY_RETRACE_THRESHOLD 40
+#define KY_RETRACE_THRESHOLD 80
 #endif
 #ifndef KY_WAVES_PER_EU
 #define KY_WAVES_PER_EU 6           // the hot instantiation <false, both_mis>: 80 VGPRs
@@ -370,7 +370,9 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? KY_WAVES_PER_EU_QUEUE
                     alive = false;
                 }
             }
-            if (attempt >= KY_MAX_RETRACE) break;
+            // (single-light instantiations never retrace: one more traversal against two per vertex never paid there, and the loop
+            // around it cost 1.9 % by itself; with Veach's five lights the retrace is worth 16 %)
+            if (attempt >= ((FEAT & KY_FEAT_SINGLE_LIGHT) ? 0 : KY_MAX_RETRACE)) break;
             // lanes that could start another path right now; worth one more traversal if they would otherwise idle
             // through (2 traversals x lights + shading) that is worth more than the extra traversal
             const int idle = __popcll(__ballot(!alive && !done && open));

@@ -21,7 +21,7 @@ Rank 0 prints ONE JSON line.  The CPU oracle is used here ONLY for the reported 
 never inside the timed GPU region.
 
 Beside the contract's fields the default N = 1 line carries (all measured live, outside the timed region):
-  extra_workloads     one step each of configs[2] (veach) and configs[3] (batch) with their kernel durations
+  extra_workloads     one step each of configs[2] (veach), configs[3] (batch) and configs[4] (stress) with their kernel durations
   projected_scaling   kernel-level strong-scaling efficiency for N = 2, 4, 8 from rendering every 1/N shard of the frame on this
                       one GPU (the slowest shard sets the pace), and the cost of an N = 8 shard when launches are pipelined
   roofline.valu       the counters of the real bound (VALU issue) from profiles/valu.json, flagged stale when the live kernel time has
@@ -284,9 +284,10 @@ def main():
     # this very command, so the single-GPU line renders on one stream; --pipeline forces it on (projected_scaling measures its effect).
     pipeline = (world > 1 or args.pipeline) and not args.no_pipeline
 
-    def run_workload(wargs, steps, warmup):
+    def run_workload(wargs, steps, warmup, record_in_timed=False):
         """-> dict(frames, name, elapsed, kernel_ms per frame, film_mean): `warmup` untimed and `steps` timed steps of the workload, then an
-        untimed pass that reads every frame's kernel duration (HIP events recorded by the library around render_kernel only)."""
+        untimed pass that reads every frame's kernel duration (HIP events recorded by the library around render_kernel only).
+        record_in_timed (the 25-second stress frame): the timed steps themselves read the kernel durations, nothing is rendered twice."""
         frames, (FH, FW_), name = workload(wargs)
         film = torch.zeros((FH, FW_, 3), dtype=torch.float32, device=dev) if rank == 0 else None
 
@@ -312,12 +313,13 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            step(False)
+            step(record_in_timed)
         barrier()
         elapsed = time.perf_counter() - t0
-        for _ in range(1 if frames[0].samples > 2e10 else max(1, min(steps, 3))):
-            step(True)
-        barrier()
+        if not record_in_timed:
+            for _ in range(1 if frames[0].samples > 2e10 else max(1, min(steps, 3))):
+                step(True)
+            barrier()
         t = torch.tensor([elapsed] + [sum(k) / len(k) for k in kernel_ms], dtype=torch.float64, device=dev)
         if world > 1:
             tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
@@ -394,17 +396,19 @@ def main():
 
 
 def extra_workloads(args, run_workload):
-    """configs[2] and configs[3], one timed step each after a warm-up step (outside the headline's timed region), so that the driver's
-    record of the default run carries them: value, ms per step, the live kernel duration of every frame, the contract fraction."""
+    """configs[2], [3] and [4], one timed step each (outside the headline's timed region; veach and batch after a warm-up step, the
+    25-second stress frame without one), so that the driver's record of the default run carries them: value, ms per step, the live kernel
+    duration of every frame, the contract fraction."""
     out = {}
-    for wl in ("veach", "batch"):
+    for wl in ("veach", "batch", "stress"):
         wargs = argparse.Namespace(**vars(args))
         wargs.workload = wl
         wargs.width = wargs.height = wargs.spp = wargs.depth = 0
-        r = run_workload(wargs, 1, 1)
+        warm = 0 if wl == "stress" else 1
+        r = run_workload(wargs, 1, warm, record_in_timed=(wl == "stress"))
         samples = sum(fr.samples for fr in r["frames"])
         achieved, _ = contract_frac(r["frames"], r["kernel_ms"])
-        out[wl] = {"workload": r["name"], "value": samples / r["elapsed"] / 1e6, "unit": "Msamples/s", "steps": 1, "warmup": 1, "ms_per_step": r["elapsed"] * 1e3,
+        out[wl] = {"workload": r["name"], "value": samples / r["elapsed"] / 1e6, "unit": "Msamples/s", "steps": 1, "warmup": warm, "ms_per_step": r["elapsed"] * 1e3,
                    "frames": [fr.label for fr in r["frames"]], "kernel_ms_per_frame": r["kernel_ms"], "kernel_ms": sum(r["kernel_ms"]),
                    "roofline_frac": achieved / HBM_PEAK_GBS, "film_mean": r["film_mean"]}
     return out

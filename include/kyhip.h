@@ -229,7 +229,7 @@ int kyhip_render(int device, const ky_scene* scene, const ky_render_params* para
  *   shard (tile_first, tile_step) into a DEVICE film (same layout as kyhip_render's film_rgb).
  *
  * Streams: what a launch writes (work counter, accumulator workspace, timing events, shadow-ray stacks) belongs to the STREAM it is
- *   enqueued on -- the library keeps one such state per (device, stream), up to four per device -- so calls on one stream execute in
+ *   enqueued on -- the library keeps one such state per (device, stream), up to eight per device -- so calls on one stream execute in
  *   stream order and calls on different streams share nothing and may overlap on the device: a frame's kernel starts on the compute
  *   units the previous frame's persistent kernel is draining from (ky_amd/dist.py alternates two streams).  The packed scene is cached
  *   per device by content (eight slots): alternating between a few scenes uploads each once.  Calls for different devices are

@@ -1100,7 +1100,7 @@ struct SceneSlot {
     hipStream_t upload_stream = nullptr;
     unsigned long long last_use = 0;
 };
-constexpr int KY_STREAM_STATES = 4, KY_SCENE_SLOTS = 8;
+constexpr int KY_STREAM_STATES = 8, KY_SCENE_SLOTS = 8;
 struct DeviceCtx {
     std::mutex m;
     int device = 0;

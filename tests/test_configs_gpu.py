@@ -299,14 +299,40 @@ def test_specialised_instantiations_change_nothing(A, api, O):
                 p = api.make_params(w, h, 96, max_path_depth=depth, direct_sample=strategy, tile_w=16, tile_h=8)
                 lib.kyhip_set_specialisation(1)
                 on = api.render(scene, p)
+                kernel_on = lib.kyhip_last_kernel(0).decode()
                 lib.kyhip_set_specialisation(0)
                 off = api.render(scene, p)
+                kernel_off = lib.kyhip_last_kernel(0).decode()
                 assert on.mean() > 0.01 or strategy == A.DIRECT_IDLE
-                if strategy == A.DIRECT_BOTH_MIS and scene is not room:
-                    # the Cornell-lamp instantiation: the same expressions, but with code removed around them the compiler contracts a
-                    # few multiply-adds differently -- the last bit of some pixels (measured: 6e-8 on 10 % of them)
-                    assert np.abs(on - off).max() <= 1.2e-7, (strategy, depth, np.abs(on - off).max())
+                assert "feat 0" in kernel_off and ("strategy -1" in kernel_off or "strategy 48" in kernel_off), kernel_off
+                if "feat 0" not in kernel_on:
+                    # an instantiation by scene facts (the Cornell lamp): the same expressions, but with code removed around them the
+                    # compiler contracts a few multiply-adds differently -- the last bit of some pixels (measured: 6e-8 on 10 % of them)
+                    assert scene is not room and np.abs(on - off).max() <= 1.2e-7, (kernel_on, depth, np.abs(on - off).max())
                 else:
                     assert np.array_equal(on, off), (strategy, depth)
+        # round 3: the other single-light facts and the other integrators' own kernels -- which instantiation runs, and that it changes nothing
+        W, H = 64, 48
+        for flag, fact in ((A.CB_LIGHT_AREA, "feat 7"), (A.CB_LIGHT_POINT, "feat 8"), (A.CB_LIGHT_DIRECTION, "feat 8"), (A.CB_LIGHT_ENVIRONMENT, "feat 16")):
+            scene = api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | flag, W, H)
+            for integrator in (A.INTEGRATOR_PATH_TRACING_ITERATION, A.INTEGRATOR_DIRECT_LIGHTING, A.INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION,
+                               A.INTEGRATOR_PATH_TRACING_RECURSION, A.INTEGRATOR_PATH_TRACING_RECURSION_DEFERED):
+                p = api.make_params(W, H, 64, integrator=integrator)
+                lib.kyhip_set_specialisation(1)
+                on = api.render(scene, p)
+                kernel_on = lib.kyhip_last_kernel(0).decode()
+                lib.kyhip_set_specialisation(0)
+                off = api.render(scene, p)
+                kernel_off = lib.kyhip_last_kernel(0).decode()
+                assert "integrator %d" % integrator in kernel_on and "strategy 48" in kernel_on, kernel_on
+                if integrator != A.INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION:    # (it samples no lights: one kernel for every scene)
+                    assert fact in kernel_on, (kernel_on, fact)
+                if integrator != A.INTEGRATOR_PATH_TRACING_ITERATION:
+                    assert "strategy -1" in kernel_off, kernel_off
+                fin = np.isfinite(on) & np.isfinite(off)
+                assert fin.mean() > 0.999 and np.abs(on[fin] - off[fin]).max() <= 2.4e-7, (kernel_on, kernel_off, np.abs(on[fin] - off[fin]).max())
+        lib.kyhip_set_specialisation(1)
+        api.render(api.mis_scene(64, 36), api.make_params(64, 36, 8))
+        assert "deferred shadow rays" in lib.kyhip_last_kernel(0).decode()
     finally:
         lib.kyhip_set_specialisation(prev)

@@ -255,7 +255,10 @@ enum : int {
                                  // BSDF-sampling estimators always take the carrier test, never the full traversal (estimate_by_bsdf)
     KY_FEAT_SINGLE_DELTA = 8,    // the lights are exactly ONE point or directional light, no environment light: the BSDF-sampling estimators
                                  // are gone (they return black for a delta light, 3894 / 3977), and with them every area / environment path
-    KY_FEAT_SINGLE_ENV = 16      // the lights are exactly ONE environment light (which is the scene's environment): no area / delta light code
+    KY_FEAT_SINGLE_ENV = 16,     // the lights are exactly ONE environment light (which is the scene's environment): no area / delta light code
+    KY_FEAT_SPHERE_LIGHTS = 32,  // every light is an area light that samples a SPHERE and is carried by sphere surfaces only, no environment light (the
+                                 // Veach scene's five): no other light kind's or light shape's code, no dispatch on either per light and vertex
+    KY_FEAT_NO_DELTA = 64        // no material is a mirror or glass: no delta lobe's code, prev_specular is never set
 };
 constexpr int KY_FEAT_SINGLE_LIGHT = KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_DELTA | KY_FEAT_SINGLE_ENV;   // any of them: no lights loop
 // (Measured and not kept: "every area light samples a sphere" + "no mirror or glass material" for the Veach scene: 11 fewer spilled
@@ -272,15 +275,16 @@ struct SceneRef {
     __device__ __forceinline__ bool single_light() const { return (feat & KY_FEAT_SINGLE_LIGHT) != 0; }
     // light kinds as far as the instantiation's facts decide them (wave-uniform; the rest is read from the light)
     __device__ __forceinline__ bool is_area(int kind) const {
-        return (feat & KY_FEAT_SINGLE_AREA) ? true : ((feat & (KY_FEAT_SINGLE_DELTA | KY_FEAT_SINGLE_ENV)) ? false : kind == KY_LIGHT_AREA);
+        return (feat & (KY_FEAT_SINGLE_AREA | KY_FEAT_SPHERE_LIGHTS)) ? true : ((feat & (KY_FEAT_SINGLE_DELTA | KY_FEAT_SINGLE_ENV)) ? false : kind == KY_LIGHT_AREA);
     }
     __device__ __forceinline__ bool is_delta(int kind) const {
-        return (feat & KY_FEAT_SINGLE_DELTA) ? true : ((feat & (KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_ENV)) ? false : (kind == KY_LIGHT_POINT || kind == KY_LIGHT_DIRECTION));
+        return (feat & KY_FEAT_SINGLE_DELTA) ? true : ((feat & (KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_ENV | KY_FEAT_SPHERE_LIGHTS)) ? false : (kind == KY_LIGHT_POINT || kind == KY_LIGHT_DIRECTION));
     }
     __device__ __forceinline__ bool is_env(int kind) const {
-        return (feat & KY_FEAT_SINGLE_ENV) ? true : ((feat & (KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_DELTA)) ? false : kind == KY_LIGHT_ENVIRONMENT);
+        return (feat & KY_FEAT_SINGLE_ENV) ? true : ((feat & (KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_DELTA | KY_FEAT_SPHERE_LIGHTS)) ? false : kind == KY_LIGHT_ENVIRONMENT);
     }
-    __device__ __forceinline__ bool may_have_env() const { return (feat & (KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_DELTA)) == 0; }
+    __device__ __forceinline__ bool may_have_env() const { return (feat & (KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_DELTA | KY_FEAT_SPHERE_LIGHTS)) == 0; }
+    __device__ __forceinline__ bool sphere_lights() const { return (feat & KY_FEAT_SPHERE_LIGHTS) != 0; }
 };
 
 // The per-workgroup LDS copy of the tables that are indexed per lane: hit[n_surfaces], mat[n_materials], light_color[n_lights][4].
@@ -485,7 +489,8 @@ KY_DEV bool sph_hit(const float4 c, f3 o, f3 d, float tmax, float& t_out) {
 
 // one shape given as a generic record (KAT entry point, light shapes re-intersected by pdf_direction)
 // `general` false: the caller knows the record is a parallelogram or a sphere (SceneRef::general)
-KY_DEV bool surf_hit(const DSurf& S, const DShapeFull* __restrict__ full, f3 o, f3 d, float tmax, float& t_out, bool general = true) {
+KY_DEV bool surf_hit(const DSurf& S, const DShapeFull* __restrict__ full, f3 o, f3 d, float tmax, float& t_out, bool general = true, bool sphere_only = false) {
+    if (sphere_only) return sph_hit(make_float4(S.f[0], S.f[1], S.f[2], S.f[3]), o, d, tmax, t_out);   // the caller knows (KY_FEAT_SPHERE_LIGHTS)
     if (S.kind == TK_PARALLELOGRAM)
         return par_hit(make_float4(S.f[0], S.f[1], S.f[2], S.f[3]), make_float4(S.f[4], S.f[5], S.f[6], S.f[7]), make_float4(S.f[8], S.f[9], S.f[10], S.f[11]), o, d, tmax, t_out);
     if (!general || S.kind == TK_SPHERE) return sph_hit(make_float4(S.f[0], S.f[1], S.f[2], S.f[3]), o, d, tmax, t_out);
@@ -643,14 +648,15 @@ struct Bsdf {
 };
 KY_DEV bool bsdf_is_delta(const Bsdf& B) { return B.lobe == LOBE_MIRROR || B.lobe == LOBE_GLASS; }
 
-KY_DEV int pick_lobe(const DMat& M, float lobe_random) {
+KY_DEV int pick_lobe(const DMat& M, float lobe_random, bool no_delta = false) {
+    if (no_delta) return (M.kind == KY_MATERIAL_PLASTIC && lobe_random < M.p_specular) ? LOBE_PHONG : LOBE_LAMBERT;   // KY_FEAT_NO_DELTA: a select of two constants
     if (M.kind == KY_MATERIAL_MIRROR) return LOBE_MIRROR;
     if (M.kind == KY_MATERIAL_GLASS) return LOBE_GLASS;
     if (M.kind == KY_MATERIAL_PLASTIC && lobe_random < M.p_specular) return LOBE_PHONG;   // 2663
     return LOBE_LAMBERT;
 }
 KY_DEV Bsdf make_bsdf_for_lobe(const DMat& M, int lobe) { return Bsdf{lobe, &M}; }
-KY_DEV Bsdf make_bsdf(const DMat& M, float lobe_random) { return Bsdf{pick_lobe(M, lobe_random), &M}; }
+KY_DEV Bsdf make_bsdf(const DMat& M, float lobe_random, bool no_delta = false) { return Bsdf{pick_lobe(M, lobe_random, no_delta), &M}; }
 
 // std::pow(base, exponent) of the Phong lobe (2499): a negative base is legal for an integral exponent
 KY_DEV float phong_pow(float base, float exponent, int exp_flags) {
@@ -918,10 +924,10 @@ KY_DEV f3 uniform_sphere_sample(float u0, float u1) {  // 761-769
 
 // shape_t::sample_position x4 (1144, 1225, 1307, 1404); normals are the stored (unit) ones
 KY_DEV void shape_sample_position(const DLight& L, float u0, float u1, f3& position, f3& normal, int feat = 0) {
-    if ((feat & KY_FEAT_RECT_LIGHTS) || L.shape_kind == KY_SHAPE_RECTANGLE) {
+    if ((feat & KY_FEAT_RECT_LIGHTS) || (!(feat & KY_FEAT_SPHERE_LIGHTS) && L.shape_kind == KY_SHAPE_RECTANGLE)) {
         position = ld3(L.p1) + ld3(L.e0) * u0 + ld3(L.e1) * u1;
         normal = ld3(L.n);
-    } else if (L.shape_kind == KY_SHAPE_SPHERE) {
+    } else if ((feat & KY_FEAT_SPHERE_LIGHTS) || L.shape_kind == KY_SHAPE_SPHERE) {
         const f3 dir = uniform_sphere_sample(u0, u1);
         position = ld3(L.p1) + L.radius * dir;
         normal = dir;
@@ -941,7 +947,7 @@ KY_DEV void shape_sample_position(const DLight& L, float u0, float u1, f3& posit
 
 // shape_t::sample_direction (1028-1051) and sphere_t::sample_direction (1419-1501)
 KY_DEV void shape_sample_direction(const DLight& L, f3 p, f3 p_normal, float u0, float u1, f3& lposition, f3& lnormal, float& pdf, int feat = 0) {
-    const bool sphere = (feat & KY_FEAT_RECT_LIGHTS) == 0 && L.shape_kind == KY_SHAPE_SPHERE;
+    const bool sphere = (feat & KY_FEAT_SPHERE_LIGHTS) ? true : ((feat & KY_FEAT_RECT_LIGHTS) == 0 && L.shape_kind == KY_SHAPE_SPHERE);
     const f3 c = ld3(L.p1);
     const float dc2 = length_sq(p - c);
     if (sphere && !(dc2 <= L.radius * L.radius)) {
@@ -983,7 +989,7 @@ KY_DEV void shape_sample_direction(const DLight& L, f3 p, f3 p_normal, float u0,
 
 // shape_t::pdf_direction (1055-1090) and sphere_t::pdf_direction (1503-1513)
 KY_DEV float shape_pdf_direction(const DLight& L, const DShapeFull* __restrict__ full, f3 p, f3 p_normal, f3 wi, bool general = true, int feat = 0) {
-    const bool sphere = (feat & KY_FEAT_RECT_LIGHTS) == 0 && L.shape_kind == KY_SHAPE_SPHERE;
+    const bool sphere = (feat & KY_FEAT_SPHERE_LIGHTS) ? true : ((feat & KY_FEAT_RECT_LIGHTS) == 0 && L.shape_kind == KY_SHAPE_SPHERE);
     const f3 c = ld3(L.p1);
     const float dc2 = length_sq(p - c);
     if (sphere && !(dc2 <= L.radius * L.radius)) {
@@ -1105,7 +1111,7 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 
         int c = -1;
         for (int k = 0; k < L.n_carriers; ++k) {
             float t;
-            const bool ok = act & surf_hit(S->all[L.carrier[k]], S->full, o, bs.wi, t_l, t, S.general);
+            const bool ok = act & surf_hit(S->all[L.carrier[k]], S->full, o, bs.wi, t_l, t, S.general, S.sphere_lights());
             t_l = ok ? t : t_l;
             c = ok ? L.carrier[k] : c;
         }
@@ -1280,10 +1286,11 @@ KY_DEV void sq_drain(SceneRef S, ShadowQueue& q) {
     q.n = 0;
 }
 
-// light-sampling half with the occlusion test deferred: by_emitter_mis (4035-4074) in the order sample -> BSDF value ->
+// light-sampling half with the occlusion test deferred: by_emitter (3933-3962, MIS = false) / by_emitter_mis (4035-4074) in the order sample -> BSDF value ->
 // weight -> [sampled shape's own hit] -> push; the reference's order (occlusion before the BSDF value) gives the same sum
 // because every factor is computed from the same inputs and a zero factor zeroes the term either way.
 // Wave-uniform call.  beta x weight = throughput x strategy weight x 1 / spp: what multiplies this estimate in the pixel's sum.
+template <bool MIS>
 KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, f3 wo, int li, float u0, float u1, bool active, f3 beta, float weight,
                                          unsigned tag, ShadowQueue& q) {
     const DLight& L = S->light[li];
@@ -1299,7 +1306,7 @@ KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, f3 wo, int
         bsdf_eval_pdf(v, wo, ls.wi, f, bsdf_pdf, abs_cos_i);
         const f3 f_cos = f * abs_cos_i;
         const bool delta_light = S.is_delta(L.kind);
-        const f3 Ld = delta_light ? (f_cos * ls.Li) * rcp(ls.pdf) : (f_cos * ls.Li) * (2.f * rcp(ls.pdf + bsdf_pdf));   // 4057 / 4070
+        const f3 Ld = (!MIS || delta_light) ? (f_cos * ls.Li) * rcp(ls.pdf) : (f_cos * ls.Li) * (2.f * rcp(ls.pdf + bsdf_pdf));   // 3956 / 4057 / 4070
         r.c = (Ld * beta) * weight;   // the product beta x weight is not kept in registers across the lights loop: three multiplies per light instead
         // scene_t::occluded(isect, ls.position), 3187-3201: the ray
         const f3 to = ls.position - v.position;
@@ -1308,11 +1315,11 @@ KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, f3 wo, int
         r.d = to * inv_d;
         r.tmax = d2 * inv_d - 2e-3f;
         r.o = offset_ray_origin(v.position, v.normal, r.d);
-        push = !(is_black(ls.Li) || ls.pdf <= 0) && !is_black(f_cos) && !(r.c.x == 0.f && r.c.y == 0.f && r.c.z == 0.f);
+        push = !(is_black(ls.Li) || (MIS ? ls.pdf <= 0 : ls.pdf == 0)) && !is_black(f_cos) && !(r.c.x == 0.f && r.c.y == 0.f && r.c.z == 0.f);
         // the sampled shape itself is the likeliest occluder (quirk 1): one test here saves the ray a full traversal
         if (S.is_area(L.kind) && L.sampled_is_surface) {   // wave-uniform
             float t;
-            if (surf_hit(L.isect, S->full, r.o, r.d, r.tmax, t, S.general)) push = false;
+            if (surf_hit(L.isect, S->full, r.o, r.d, r.tmax, t, S.general, S.sphere_lights())) push = false;
         }
     }
     sq_push(S, q, push, r);
@@ -1379,8 +1386,8 @@ KY_DEV f3 estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, 
 // strategy, 3900) and accumulate the estimators.
 // `decisions` (KAT tracing only; a null constant everywhere else, which removes the code): bit li = the BSDF half of light li's
 // estimate was non-black, bit 16 + li = its light half.
-// `sq` (the QUEUE instantiation of the lane engine, strategy both_mis): the light-sampling halves are not returned but pushed on
-// the wave's shadow-ray stack with beta x weight x 0.5 as their weight in the pixel's sum.
+// `sq` (the QUEUE instantiations of the lane engine: strategies both_mis, light_mis, light): the light-sampling halves are not returned but
+// pushed on the wave's shadow-ray stack with beta x weight (x 0.5 under both_mis) as their weight in the pixel's sum.
 template <bool DEBUG_SAMPLER>
 KY_DEV f3 sample_all_light(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, Sampler& smp, int strategy, bool active,
                            unsigned* decisions = nullptr, ShadowQueue* sq = nullptr, f3 beta = f3{0, 0, 0}, float weight = 0.f, unsigned tag = 0) {
@@ -1397,7 +1404,7 @@ KY_DEV f3 sample_all_light(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 
             f3 Ll = mk3(0, 0, 0);
             // random_light is drawn here, after the BSDF half: same stream position, two registers fewer across it
             if (active) { ul0 = sampler_next<DEBUG_SAMPLER>(smp); ul1 = sampler_next<DEBUG_SAMPLER>(smp); }
-            if (sq) estimate_by_emitter_deferred(S, v, wo, li, ul0, ul1, active, beta, weight * 0.5f, tag, *sq);
+            if (sq) estimate_by_emitter_deferred<true>(S, v, wo, li, ul0, ul1, active, beta, weight * 0.5f, tag, *sq);
             else if (active) Ll = estimate_by_emitter<true>(S, Lds, v, wo, li, ul0, ul1);
             Ld = Ld + (0.5f * Lb + 0.5f * Ll);
             if (decisions && li < 16) *decisions |= (is_black(Lb) ? 0u : 1u << li) | (is_black(Ll) ? 0u : 1u << (16 + li));
@@ -1409,9 +1416,11 @@ KY_DEV f3 sample_all_light(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 
         if (strategy == KY_DIRECT_BSDF_MIS) {
             Lb = estimate_by_bsdf<true>(S, Lds, v, wo, li, ub0, ub1, active);
         } else if (strategy == KY_DIRECT_LIGHT_MIS) {
-            if (active) Ll = estimate_by_emitter<true>(S, Lds, v, wo, li, ul0, ul1);
+            if (sq) estimate_by_emitter_deferred<true>(S, v, wo, li, ul0, ul1, active, beta, weight, tag, *sq);
+            else if (active) Ll = estimate_by_emitter<true>(S, Lds, v, wo, li, ul0, ul1);
         } else if (strategy == KY_DIRECT_LIGHT) {
-            if (active) Ll = estimate_by_emitter<false>(S, Lds, v, wo, li, ul0, ul1);
+            if (sq) estimate_by_emitter_deferred<false>(S, v, wo, li, ul0, ul1, active, beta, weight, tag, *sq);
+            else if (active) Ll = estimate_by_emitter<false>(S, Lds, v, wo, li, ul0, ul1);
         } else if (strategy == KY_DIRECT_BSDF) {
             const int lk = S->light[li].kind;
             if (!S.is_delta(lk)) {  // the third float2 is drawn after the delta test (3894-3900)
@@ -1524,7 +1533,7 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, SceneRef S, const LdsScene& Lds
         if (lobe < 0) {
             float lobe_u = 0.f;
             if (M.kind == KY_MATERIAL_PLASTIC) lobe_u = sampler_next<DEBUG_SAMPLER>(ps.smp);
-            v.bsdf = make_bsdf(M, lobe_u);
+            v.bsdf = make_bsdf(M, lobe_u, (S.feat & KY_FEAT_NO_DELTA) != 0);
         } else {
             v.bsdf = make_bsdf_for_lobe(M, lobe);
         }

@@ -210,11 +210,15 @@ static ShardConst make_shard(const ky_render_params* p) {
 #ifndef KY_WAVES_PER_EU_QUEUE
 #define KY_WAVES_PER_EU_QUEUE 5     // the instantiation with deferred shadow rays: 96 VGPRs (6 spilled) beat 80 (28 spilled) by 3.5 % since round 3
 #endif
+#ifndef KY_WAVES_PER_EU_QUEUE_FEAT
+#define KY_WAVES_PER_EU_QUEUE_FEAT 6   // ... with scene facts (the sphere-lights kernel): 80 VGPRs with 11 spilled beat 96 with 2 by 4 %
+#endif
 #ifndef KY_WAVES_PER_EU_GENERIC
 #define KY_WAVES_PER_EU_GENERIC 5   // strategy / integrator read at run time: more code alive at once, 96 VGPRs measured best
 #endif
 
 constexpr int KY_FEAT_CORNELL = KY_FEAT_SINGLE_AREA | KY_FEAT_RECT_LIGHTS | KY_FEAT_CARRIERS;   // what the Cornell-lamp instantiation assumes
+constexpr int KY_FEAT_VEACH = KY_FEAT_SPHERE_LIGHTS | KY_FEAT_CARRIERS | KY_FEAT_NO_DELTA;       // what the sphere-lights instantiation assumes (create_mis_scene)
 
 struct ItemSlot {  // one fetched work item, decoded once (wave-uniform) and read per lane
     int x0, y0, pix0, s_begin, s_end;
@@ -233,11 +237,12 @@ struct ItemSlot {  // one fetched work item, decoded once (wave-uniform) and rea
 // LARGE: the scene's per-lane tables live in dynamic shared memory sized by the scene (more than KY_LDS_SURFACES surfaces or
 // KY_LDS_MATERIALS materials; ky_device.hpp, LdsScene).
 template <bool DEBUG_SAMPLER, int STRATEGY, bool QUEUE = false, bool GENERAL = false, int FEAT = 0, int INTEGRATOR = KY_INTEGRATOR_PATH_TRACING_ITERATION, bool LARGE = false>
-__global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? KY_WAVES_PER_EU_QUEUE : KY_WAVES_PER_EU) : KY_WAVES_PER_EU_GENERIC) void render_kernel(const DScene* __restrict__ S_, RenderConst rc, ShardConst sh,
+__global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? (FEAT ? KY_WAVES_PER_EU_QUEUE_FEAT : KY_WAVES_PER_EU_QUEUE) : KY_WAVES_PER_EU) : KY_WAVES_PER_EU_GENERIC) void render_kernel(const DScene* __restrict__ S_, RenderConst rc, ShardConst sh,
                                                                      unsigned* __restrict__ counter, unsigned long long* __restrict__ accum,
                                                                      unsigned* __restrict__ flags, float4* __restrict__ queue_mem) {
-    static_assert(!QUEUE || (STRATEGY == KY_DIRECT_BOTH_MIS && INTEGRATOR == KY_INTEGRATOR_PATH_TRACING_ITERATION), "the deferred shadow rays are built into the iterative both_mis instantiation");
-    static_assert(FEAT == 0 || (STRATEGY >= 0 && !QUEUE && !GENERAL && !DEBUG_SAMPLER), "scene facts are instantiated for kernels with a fixed strategy only");
+    static_assert(!QUEUE || ((STRATEGY == KY_DIRECT_BOTH_MIS || STRATEGY == KY_DIRECT_LIGHT_MIS || STRATEGY == KY_DIRECT_LIGHT) && INTEGRATOR == KY_INTEGRATOR_PATH_TRACING_ITERATION),
+                  "the deferred shadow rays belong to the iterative integrator's strategies with a light-sampling half");
+    static_assert(FEAT == 0 || (STRATEGY >= 0 && !GENERAL && !DEBUG_SAMPLER), "scene facts are instantiated for kernels with a fixed strategy only");
     static_assert(STRATEGY >= 0 || INTEGRATOR == KY_INTEGRATOR_PATH_TRACING_ITERATION, "the run-time-dispatched kernel reads the integrator from rc");
     const SceneRef S{S_, GENERAL, FEAT, LARGE};
     __shared__ ItemSlot ring[4][KY_RING];
@@ -973,6 +978,15 @@ static int pack_scene(const ky_scene* in, DScene* out) {
         for (int i = 0; i < in->light_count; ++i)
             if (in->lights[i].kind == KY_LIGHT_AREA) rect = rect && in->shapes[in->lights[i].shape].kind == KY_SHAPE_RECTANGLE;
         if (rect) out->feat |= KY_FEAT_RECT_LIGHTS;
+        bool spheres = in->light_count > 0 && in->environment_light < 0;   // KY_FEAT_SPHERE_LIGHTS; the carriers are checked below
+        for (int i = 0; i < in->light_count; ++i)
+            spheres = spheres && in->lights[i].kind == KY_LIGHT_AREA && in->shapes[in->lights[i].shape].kind == KY_SHAPE_SPHERE;
+        for (int i = 0; i < in->surface_count; ++i)
+            if (in->surfaces[i].area_light >= 0) spheres = spheres && in->shapes[in->surfaces[i].shape].kind == KY_SHAPE_SPHERE;
+        if (spheres) out->feat |= KY_FEAT_SPHERE_LIGHTS;
+        bool no_delta = true;
+        for (int i = 0; i < in->material_count; ++i) no_delta = no_delta && in->materials[i].kind != KY_MATERIAL_MIRROR && in->materials[i].kind != KY_MATERIAL_GLASS;
+        if (no_delta) out->feat |= KY_FEAT_NO_DELTA;
     }
     if (non.ts_light >= 0) {
         build_trav(out->occ_front, [&](int i) { return non.wall[i] != 0 || non.ts_behind[i] != 0; });
@@ -1335,13 +1349,22 @@ static const Variant g_variants[] = {
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL, IT),                  // one rectangle area light: configs[1], [4]
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_DELTA, IT),             // one point / directional light
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_ENV, IT),               // one environment light
-    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, 0, IT),                                 // several lights: deferred shadow rays (configs[2])
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, KY_FEAT_VEACH, IT),                     // several sphere lights, no mirror / glass: configs[2]
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, 0, IT),                                 // several lights: deferred shadow rays
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, 0, IT),
     // the iterative integrator, the other five strategies (render_direct_sample_enum 4779, render_mis_scene 4878)
+    KY_VARIANT(false, KY_DIRECT_BSDF, false, false, KY_FEAT_VEACH, IT),                        // render_mis_scene's other strategies on its sphere lights
+    KY_VARIANT(false, KY_DIRECT_LIGHT, true, false, KY_FEAT_VEACH, IT),
+    KY_VARIANT(false, KY_DIRECT_LIGHT, false, false, KY_FEAT_VEACH, IT),
+    KY_VARIANT(false, KY_DIRECT_BSDF_MIS, false, false, KY_FEAT_VEACH, IT),
+    KY_VARIANT(false, KY_DIRECT_LIGHT_MIS, true, false, KY_FEAT_VEACH, IT),
+    KY_VARIANT(false, KY_DIRECT_LIGHT_MIS, false, false, KY_FEAT_VEACH, IT),
     KY_VARIANT(false, KY_DIRECT_BSDF, false, false, KY_FEAT_CORNELL, IT),
     KY_VARIANT(false, KY_DIRECT_BSDF_MIS, false, false, KY_FEAT_CORNELL, IT),
     KY_VARIANT(false, KY_DIRECT_IDLE, false, false, 0, IT),
     KY_VARIANT(false, KY_DIRECT_BSDF, false, false, 0, IT),
+    KY_VARIANT(false, KY_DIRECT_LIGHT, true, false, 0, IT),                                    // several lights: deferred shadow rays
+    KY_VARIANT(false, KY_DIRECT_LIGHT_MIS, true, false, 0, IT),
     KY_VARIANT(false, KY_DIRECT_LIGHT, false, false, 0, IT),
     KY_VARIANT(false, KY_DIRECT_BSDF_MIS, false, false, 0, IT),
     KY_VARIANT(false, KY_DIRECT_LIGHT_MIS, false, false, 0, IT),

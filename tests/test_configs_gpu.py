@@ -309,6 +309,10 @@ def test_specialised_instantiations_change_nothing(A, api, O):
                     # an instantiation by scene facts (the Cornell lamp): the same expressions, but with code removed around them the
                     # compiler contracts a few multiply-adds differently -- the last bit of some pixels (measured: 6e-8 on 10 % of them)
                     assert scene is not room and np.abs(on - off).max() <= 1.2e-7, (kernel_on, depth, np.abs(on - off).max())
+                elif "deferred" in kernel_on and "deferred" not in kernel_off:
+                    # light / light_mis on the two-light room: the strategy's kernel defers its shadow rays, the run-time-dispatched one does
+                    # not -- the same terms, added to a pixel in fixed point as they resolve instead of in float per vertex
+                    assert np.abs(on - off).max() <= 2e-6, (kernel_on, depth, np.abs(on - off).max())
                 else:
                     assert np.array_equal(on, off), (strategy, depth)
         # round 3: the other single-light facts and the other integrators' own kernels -- which instantiation runs, and that it changes nothing

@@ -767,22 +767,30 @@ KY_DEV void bsdf_eval_pdf(const Vertex& v, f3 wo, f3 wi, f3& f, float& pdf, floa
     const Bsdf& B = v.bsdf;
     const float cos_o = dot(v.normal, wo), cos_i = dot(v.normal, wi);   // wo.z, wi.z of the shading frame
     abs_cos_i = fabsf(cos_i);
-    f = mk3(0, 0, 0);
-    pdf = 0.f;
     const bool same = cos_o * cos_i > 0;  // same_hemisphere, 1921
-    if (B.lobe == LOBE_LAMBERT) {
-        if (same) { f = ld3(B.m->c0) * K_INV_PI; pdf = abs_cos_i * K_INV_PI; }
-    } else if (B.lobe == LOBE_PHONG) {
+    // Two arms that both assign everything, then selects: a default of zero overwritten under nested conditions costs a v_mov per
+    // register and nesting level in every caller (the listing of the deferred estimator had four groups of four).
+    f3 col;
+    float scale, p;
+    if (B.lobe == LOBE_PHONG) {
         const float cos_alpha = dot(vertex_basis_c(v), wi);   // dot(wr, wi), 2497
         // eval: cos_alpha is not clamped (a negative base with an even integral exponent is positive);
         // pdf: clamped at 0, no hemisphere test (quirk 6)
         const float exponent = B.m->exponent;
         const float pe = phong_pow(cos_alpha, exponent, B.m->exp_flags);
         const float p0 = exponent == 0.f ? 1.f : (exponent > 0.f ? 0.f : K_INF);
-        const float pp = cos_alpha > 0.f ? pe : p0;
-        if (same) f = (ld3(B.m->cs) * B.m->inv_eta) * pe;   // (exponent + 2) / 2 pi
-        pdf = pp * B.m->phong_pdf_norm;                      // (exponent + 1) / 2 pi
+        col = ld3(B.m->cs) * B.m->inv_eta;                          // (exponent + 2) / 2 pi
+        scale = same ? pe : 0.f;
+        p = (cos_alpha > 0.f ? pe : p0) * B.m->phong_pdf_norm;      // (exponent + 1) / 2 pi
+    } else {   // Lambert; the delta lobes (eval 0, pdf 0: 2289-2290, 2352-2353) pass through and are zeroed below
+        col = ld3(B.m->c0);
+        scale = same ? K_INV_PI : 0.f;
+        p = same ? abs_cos_i * K_INV_PI : 0.f;
     }
+    const bool nondelta = !bsdf_is_delta(B);
+    scale = nondelta ? scale : 0.f;
+    f = col * scale;
+    pdf = nondelta ? p : 0.f;
 }
 
 // The direction half of sample_ for the two non-delta lobes, world space (their value and pdf are eval_ / pdf_ of that
@@ -1091,11 +1099,11 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 
     if (S.is_delta(L.kind)) return Ld;  // light.is_delta(), 3894 / 3977 (wave-uniform)
     BsdfSample bs;
     // what `live` guards: read at the end only for lanes whose sample counts (and, in the query loop, through __shfl from such lanes)
-    f3 f_cos = any3(), o = any3(), Li = mk3(0, 0, 0);
+    f3 f_cos = any3(), o = any3(), Li = any3();
     bs.wi = any3();
     bs.f = any3();
     bs.pdf = any_f();
-    bool live = false;
+    bool live = false, lit = false;   // live: the sample's value and pdf count; lit: it sees light (Li is set and not black)
     const bool fast = S.is_area(L.kind) && ((S.feat & KY_FEAT_CARRIERS) || (L.n_carriers >= 0 && S->n_gen == 0));  // wave-uniform
     if (fast) {
         // Only the DIRECTION is sampled up front; the BSDF value and pdf (a pow for the Phong lobe) are evaluated for the few
@@ -1115,11 +1123,13 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 
             t_l = ok ? t : t_l;
             c = ok ? L.carrier[k] : c;
         }
-        bool pending = c >= 0;
+        // every carrier carries THIS light (surface_t::area_light == &light, 3994): what it emits is the light's radiance, on the side its
+        // normal faces (areal_radiance, 2957-2960) -- a wave-uniform colour, no per-lane look-up
+        Li = ld3(L.color);
+        bool pending = c >= 0 && !is_black(Li);
         if (pending) {
             const f3 hp = o + t_l * bs.wi;
-            Li = surface_emission(Lds, c, hit_normal(Lds.hit[c], hp, bs.wi), -bs.wi);
-            pending = !is_black(Li);
+            pending = dot(hit_normal(Lds.hit[c], hp, bs.wi), bs.wi) < 0;
         }
         if (pending) {  // rare: now the sample's value and pdf (3979-3987)
             float abs_cos_i;
@@ -1155,7 +1165,7 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 
                 if (lane == src) blocked = any;
             }
         }
-        if (blocked) Li = mk3(0, 0, 0);
+        lit = pending && !blocked;   // (pending implies live here)
     } else {
         if (active) {
             bs = bsdf_sample(v, wo, u0, u1);
@@ -1166,6 +1176,7 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 
         float t = K_INF;
         KY_PROBE(2);
         const int hs = live ? trace_nearest(S, o, bs.wi, t) : -1;
+        Li = mk3(0, 0, 0);
         if (hs >= 0) {
             if (Lds.hit[hs].area_light == li) {  // 3912 / 3994
                 const f3 hp = o + t * bs.wi;
@@ -1174,8 +1185,9 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 
         } else if (live && S.is_env(L.kind)) {
             Li = ld3(L.color);  // light.environmental_radiance(ray), 3918 / 4000
         }
+        lit = live && !is_black(Li);
     }
-    if (live && !is_black(Li)) {
+    if (lit) {
         if (MIS) {
             const float light_pdf = light_pdf_Li(L, S->full, v.position, v.normal, bs.wi, S.general, S.feat);
             if (light_pdf > 0) Ld = (f_cos * Li) * (2.f * rcp(bs.pdf + light_pdf));  // 4028

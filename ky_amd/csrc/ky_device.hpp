@@ -1092,8 +1092,14 @@ KY_DEV f3 surface_emission(const LdsScene& Lds, int surface, f3 normal, f3 wo) {
 // are resolved SURFACE-parallel: the query ray is broadcast (v_readlane) and lane j tests surface j (records in LDS),
 // one ballot per query.  With more than KY_TRANSPOSE_MAX queries in the wave, or for scenes the fast path does not
 // cover (general quads / triangles / disks, environment lights, many carriers), the ordinary traversal runs instead.
+struct ShadowQueue;
+struct SqRay;
+KY_DEV void sq_push_bsdf_query(SceneRef S, ShadowQueue& q, bool push, f3 o, f3 d, float tmax, f3 c, unsigned tag);
+// `sq` (QUEUE instantiations): the occlusion queries of (b) are not resolved here but join the wave's stack of deferred shadow rays, with
+// the estimate x beta x weight as the contribution; the function then returns black.
 template <bool MIS>
-KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, int li, float u0, float u1, bool active) {
+KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, int li, float u0, float u1, bool active,
+                           ShadowQueue* sq = nullptr, f3 beta = f3{0, 0, 0}, float weight = 0.f, unsigned tag = 0) {
     const DLight& L = S->light[li];
     f3 Ld = mk3(0, 0, 0);
     if (S.is_delta(L.kind)) return Ld;  // light.is_delta(), 3894 / 3977 (wave-uniform)
@@ -1137,6 +1143,20 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 
             f_cos = bs.f * abs_cos_i;
             live = !(is_black(f_cos) || (MIS ? (bs.pdf <= 0) : (bs.pdf == 0)));
             pending = live;
+        }
+        if (sq) {   // (b) deferred: a ray that ends just short of the carrier (its own hit, a few ulp around t_l, stays out of the interval)
+            f3 c = any3();
+            if (pending) {
+                f3 Lq = (f_cos * Li) * rcp(bs.pdf);  // 3924
+                if (MIS) {
+                    const float light_pdf = light_pdf_Li(L, S->full, v.position, v.normal, bs.wi, S.general, S.feat);
+                    Lq = light_pdf > 0 ? (f_cos * Li) * (2.f * rcp(bs.pdf + light_pdf)) : mk3(0, 0, 0);  // 4028
+                }
+                c = (Lq * beta) * weight;
+                pending = !(c.x == 0.f && c.y == 0.f && c.z == 0.f);
+            }
+            sq_push_bsdf_query(S, *sq, pending, o, bs.wi, t_l * (1.f - 1e-6f), c, tag);
+            return Ld;
         }
         // (b) is any surface in front of the carrier?  (the carrier itself reproduces t_l exactly, and t < t_l is strict)
         unsigned long long queries = __ballot(pending);
@@ -1290,6 +1310,9 @@ KY_DEV void sq_push(SceneRef S, ShadowQueue& q, bool push, SqRay r) {
     q.n = k - take;
     sq_trace(S, q, r);
 }
+KY_DEV void sq_push_bsdf_query(SceneRef S, ShadowQueue& q, bool push, f3 o, f3 d, float tmax, f3 c, unsigned tag) {
+    sq_push(S, q, push, SqRay{o, d, c, tmax, tag});
+}
 // end of the kernel: what is left on the stack (wave-uniform call)
 KY_DEV void sq_drain(SceneRef S, ShadowQueue& q) {
     const int lane = (int)__lane_id();
@@ -1411,7 +1434,7 @@ KY_DEV f3 sample_all_light(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 
         if (active) { ub0 = sampler_next<DEBUG_SAMPLER>(smp); ub1 = sampler_next<DEBUG_SAMPLER>(smp); }
         if (strategy == KY_DIRECT_BOTH_MIS) {  // 4076-4088
             KY_CLK(3);
-            const f3 Lb = estimate_by_bsdf<true>(S, Lds, v, wo, li, ub0, ub1, active);   // draws nothing itself
+            const f3 Lb = estimate_by_bsdf<true>(S, Lds, v, wo, li, ub0, ub1, active, sq, beta, weight * 0.5f, tag);   // draws nothing itself
             KY_CLK(4);
             f3 Ll = mk3(0, 0, 0);
             // random_light is drawn here, after the BSDF half: same stream position, two registers fewer across it

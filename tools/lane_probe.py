@@ -4,7 +4,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from ky_amd import api, _abi as A
-names = {0: "path trace", 1: "NEE entered", 2: "MIS bsdf trace", 3: "light sample", 4: "shadow trace", 5: "unoccluded eval", 6: "post-hit (vertex)", 7: "continuation sample"}
+names = {0: "path trace", 1: "NEE entered", 2: "MIS bsdf trace", 3: "light sample", 4: "shadow trace", 5: "unoccluded eval", 6: "post-hit (vertex)", 7: "continuation sample", 8: "by_bsdf query (surface-parallel)", 9: "by_bsdf fast path calls", 10: "by_bsdf pending lanes"}
 which = sys.argv[1] if len(sys.argv) > 1 else "cornell"
 scene = api.cornell_box_scene(A.CB_DEFAULT_SCENE, 512, 384) if which == "cornell" else api.mis_scene(640, 360)
 W, H = (512, 384) if which == "cornell" else (640, 360)

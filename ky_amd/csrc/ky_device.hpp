@@ -1092,6 +1092,15 @@ KY_DEV f3 surface_emission(const LdsScene& Lds, int surface, f3 normal, f3 wo) {
 // are resolved SURFACE-parallel: the query ray is broadcast (v_readlane) and lane j tests surface j (records in LDS),
 // one ballot per query.  With more than KY_TRANSPOSE_MAX queries in the wave, or for scenes the fast path does not
 // cover (general quads / triangles / disks, environment lights, many carriers), the ordinary traversal runs instead.
+// path_tracing_recursion_t's emitter look-up at a specular vertex (4341-4349) needs the nearest hit along one more ray -- for exactly the lanes
+// that take no part in the vertex's direct lighting.  In that integrator's own instantiations the look-up RIDES ALONG with the first
+// nearest-hit or shadow traversal the light loop runs for the other lanes: one traversal with fuller lanes instead of two sparse ones.
+struct RideAlong {
+    bool want;   // this lane has a ray that nobody has traced yet
+    f3 o, d;
+    float t;     // out: distance of the nearest hit
+    int hs;      // out: its (sorted) surface index, -1 on a miss
+};
 struct ShadowQueue;
 struct SqRay;
 KY_DEV void sq_push_bsdf_query(SceneRef S, ShadowQueue& q, bool push, f3 o, f3 d, float tmax, f3 c, unsigned tag);
@@ -1099,7 +1108,7 @@ KY_DEV void sq_push_bsdf_query(SceneRef S, ShadowQueue& q, bool push, f3 o, f3 d
 // the estimate x beta x weight as the contribution; the function then returns black.
 template <bool MIS>
 KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, int li, float u0, float u1, bool active,
-                           ShadowQueue* sq = nullptr, f3 beta = f3{0, 0, 0}, float weight = 0.f, unsigned tag = 0) {
+                           ShadowQueue* sq = nullptr, f3 beta = f3{0, 0, 0}, float weight = 0.f, unsigned tag = 0, RideAlong* ra = nullptr) {
     const DLight& L = S->light[li];
     f3 Ld = mk3(0, 0, 0);
     if (S.is_delta(L.kind)) return Ld;  // light.is_delta(), 3894 / 3977 (wave-uniform)
@@ -1195,7 +1204,17 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 
         }
         float t = K_INF;
         KY_PROBE(2);
-        const int hs = live ? trace_nearest(S, o, bs.wi, t) : -1;
+        int hs = -1;
+        if (ra) {   // (no lane is both live and riding: riders hold specular vertices, which sample no light)
+            const bool ride = ra->want;
+            f3 to = o, td = bs.wi;
+            if (ride) { to = ra->o; td = ra->d; }
+            const int h = (live || ride) ? trace_nearest(S, to, td, t) : -1;
+            if (ride) { ra->hs = h; ra->t = t; ra->want = false; }
+            else hs = h;
+        } else {
+            hs = live ? trace_nearest(S, o, bs.wi, t) : -1;
+        }
         Li = mk3(0, 0, 0);
         if (hs >= 0) {
             if (Lds.hit[hs].area_light == li) {  // 3912 / 3994
@@ -1417,6 +1436,54 @@ KY_DEV f3 estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, 
     return Ld;
 }
 
+// the same estimator as a WAVE-UNIFORM call whose shadow traversal also serves the lanes of `ra` (RideAlong) that still wait: when there are any,
+// shadow rays and look-up rays go through one nearest-hit scan of the whole scene (a shadow ray is occluded iff that scan finds a hit
+// inside its interval: the occluder tables are subsets that decide the same, tests/test_occluders.py).
+template <bool MIS>
+KY_DEV f3 estimate_by_emitter_ride(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, int li, float u0, float u1, bool active, RideAlong& ra) {
+    const DLight& L = S->light[li];
+    f3 Ld = mk3(0, 0, 0);
+    LightSample ls{any3(), any3(), any3(), any_f()};
+    bool dead = true;
+    if (active) {
+        ls = light_sample_Li(L, v.position, v.normal, u0, u1, S.feat);
+        dead = is_black(ls.Li) || (MIS ? (ls.pdf <= 0) : (ls.pdf == 0));
+    }
+    f3 o = any3(), dir = any3();
+    float tmax = any_f();
+    if (!dead) {  // scene_t::occluded(isect, ls.position), 3187-3201
+        const f3 to = ls.position - v.position;
+        const float d2 = length_sq(to);
+        const float inv_d = rsq(d2);
+        dir = to * inv_d;
+        tmax = d2 * inv_d - 2e-3f;
+        o = offset_ray_origin(v.position, v.normal, dir);
+    }
+    bool occ = true;
+    const bool ride = ra.want;
+    if (__any(ride)) {
+        if (ride) { o = ra.o; dir = ra.d; tmax = K_INF; }
+        int hs = -1;
+        if (ride || !dead) hs = trace_nearest(S, o, dir, tmax);
+        occ = hs >= 0;
+        if (ride) { ra.hs = hs; ra.t = tmax; ra.want = false; }
+    } else if (!dead) {
+        occ = light_sample_occluded(S, li, o, dir, tmax);
+    }
+    if (!dead && !occ) {
+        f3 f;
+        float bsdf_pdf, abs_cos_i;
+        bsdf_eval_pdf(v, wo, ls.wi, f, bsdf_pdf, abs_cos_i);
+        const f3 f_cos = f * abs_cos_i;
+        if (!is_black(f_cos)) {
+            const bool delta_light = S.is_delta(L.kind);
+            if (!MIS || delta_light) Ld = (f_cos * ls.Li) * rcp(ls.pdf);          // 3956 / 4057
+            else Ld = (f_cos * ls.Li) * (2.f * rcp(ls.pdf + bsdf_pdf));            // 4070
+        }
+    }
+    return Ld;
+}
+
 // sample_all_light, 3834-3872.  Wave-uniform call; `active` lanes draw 4 numbers per light (+2 for the plain bsdf
 // strategy, 3900) and accumulate the estimators.
 // `decisions` (KAT tracing only; a null constant everywhere else, which removes the code): bit li = the BSDF half of light li's
@@ -1425,7 +1492,8 @@ KY_DEV f3 estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, 
 // pushed on the wave's shadow-ray stack with beta x weight (x 0.5 under both_mis) as their weight in the pixel's sum.
 template <bool DEBUG_SAMPLER>
 KY_DEV f3 sample_all_light(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, Sampler& smp, int strategy, bool active,
-                           unsigned* decisions = nullptr, ShadowQueue* sq = nullptr, f3 beta = f3{0, 0, 0}, float weight = 0.f, unsigned tag = 0) {
+                           unsigned* decisions = nullptr, ShadowQueue* sq = nullptr, f3 beta = f3{0, 0, 0}, float weight = 0.f, unsigned tag = 0,
+                           RideAlong* ra = nullptr) {
     f3 Ld = mk3(0, 0, 0);
     const int nl = S.single_light() ? 1 : S->n_lights;
     for (int li = 0; li < nl; ++li) {
@@ -1434,12 +1502,13 @@ KY_DEV f3 sample_all_light(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 
         if (active) { ub0 = sampler_next<DEBUG_SAMPLER>(smp); ub1 = sampler_next<DEBUG_SAMPLER>(smp); }
         if (strategy == KY_DIRECT_BOTH_MIS) {  // 4076-4088
             KY_CLK(3);
-            const f3 Lb = estimate_by_bsdf<true>(S, Lds, v, wo, li, ub0, ub1, active, sq, beta, weight * 0.5f, tag);   // draws nothing itself
+            const f3 Lb = estimate_by_bsdf<true>(S, Lds, v, wo, li, ub0, ub1, active, sq, beta, weight * 0.5f, tag, ra);   // draws nothing itself
             KY_CLK(4);
             f3 Ll = mk3(0, 0, 0);
             // random_light is drawn here, after the BSDF half: same stream position, two registers fewer across it
             if (active) { ul0 = sampler_next<DEBUG_SAMPLER>(smp); ul1 = sampler_next<DEBUG_SAMPLER>(smp); }
             if (sq) estimate_by_emitter_deferred<true>(S, v, wo, li, ul0, ul1, active, beta, weight * 0.5f, tag, *sq);
+            else if (ra) Ll = estimate_by_emitter_ride<true>(S, Lds, v, wo, li, ul0, ul1, active, *ra);
             else if (active) Ll = estimate_by_emitter<true>(S, Lds, v, wo, li, ul0, ul1);
             Ld = Ld + (0.5f * Lb + 0.5f * Ll);
             if (decisions && li < 16) *decisions |= (is_black(Lb) ? 0u : 1u << li) | (is_black(Ll) ? 0u : 1u << (16 + li));
@@ -1560,7 +1629,7 @@ struct VertexTrace {
 // `tr` is a null constant everywhere but in the trace KAT kernel, which removes the tracing code.
 template <bool DEBUG_SAMPLER>
 KY_DEV bool path_shade(PathState& ps, Vertex& v, SceneRef S, const LdsScene& Lds, const RenderConst& rc, bool active,
-                       int lobe = -1, VertexTrace* tr = nullptr, ShadowQueue* sq = nullptr, unsigned tag = 0) {
+                       int lobe = -1, VertexTrace* tr = nullptr, ShadowQueue* sq = nullptr, unsigned tag = 0, bool ride_along = false) {
     if (active) {
         // material->scattering(isect) for the nearest hit (3083); only plastic draws a lobe number (2663).
         // lobe >= 0: the caller has already made that draw (path_pick_lobe).
@@ -1596,8 +1665,25 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, SceneRef S, const LdsScene& Lds
     const bool nee = active && !delta;  // 4571
     KY_PROBE(6);
     unsigned decisions = 0;
+    // path_tracing_recursion_t, specular vertex (4341-4349): look the emitter up along a sampled direction, from the un-offset hit point
+    // (the continuation below draws a NEW sample).  `ride_along` (that integrator's own instantiations): the specular lanes -- which draw
+    // nothing in the light loop -- sample the direction here and let the loop's first traversal carry the ray (RideAlong).
+    const bool riding = recursion && ride_along;
+    RideAlong ra{false, any3(), any3(), K_INF, -1};
+    f3 es_f = any3();
+    float es_k = any_f();
+    if (riding && active && delta) {
+        const float e0 = sampler_next<DEBUG_SAMPLER>(ps.smp), e1 = sampler_next<DEBUG_SAMPLER>(ps.smp);
+        const BsdfSample es = bsdf_sample(v, wo, e0, e1);
+        ra.want = true;
+        ra.o = v.position;
+        ra.d = es.wi;
+        es_f = es.f;
+        es_k = fabsf(dot(es.wi, v.normal)) / es.pdf;
+    }
     if (!simple) {  // simple_path_tracing_recursion_t samples the BSDF only
-        const f3 Ld = sample_all_light<DEBUG_SAMPLER>(S, Lds, v, wo, ps.smp, rc.strategy, nee, tr ? &decisions : nullptr, sq, ps.beta, rc.inv_spp, tag);  // 4575 / 4337 / 4458
+        const f3 Ld = sample_all_light<DEBUG_SAMPLER>(S, Lds, v, wo, ps.smp, rc.strategy, nee, tr ? &decisions : nullptr, sq, ps.beta, rc.inv_spp, tag,
+                                                      riding ? &ra : nullptr);  // 4575 / 4337 / 4458
         if (nee) ps.Lo = ps.Lo + ps.beta * Ld;
     }
     KY_CLK(8);
@@ -1605,20 +1691,27 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, SceneRef S, const LdsScene& Lds
     if (!active) return false;
 
     if (recursion && delta) {
-        // path_tracing_recursion_t, specular vertex (4341-4349): look the emitter up along a sampled direction, from the
-        // un-offset hit point; the continuation below draws a NEW sample
-        const float e0 = sampler_next<DEBUG_SAMPLER>(ps.smp), e1 = sampler_next<DEBUG_SAMPLER>(ps.smp);
-        const BsdfSample es = bsdf_sample(v, wo, e0, e1);
-        float t = K_INF;
-        const int hs = trace_nearest(S, v.position, es.wi, t);
-        f3 Le = (S.may_have_env() && S->env_light >= 0) ? ld3(S->light[S->env_light].color) : mk3(0, 0, 0);
-        if (hs >= 0) {
-            const f3 hp = v.position + t * es.wi;
-            Le = surface_emission(Lds, hs, hit_normal(Lds.hit[hs], hp, es.wi), -es.wi);
-            // scene->intersect builds the hit's BSDF: a plastic surface draws its lobe number (2663)
-            if (Lds.mat[Lds.hit[hs].material].kind == KY_MATERIAL_PLASTIC) (void)sampler_next<DEBUG_SAMPLER>(ps.smp);
+        if (!riding) {
+            const float e0 = sampler_next<DEBUG_SAMPLER>(ps.smp), e1 = sampler_next<DEBUG_SAMPLER>(ps.smp);
+            const BsdfSample es = bsdf_sample(v, wo, e0, e1);
+            ra.o = v.position;
+            ra.d = es.wi;
+            ra.want = true;
+            es_f = es.f;
+            es_k = fabsf(dot(es.wi, v.normal)) / es.pdf;
         }
-        ps.Lo = ps.Lo + ps.beta * ((es.f * Le) * (fabsf(dot(es.wi, v.normal)) / es.pdf));  // 0/0 = NaN on total internal reflection, as in 4349
+        if (ra.want) {   // nobody carried the ray (no light loop, or none of its traversals ran)
+            ra.t = K_INF;
+            ra.hs = trace_nearest(S, ra.o, ra.d, ra.t);
+        }
+        f3 Le = (S.may_have_env() && S->env_light >= 0) ? ld3(S->light[S->env_light].color) : mk3(0, 0, 0);
+        if (ra.hs >= 0) {
+            const f3 hp = ra.o + ra.t * ra.d;
+            Le = surface_emission(Lds, ra.hs, hit_normal(Lds.hit[ra.hs], hp, ra.d), -ra.d);
+            // scene->intersect builds the hit's BSDF: a plastic surface draws its lobe number (2663)
+            if (Lds.mat[Lds.hit[ra.hs].material].kind == KY_MATERIAL_PLASTIC) (void)sampler_next<DEBUG_SAMPLER>(ps.smp);
+        }
+        ps.Lo = ps.Lo + ps.beta * ((es_f * Le) * es_k);  // 0/0 = NaN on total internal reflection, as in 4349
     }
 
     // sample BSDF to get the new path direction, 4586 / 4213 / 4383 / 4495

@@ -392,7 +392,8 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? (FEAT ? KY_WAVES_PER_
         if (QUEUE) tag = ((unsigned)c_pix[tid] << 6) | (unsigned)lane;
         // ---- (3) shade the vertex: direct lighting, continuation ----
         {
-            const bool cont = path_shade<DEBUG_SAMPLER>(ps, v, S, Lds, rc, have_vertex, -1, nullptr, QUEUE ? &sq : nullptr, tag);  // wave-uniform call
+            const bool cont = path_shade<DEBUG_SAMPLER>(ps, v, S, Lds, rc, have_vertex, -1, nullptr, QUEUE ? &sq : nullptr, tag,
+                                                        STRATEGY >= 0 && INTEGRATOR == KY_INTEGRATOR_PATH_TRACING_RECURSION);  // wave-uniform call
             if (have_vertex && !cont) {
                 c_lsum[0][tid] += ps.Lo.x * rc.inv_spp; c_lsum[1][tid] += ps.Lo.y * rc.inv_spp; c_lsum[2][tid] += ps.Lo.z * rc.inv_spp;
                 alive = false;

@@ -118,3 +118,43 @@ def test_film_writers(A, api, tmp_path):
     head = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 2 +X 4\n"
     assert raw.startswith(head) and len(raw) == len(head) + 8 * 4
     assert list(raw[len(head):len(head) + 4]) == [128, 0, 0, 129]  # (1,0,0): mantissa 0.5*256, exponent 1+128
+
+
+def test_written_files_decode_back_to_the_film(A, api, tmp_path):
+    """The writers checked from the READER's side, with no restatement of ky.cpp in between.  HDR: the Radiance format's published decoding
+    (value = byte * 2^(exponent - 128 - 8), the formula ky.cpp:1762-1765 quotes) applied to the product's file must bracket the film:
+    the writer truncates (1772-1774), so byte * f <= value < (byte + 1) * f.  PPM: every token of the P3 body is the gamma code whose
+    reference-produced values tests/golden/rewrite_kat.npz holds (gamma_in / gamma_out: GammaEncoding of smallpt_rewrite.cpp:494 == ky.cpp:1548)."""
+    rng = np.random.default_rng(11)
+    film = (rng.uniform(0, 1, (7, 9, 3)) ** 6 * 300).astype(np.float32)
+    film[0, 0] = 0
+    film[1, 1] = [1e-35, 0, 0]      # below the writer's 1e-32 threshold: stored as four zero bytes
+    film[2, 2] = [5.0, 1e-4, 0.0]   # one component dominates: the others lose their bits, not their bracket
+    f = str(tmp_path / "d.hdr")
+    api.store_image(f, film, "hdr")
+    raw = open(f, "rb").read()
+    head, _, body = raw.partition(b"\n\n")
+    assert head.split(b"\n")[0] == b"#?RADIANCE"
+    res, _, pix = body.partition(b"\n")
+    tok = res.split()
+    assert tok[0] == b"-Y" and tok[2] == b"+X"
+    h, w = int(tok[1]), int(tok[3])
+    assert (h, w) == film.shape[:2]
+    q = np.frombuffer(pix, np.uint8).reshape(h, w, 4).astype(np.float64)
+    scale = np.ldexp(1.0, q[..., 3].astype(np.int64) - 136)[..., None]
+    lo, hi = q[..., :3] * scale, (q[..., :3] + 1) * scale
+    stored = q[..., 3] > 0
+    v = film.astype(np.float64)
+    assert np.all(lo[stored] <= v[stored] * (1 + 1e-6)) and np.all(v[stored] < hi[stored] * (1 + 1e-6))
+    assert np.all(q[~stored] == 0) and np.all(v[~stored].max(axis=-1) < 1e-32)
+    assert stored.sum() == h * w - 2
+
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rewrite_kat.npz"))
+    gin, gout = G["gamma_in"], G["gamma_out"]
+    n = (len(gin) // 3) * 3
+    strip = gin[:n].reshape(1, n // 3, 3)
+    f = str(tmp_path / "d.ppm")
+    api.store_image(f, strip, "ppm")
+    words = open(f).read().split()
+    assert words[:4] == ["P3", str(n // 3), "1", "255"]
+    assert np.array_equal(np.array(words[4:], np.int64), gout[:n].astype(np.int64))

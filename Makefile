@@ -7,7 +7,7 @@ CXX      ?= g++
 ROCM     ?= /opt/rocm
 # -no-hip-rt: libkyhip.so does NOT pin a HIP runtime.  A process must hold exactly one runtime: Python callers get the
 # one torch bundles (ky_amd/_abi.py loads it RTLD_GLOBAL first), C++ callers link $(ROCM)/lib/libamdhip64.so themselves.
-HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical -no-hip-rt -fno-slp-vectorize -fno-hip-fp32-correctly-rounded-divide-sqrt -DKY_WAVES_PER_EU=6
+HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical -no-hip-rt -fno-slp-vectorize -fno-hip-fp32-correctly-rounded-divide-sqrt
 LIBDIR   := ky_amd/lib
 
 all: $(LIBDIR)/libkyhip.so $(LIBDIR)/libkyhost.so oracle examples

@@ -174,10 +174,6 @@ struct DLight {  // light_t + the shape an area light samples; wave-uniform inde
     DSurf isect;          // traversal record of the sampled shape (pdf_direction re-intersects it, 1057-1061)
 };
 constexpr int KY_MAX_CARRIERS = 4;
-#ifndef KY_TRANSPOSE_QUERIES
-#define KY_TRANSPOSE_QUERIES 4
-#endif
-constexpr int KY_TRANSPOSE_MAX = KY_TRANSPOSE_QUERIES;   // at most this many occlusion queries per wave are resolved surface-parallel
 
 struct DPar {  // planar parallelogram, 48 B: q0 = (n, n.p0), q1 = (a*, a*.p1 + 0.5), q2 = (b*, b*.p1 + 0.5)
     float4 q0, q1, q2;
@@ -1090,8 +1086,10 @@ KY_DEV f3 surface_emission(const LdsScene& Lds, int surface, f3 normal, f3 wo) {
 // per ray, but only the few rays that reach a carrier surface at all need an answer.  So each lane first tests just
 // the carrier surfaces; the rare lanes that hit one then ask "is anything in front of it?", and those few queries
 // are resolved SURFACE-parallel: the query ray is broadcast (v_readlane) and lane j tests surface j (records in LDS),
-// one ballot per query.  With more than KY_TRANSPOSE_MAX queries in the wave, or for scenes the fast path does not
-// cover (general quads / triangles / disks, environment lights, many carriers), the ordinary traversal runs instead.
+// one ballot per query -- however many queries the wave has (rounds 1-3 switched to a traversal by the querying lanes beyond four
+// queries; without that second way out the hot kernel needs 72 VGPRs instead of 80, which is a seventh wavefront per SIMD: +0.8 % by
+// itself, +4.3 % with the wavefront).  Scenes the fast path does not cover (general quads / triangles / disks, environment lights, many
+// carriers, more than 64 surfaces) take the ordinary traversal.
 // path_tracing_recursion_t's emitter look-up at a specular vertex (4341-4349) needs the nearest hit along one more ray -- for exactly the lanes
 // that take no part in the vertex's direct lighting.  In that integrator's own instantiations the look-up RIDES ALONG with the first
 // nearest-hit or shadow traversal the light loop runs for the other lanes: one traversal with fuller lanes instead of two sparse ones.
@@ -1170,7 +1168,7 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 
         // (b) is any surface in front of the carrier?  (the carrier itself reproduces t_l exactly, and t < t_l is strict)
         unsigned long long queries = __ballot(pending);
         bool blocked = false;
-        if (__popcll(queries) > KY_TRANSPOSE_MAX || (S.large && S->n_surfaces > 64)) {   // (lane j tests surface j: scenes of up to 64 surfaces)
+        if (S.large && S->n_surfaces > 64) {   // (lane j tests surface j: scenes of up to 64 surfaces)
             KY_PROBE(2);
             // the traversal may test the carrier with another formulation than (a) did (aar_hit vs par_hit): keep its own
             // hit, a few ulp around t_l, out of the interval

@@ -205,13 +205,16 @@ static ShardConst make_shard(const ky_render_params* p) {
 #define KY_RETRACE_THRESHOLD 80
 #endif
 #ifndef KY_WAVES_PER_EU
-#define KY_WAVES_PER_EU 6           // the hot instantiation <false, both_mis>: 80 VGPRs
+#define KY_WAVES_PER_EU 7           // the hot instantiation <false, both_mis, feat 7>: 72 VGPRs, nothing spilled (six: 80; +3.5 % for the seventh wavefront)
 #endif
 #ifndef KY_WAVES_PER_EU_QUEUE
 #define KY_WAVES_PER_EU_QUEUE 5     // the instantiation with deferred shadow rays: 96 VGPRs (6 spilled) beat 80 (28 spilled) by 3.5 % since round 3
 #endif
 #ifndef KY_WAVES_PER_EU_QUEUE_FEAT
 #define KY_WAVES_PER_EU_QUEUE_FEAT 6   // ... with scene facts (the sphere-lights kernel): 80 VGPRs with 11 spilled beat 96 with 2 by 4 %
+#endif
+#ifndef KY_WAVES_PER_EU_NO_FACTS
+#define KY_WAVES_PER_EU_NO_FACTS 6     // both_mis without scene facts (any lights, inline shadow rays; every integrator): 19-39 spilled VGPRs at seven
 #endif
 #ifndef KY_WAVES_PER_EU_GENERIC
 #define KY_WAVES_PER_EU_GENERIC 5   // strategy / integrator read at run time: more code alive at once, 96 VGPRs measured best
@@ -237,7 +240,9 @@ struct ItemSlot {  // one fetched work item, decoded once (wave-uniform) and rea
 // LARGE: the scene's per-lane tables live in dynamic shared memory sized by the scene (more than KY_LDS_SURFACES surfaces or
 // KY_LDS_MATERIALS materials; ky_device.hpp, LdsScene).
 template <bool DEBUG_SAMPLER, int STRATEGY, bool QUEUE = false, bool GENERAL = false, int FEAT = 0, int INTEGRATOR = KY_INTEGRATOR_PATH_TRACING_ITERATION, bool LARGE = false>
-__global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? (FEAT ? KY_WAVES_PER_EU_QUEUE_FEAT : KY_WAVES_PER_EU_QUEUE) : KY_WAVES_PER_EU) : KY_WAVES_PER_EU_GENERIC) void render_kernel(const DScene* __restrict__ S_, RenderConst rc, ShardConst sh,
+__global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? (FEAT ? KY_WAVES_PER_EU_QUEUE_FEAT : KY_WAVES_PER_EU_QUEUE)
+                                                          : ((FEAT == 0 && STRATEGY == KY_DIRECT_BOTH_MIS) ? KY_WAVES_PER_EU_NO_FACTS : KY_WAVES_PER_EU))
+                                                : KY_WAVES_PER_EU_GENERIC) void render_kernel(const DScene* __restrict__ S_, RenderConst rc, ShardConst sh,
                                                                      unsigned* __restrict__ counter, unsigned long long* __restrict__ accum,
                                                                      unsigned* __restrict__ flags, float4* __restrict__ queue_mem) {
     static_assert(!QUEUE || ((STRATEGY == KY_DIRECT_BOTH_MIS || STRATEGY == KY_DIRECT_LIGHT_MIS || STRATEGY == KY_DIRECT_LIGHT) && INTEGRATOR == KY_INTEGRATOR_PATH_TRACING_ITERATION),

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/mkvariant.sh <name> [extra hipcc flags...]  -> build_variants/<name>.so + build_variants/<name>.txt (resource usage of the render kernels)
 NAME=$1; shift
-BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical -no-hip-rt -fno-slp-vectorize -fno-hip-fp32-correctly-rounded-divide-sqrt -DKY_WAVES_PER_EU=6"
+BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical -no-hip-rt -fno-slp-vectorize -fno-hip-fp32-correctly-rounded-divide-sqrt"
 SRC=${KY_SRC:-ky_amd/csrc/kyhip.hip}
 mkdir -p /tmp/bv build_variants
 hipcc $BASE "$@" -Rpass-analysis=kernel-resource-usage -shared -o build_variants/$NAME.so $SRC 2> /tmp/bv/$NAME.log

@@ -93,7 +93,7 @@ static int fail(int code, const char* fmt, ...) {
 constexpr int KY_CHUNK = KY_CHUNK_BIG;
 static_assert(KY_CHUNK_BIG <= 127, "the lane's sample cursor keeps the chunk's remaining samples in 7 bits");
 #ifndef KY_RING_SLOTS
-#define KY_RING_SLOTS 4
+#define KY_RING_SLOTS 3   // (a wave reads at most the two newest items; three slots keep the standard kernels' LDS block under 20 480 bytes: eight per CU)
 #endif
 constexpr int KY_RING = KY_RING_SLOTS;          // fetched-but-not-yet-started items a wave can hold
 constexpr double KY_FIX_SCALE = 4294967296.0;   // 2^32: accumulator resolution 2.3e-10, range +-2.1e9
@@ -213,6 +213,9 @@ static ShardConst make_shard(const ky_render_params* p) {
 #ifndef KY_WAVES_PER_EU_QUEUE_FEAT
 #define KY_WAVES_PER_EU_QUEUE_FEAT 6   // ... with scene facts (the sphere-lights kernel): 80 VGPRs with 11 spilled beat 96 with 2 by 4 %
 #endif
+#ifndef KY_WAVES_PER_EU_HOT
+#define KY_WAVES_PER_EU_HOT 8          // the iterative integrator's both_mis with a single-light fact (every Cornell configuration): 64 VGPRs with 0-4 spilled, +1 % over
+#endif                                 // seven (+1.0 ... +2.9 % per Cornell light variant); the other strategies lose up to 15 % at eight
 #ifndef KY_WAVES_PER_EU_NO_FACTS
 #define KY_WAVES_PER_EU_NO_FACTS 6     // both_mis without scene facts (any lights, inline shadow rays; every integrator): 19-39 spilled VGPRs at seven
 #endif
@@ -241,7 +244,8 @@ struct ItemSlot {  // one fetched work item, decoded once (wave-uniform) and rea
 // KY_LDS_MATERIALS materials; ky_device.hpp, LdsScene).
 template <bool DEBUG_SAMPLER, int STRATEGY, bool QUEUE = false, bool GENERAL = false, int FEAT = 0, int INTEGRATOR = KY_INTEGRATOR_PATH_TRACING_ITERATION, bool LARGE = false>
 __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? (FEAT ? KY_WAVES_PER_EU_QUEUE_FEAT : KY_WAVES_PER_EU_QUEUE)
-                                                          : ((FEAT == 0 && STRATEGY == KY_DIRECT_BOTH_MIS) ? KY_WAVES_PER_EU_NO_FACTS : KY_WAVES_PER_EU))
+                                                          : ((FEAT == 0 && STRATEGY == KY_DIRECT_BOTH_MIS) ? KY_WAVES_PER_EU_NO_FACTS
+                                                             : ((FEAT != 0 && STRATEGY == KY_DIRECT_BOTH_MIS && INTEGRATOR == KY_INTEGRATOR_PATH_TRACING_ITERATION) ? KY_WAVES_PER_EU_HOT : KY_WAVES_PER_EU)))
                                                 : KY_WAVES_PER_EU_GENERIC) void render_kernel(const DScene* __restrict__ S_, RenderConst rc, ShardConst sh,
                                                                      unsigned* __restrict__ counter, unsigned long long* __restrict__ accum,
                                                                      unsigned* __restrict__ flags, float4* __restrict__ queue_mem) {
@@ -1487,6 +1491,7 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
         if (v->queue && !st->d_shadow_queue)   // the wavefronts' shadow-ray stacks of this stream's launches
             HIP_TRY(hipMalloc(&st->d_shadow_queue, (size_t)c->cus * per_cu * 4 * KY_SQ_ENTRY * KY_SQ_CAP * sizeof(float4)));
         unsigned grid = (unsigned)(c->cus * per_cu);
+        if (const char* e = std::getenv("KYHIP_BLOCKS_PER_CU")) { const int b = std::atoi(e); if (b > 0 && b < per_cu) grid = (unsigned)(c->cus * b); }
         const unsigned need_blocks = sh.n_items / 4 + 1;
         if (grid > need_blocks) grid = need_blocks;
         if (grid < 1) grid = 1;

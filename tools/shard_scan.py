@@ -1,16 +1,17 @@
 """kernel time of a 1/N shard vs spp: slope = per-sample cost, intercept = per-launch fixed cost of the shard; and the kernel-level
-efficiency of N = 4 / 8 at 1024 spp (slowest of the first three shards)."""
+efficiency of N = 4 / 8 at 1024 spp (slowest of the first three shards).  usage: tools/shard_scan.py [tile size, default 16]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from ky_amd import api, dist, _abi as A
 lib = A.load_kyhip()
 scene = api.cornell_box_scene(A.CB_DEFAULT_SCENE, 1024, 768)
+tile = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 t1024 = {}
 for N in (1, 4, 8):
     xs, ys = [], []
     for spp in (256, 512, 1024, 2048):
-        p = api.make_params(1024, 768, spp)
+        p = api.make_params(1024, 768, spp, tile_w=tile, tile_h=tile)
         worst = 0
         for r in range(min(N, 3)):
             best = 1e9

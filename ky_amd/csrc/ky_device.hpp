@@ -449,15 +449,30 @@ KY_DEV bool aar_hit(const float4 q0, const float ov, f3 o, f3 d, f3 inv_d, float
     return (fabsf(u) <= q0.z) & (fabsf(v) <= ov) & (t > K_SHAPE_EPS) & (t < tmax);
 }
 
-// the axis-aligned rectangles of one axis: records [first, first + n) of S->aar, whose sorted surface indices are the same
+// Scene tables are addressed as S + (32-bit byte offset): the scalar loads then take the scene pointer as their base and the offset from
+// one SGPR (s_load_dwordx4 s[..], s[S:S+1], s_off offset:16), so no table needs a 64-bit pointer of its own.  As `T.aar + i` the compiler
+// kept one hoisted base per table and loop alive across the whole path loop -- two SGPRs each, most of them spilled to VGPR lanes at the hot
+// kernels' budget of 80 SGPRs and read back with two v_readlane per use.  The empty asm keeps the offset an offset (it stops the loop
+// optimiser from turning base + offset back into a pointer that advances).
+KY_DEV unsigned scene_off(SceneRef S, const void* q) { return (unsigned)((const char*)q - (const char*)S.p); }
+template <class T>
+KY_DEV const T& scene_at(SceneRef S, unsigned off) { return *(const T*)((const char*)S.p + off); }
+// a record of the scene whose fields are read at several places of the path loop: the offset is (re)made where the record is used -- one
+// s_mov / s_mul -- instead of one hoisted pointer per FIELD ADDRESS living (spilled) across the loop
+KY_DEV unsigned opaque_off(unsigned off) { asm volatile("" : "+s"(off)); return off; }
+KY_DEV const DLight& scene_light(SceneRef S, int li) { return scene_at<DLight>(S, opaque_off((unsigned)offsetof(DScene, light) + (unsigned)li * (unsigned)sizeof(DLight))); }
+KY_DEV const DSurf& scene_surf(SceneRef S, int i) { return scene_at<DSurf>(S, opaque_off((unsigned)offsetof(DScene, all) + (unsigned)i * (unsigned)sizeof(DSurf))); }
+
+// the axis-aligned rectangles of one axis: records [first, first + n) of the table at byte offset `aar_off`, whose sorted surface indices are the same
 template <int AXIS, bool NEAREST>
-KY_DEV void aar_scan(const DAar* __restrict__ aar, int first, int n, f3 o, f3 d, f3 inv_d, float& tmax, int& best, bool& occ) {
+KY_DEV void aar_scan(SceneRef S, unsigned aar_off, int first, int n, f3 o, f3 d, f3 inv_d, float& tmax, int& best, bool& occ) {
     if (n <= 0) return;
-    float4 q0 = aar[first].q0;
-    float ov = aar[first].q1.x;
+    unsigned off = aar_off + (unsigned)first * (unsigned)sizeof(DAar);
     for (int i = first; i < first + n; ++i) {
-        const float4 n0 = aar[i + 1].q0;   // record n_aar exists (padding)
-        const float nv = aar[i + 1].q1.x;
+        asm volatile("" : "+s"(off));
+        const DAar& r = scene_at<DAar>(S, off);
+        const float4 q0 = r.q0;
+        const float ov = r.q1.x;
         float t;
         const bool ok = aar_hit<AXIS>(q0, ov, o, d, inv_d, tmax, t);
         if (NEAREST) {
@@ -466,7 +481,7 @@ KY_DEV void aar_scan(const DAar* __restrict__ aar, int first, int n, f3 o, f3 d,
         } else {
             occ = occ | ok;
         }
-        q0 = n0; ov = nv;
+        off += (unsigned)sizeof(DAar);
     }
 }
 
@@ -494,40 +509,41 @@ KY_DEV bool surf_hit(const DSurf& S, const DShapeFull* __restrict__ full, f3 o, 
 }
 
 // scene_t::intersect, ky.cpp:3172-3184: linear scan, tmax shrinks, first of equals wins.  Returns the SORTED surface index.
-// The record of surface i+1 is fetched (scalar loads) while surface i is being tested, so the scalar-cache latency
-// overlaps the VALU work instead of being exposed once per surface.
 KY_DEV int trace_nearest(SceneRef S, f3 o, f3 d, float& tmax) {
     int best = -1;
-    const DTrav& T = S->trav;
-    const int n_aar = T.n_aar, n_par = T.n_par, n_sph = S->n_sph, n_gen = S->n_gen;
+    const unsigned t_off = opaque_off((unsigned)offsetof(DScene, trav));
+    const int4 head = scene_at<int4>(S, t_off), axis = scene_at<int4>(S, t_off + 16u);   // n_aar, n_par; n_aar_axis[3]
+    const int n_aar = head.x, n_par = head.y, n_sph = S->n_sph, n_gen = S->n_gen;
     if (n_aar > 0) {
         const f3 inv_d = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
         bool unused = false;
-        const int n0 = T.n_aar_axis[0], n1 = T.n_aar_axis[1], n2 = T.n_aar_axis[2];
-        aar_scan<0, true>(T.aar, 0, n0, o, d, inv_d, tmax, best, unused);
-        aar_scan<1, true>(T.aar, n0, n1, o, d, inv_d, tmax, best, unused);
-        aar_scan<2, true>(T.aar, n0 + n1, n2, o, d, inv_d, tmax, best, unused);
+        const int n0 = axis.x, n1 = axis.y, n2 = axis.z;
+        const unsigned aar_off = t_off + (unsigned)offsetof(DTrav, aar);
+        aar_scan<0, true>(S, aar_off, 0, n0, o, d, inv_d, tmax, best, unused);
+        aar_scan<1, true>(S, aar_off, n0, n1, o, d, inv_d, tmax, best, unused);
+        aar_scan<2, true>(S, aar_off, n0 + n1, n2, o, d, inv_d, tmax, best, unused);
     }
     if (n_par > 0) {
-        float4 q0 = T.par[0].q0, q1 = T.par[0].q1, q2 = T.par[0].q2;
+        unsigned off = t_off + (unsigned)offsetof(DTrav, par);
         for (int i = 0; i < n_par; ++i) {
-            const float4 n0 = T.par[i + 1].q0, n1 = T.par[i + 1].q1, n2 = T.par[i + 1].q2;   // record n_par exists (padding)
+            asm volatile("" : "+s"(off));
+            const DPar& r = scene_at<DPar>(S, off);
             float t;
-            const bool ok = par_hit(q0, q1, q2, o, d, tmax, t);
+            const bool ok = par_hit(r.q0, r.q1, r.q2, o, d, tmax, t);
             tmax = ok ? t : tmax;
             best = ok ? n_aar + i : best;
-            q0 = n0; q1 = n1; q2 = n2;
+            off += (unsigned)sizeof(DPar);
         }
     }
     if (n_sph > 0) {
-        float4 c = S->sph[0].c;
+        unsigned off = scene_off(S, &S->sph[0]);
         for (int i = 0; i < n_sph; ++i) {
-            const float4 nc = S->sph[i + 1].c;
+            asm volatile("" : "+s"(off));
             float t;
-            const bool ok = sph_hit(c, o, d, tmax, t);
+            const bool ok = sph_hit(scene_at<DSph>(S, off).c, o, d, tmax, t);
             tmax = ok ? t : tmax;
             best = ok ? n_aar + n_par + i : best;
-            c = nc;
+            off += (unsigned)sizeof(DSph);
         }
     }
     for (int i = 0; S.general && i < n_gen; ++i) {
@@ -540,28 +556,30 @@ KY_DEV int trace_nearest(SceneRef S, f3 o, f3 d, float& tmax) {
     return best;
 }
 
-// scene_t::occluded's traversal (3193-3195): any hit inside (eps, tmax) occludes.  `T_` (wave-uniform): the table of planar surfaces
+// scene_t::occluded's traversal (3193-3195): any hit inside (eps, tmax) occludes.  `T` (wave-uniform): the table of planar surfaces
 // to test -- S->trav (all), or the occluder table when the ray qualifies for it (DScene::occ).
-KY_DEV bool trace_any_planar(const DTrav& T, f3 o, f3 d, float tmax) {
+KY_DEV bool trace_any_planar(SceneRef S, const DTrav& T, f3 o, f3 d, float tmax) {
     bool occ = false;
-    const int n_aar = T.n_aar, n_par = T.n_par;
-    const DAar* __restrict__ aar = T.aar;
-    const DPar* __restrict__ par = T.par;
-    float t;
+    const unsigned t_off = opaque_off(scene_off(S, &T));
+    const int4 head = scene_at<int4>(S, t_off), axis = scene_at<int4>(S, t_off + 16u);   // n_aar, n_par; n_aar_axis[3]
+    const int n_aar = head.x, n_par = head.y;
     if (n_aar > 0) {
         const f3 inv_d = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
         int unused = -1;
-        const int n0 = T.n_aar_axis[0], n1 = T.n_aar_axis[1], n2 = T.n_aar_axis[2];
-        aar_scan<0, false>(aar, 0, n0, o, d, inv_d, tmax, unused, occ);
-        aar_scan<1, false>(aar, n0, n1, o, d, inv_d, tmax, unused, occ);
-        aar_scan<2, false>(aar, n0 + n1, n2, o, d, inv_d, tmax, unused, occ);
+        const int n0 = axis.x, n1 = axis.y, n2 = axis.z;
+        const unsigned aar_off = t_off + (unsigned)offsetof(DTrav, aar);
+        aar_scan<0, false>(S, aar_off, 0, n0, o, d, inv_d, tmax, unused, occ);
+        aar_scan<1, false>(S, aar_off, n0, n1, o, d, inv_d, tmax, unused, occ);
+        aar_scan<2, false>(S, aar_off, n0 + n1, n2, o, d, inv_d, tmax, unused, occ);
     }
     if (n_par > 0) {
-        float4 q0 = par[0].q0, q1 = par[0].q1, q2 = par[0].q2;
+        unsigned off = t_off + (unsigned)offsetof(DTrav, par);
         for (int i = 0; i < n_par; ++i) {
-            const float4 n0 = par[i + 1].q0, n1 = par[i + 1].q1, n2 = par[i + 1].q2;
-            occ = occ | par_hit(q0, q1, q2, o, d, tmax, t);
-            q0 = n0; q1 = n1; q2 = n2;
+            asm volatile("" : "+s"(off));
+            const DPar& r = scene_at<DPar>(S, off);
+            float t;
+            occ = occ | par_hit(r.q0, r.q1, r.q2, o, d, tmax, t);
+            off += (unsigned)sizeof(DPar);
         }
     }
     return occ;
@@ -572,15 +590,15 @@ KY_DEV bool trace_any(SceneRef S, const DTrav& T_, f3 o, f3 d, float tmax) {
 #else
     const DTrav& T = T_;
 #endif
-    bool occ = trace_any_planar(T, o, d, tmax);
+    bool occ = trace_any_planar(S, T, o, d, tmax);
     const int n_sph = S->n_sph, n_gen = S->n_gen;
     float t;
     if (n_sph > 0) {
-        float4 c = S->sph[0].c;
+        unsigned off = scene_off(S, &S->sph[0]);
         for (int i = 0; i < n_sph; ++i) {
-            const float4 nc = S->sph[i + 1].c;
-            occ = occ | sph_hit(c, o, d, tmax, t);
-            c = nc;
+            asm volatile("" : "+s"(off));
+            occ = occ | sph_hit(scene_at<DSph>(S, off).c, o, d, tmax, t);
+            off += (unsigned)sizeof(DSph);
         }
     }
     for (int i = 0; S.general && i < n_gen; ++i) occ = occ || full_shape_hit(S->full[S->gen[i].full], o, d, tmax, t);
@@ -1107,7 +1125,7 @@ KY_DEV void sq_push_bsdf_query(SceneRef S, ShadowQueue& q, bool push, f3 o, f3 d
 template <bool MIS>
 KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, int li, float u0, float u1, bool active,
                            ShadowQueue* sq = nullptr, f3 beta = f3{0, 0, 0}, float weight = 0.f, unsigned tag = 0, RideAlong* ra = nullptr) {
-    const DLight& L = S->light[li];
+    const DLight& L = scene_light(S, li);
     f3 Ld = mk3(0, 0, 0);
     if (S.is_delta(L.kind)) return Ld;  // light.is_delta(), 3894 / 3977 (wave-uniform)
     BsdfSample bs;
@@ -1132,7 +1150,7 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 
         int c = -1;
         for (int k = 0; k < L.n_carriers; ++k) {
             float t;
-            const bool ok = act & surf_hit(S->all[L.carrier[k]], S->full, o, bs.wi, t_l, t, S.general, S.sphere_lights());
+            const bool ok = act & surf_hit(scene_surf(S, L.carrier[k]), S->full, o, bs.wi, t_l, t, S.general, S.sphere_lights());
             t_l = ok ? t : t_l;
             c = ok ? L.carrier[k] : c;
         }
@@ -1345,7 +1363,7 @@ KY_DEV void sq_drain(SceneRef S, ShadowQueue& q) {
 template <bool MIS>
 KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, f3 wo, int li, float u0, float u1, bool active, f3 beta, float weight,
                                          unsigned tag, ShadowQueue& q) {
-    const DLight& L = S->light[li];
+    const DLight& L = scene_light(S, li);
     bool push = false;
     SqRay r{any3(), any3(), any3(), any_f(), tag};   // read by sq_push only for lanes that push
     if (active) {
@@ -1380,18 +1398,19 @@ KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, f3 wo, int
 // light-sampling half: by_emitter (3933-3962, MIS=false) and by_emitter_mis (4035-4074, MIS=true)
 // scene_t::occluded for a shadow ray towards a sample of light li (wave-uniform), through the occluder tables that apply to that light
 KY_DEV bool light_sample_occluded(SceneRef S, int li, f3 o, f3 dir, float tmax) {
-    const bool ok = S->light[li].occ_ok != 0;
+    const bool ok = scene_light(S, li).occ_ok != 0;
 #if defined(KY_NO_TWO_STAGE) || defined(KY_NO_OCCLUDER_CULL)
     return trace_any(S, ok ? S->occ : S->trav, o, dir, tmax);
 #else
     const bool two = li == S->ts_light;
     bool occ = trace_any(S, two ? S->occ_front : (ok ? S->occ : S->trav), o, dir, tmax);
     if (two) {   // what is mounted behind the lamp: only a ray with an end in that half-space can meet it (DScene::occ_behind)
-        const f3 pn = mk3(S->ts_plane[0], S->ts_plane[1], S->ts_plane[2]);
+        const float4 plane = scene_at<float4>(S, opaque_off((unsigned)offsetof(DScene, ts_plane)));
+        const f3 pn = mk3(plane.x, plane.y, plane.z);
         const f3 e = o + dir * tmax;
-        const bool need = !occ && (fminf(dot(pn, e), dot(pn, o)) <= S->ts_plane[3]);
+        const bool need = !occ && (fminf(dot(pn, e), dot(pn, o)) <= plane.w);
         if (__any(need)) {
-            if (need) occ = trace_any_planar(S->occ_behind, o, dir, tmax);
+            if (need) occ = trace_any_planar(S, S->occ_behind, o, dir, tmax);
         }
     }
     return occ;
@@ -1400,7 +1419,7 @@ KY_DEV bool light_sample_occluded(SceneRef S, int li, f3 o, f3 dir, float tmax) 
 
 template <bool MIS>
 KY_DEV f3 estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, int li, float u0, float u1) {
-    const DLight& L = S->light[li];
+    const DLight& L = scene_light(S, li);
     f3 Ld = mk3(0, 0, 0);
     KY_PROBE(3);
     const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1, S.feat);
@@ -1439,7 +1458,7 @@ KY_DEV f3 estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, 
 // inside its interval: the occluder tables are subsets that decide the same, tests/test_occluders.py).
 template <bool MIS>
 KY_DEV f3 estimate_by_emitter_ride(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, int li, float u0, float u1, bool active, RideAlong& ra) {
-    const DLight& L = S->light[li];
+    const DLight& L = scene_light(S, li);
     f3 Ld = mk3(0, 0, 0);
     LightSample ls{any3(), any3(), any3(), any_f()};
     bool dead = true;

@@ -129,6 +129,8 @@ KYHOST_SYMBOLS = {
     "kyhost_scene_flatten": (SP, [C.c_void_p]),
     "kyhost_render": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "kyhost_debug_area": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "kyhost_store_image": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "kyhost_gamma_encoding": (C.c_int, [C.c_float]),
 }

@@ -116,6 +116,21 @@ def render_host_api(scene, integrator_enum, depth, direct_sample, sampler, spp, 
     return film
 
 
+def debug_area_host_api(scene, integrator_enum, depth, direct_sample, sampler, spp, width, height, begin, end, film=None, seed=1234, device=0):
+    """create_integrator(...)->debug_area(&scene, sampler, &film, begin, end) (ky.cpp:3733-3777) through the C++ host classes; a 1 x 1 area
+    goes through debug_pixel (3784).  Returns the film (modified in place when given)."""
+    host = A.load_kyhost()
+    if film is None:
+        film = np.zeros((height, width, 3), np.float32)
+    rc = host.kyhost_debug_area(scene.ptr, integrator_enum, depth, direct_sample, sampler, spp, seed, width, height, _fptr(film),
+                                int(begin[0]), int(begin[1]), int(end[0]), int(end[1]), device)
+    if rc == -2:
+        return None
+    if rc != 0:
+        raise KyError("kyhost_debug_area failed: " + host.kyhost_last_error().decode())
+    return film
+
+
 def kernel_ms(device=0):
     return float(A.load_kyhip().kyhip_kernel_ms(device))
 

@@ -584,12 +584,7 @@ KY_DEV bool trace_any_planar(SceneRef S, const DTrav& T, f3 o, f3 d, float tmax)
     }
     return occ;
 }
-KY_DEV bool trace_any(SceneRef S, const DTrav& T_, f3 o, f3 d, float tmax) {
-#ifdef KY_NO_OCCLUDER_CULL   // A/B measurements
-    const DTrav& T = S->trav;
-#else
-    const DTrav& T = T_;
-#endif
+KY_DEV bool trace_any(SceneRef S, const DTrav& T, f3 o, f3 d, float tmax) {
     bool occ = trace_any_planar(S, T, o, d, tmax);
     const int n_sph = S->n_sph, n_gen = S->n_gen;
     float t;
@@ -750,10 +745,6 @@ KY_DEV LobeBasis make_lobe_basis(const Bsdf& B, f3 n, f3 wo) {
     if (B.lobe == LOBE_PHONG) {       // 2533-2536: wr = reflect(wo, z) in the shading frame, frame_t(wr) there
         const f3 wo_l = to_local(fr, wo);
         const f3 wr = mk3(-wo_l.x, -wo_l.y, wo_l.z);   // unit because wo is
-#ifdef KY_PHONG_BASIS_FRAMES   // the reference's operations one by one (A/B measurements)
-        const Frame fl = make_frame(wr);
-        L.a = to_world(fr, fl.s); L.b = to_world(fr, fl.t); L.c = to_world(fr, wr);
-#else
         // frame_t(wr): t = normalize(cross(wr, X or Y)), s = cross(t, wr).  t has a zero component, and the shading frame is a rotation
         // (s x t = n), so cross products may be taken in world space: b = to_world(t), c = to_world(wr), a = cross(b, c) -- one frame
         // transform of a vector with a zero component, one of wr, one cross product instead of a frame build and three transforms.
@@ -766,7 +757,6 @@ KY_DEV LobeBasis make_lobe_basis(const Bsdf& B, f3 n, f3 wo) {
             L.b = fr.t * (wr.z * k) + fr.n * (-wr.y * k);       // t = (0, wr.z, -wr.y) k
         }
         L.a = cross(L.b, L.c);
-#endif
     }
     return L;
 }
@@ -812,7 +802,10 @@ KY_DEV void bsdf_eval_pdf(const Vertex& v, f3 wo, f3 wi, f3& f, float& pdf, floa
 // Both lobes place a point (rad cos, rad sin) on a circle and lift it: the cosine lobe by the concentric disk mapping (710-743), the
 // Phong lobe by cos(theta) = u1^(1/(n+1)) around the mirror direction (2510-2524).  A wavefront holds vertices of both kinds: the angle,
 // the radius and the height are computed per lobe, the two quarter-rate sin / cos and the combination with the basis are issued once.
-KY_DEV f3 bsdf_sample_dir_nondelta(const Vertex& v, f3 wo, float u0, float u1) {
+// `back_dead` (bsdf_continue): set when a Phong sample taken from the BACK side of its surface (wo.z < 0: the flip of 2539 moves wi away from
+// the lobe's axis) has pdf_ = 0 -- the reference clamps cos_alpha at 0 there (2549) and ends the path (4588); from the front side
+// cos_alpha = z and the caller's u1 > 0 test decides.
+KY_DEV f3 bsdf_sample_dir_nondelta(const Vertex& v, f3 wo, float u0, float u1, bool* back_dead = nullptr) {
     const bool phong = v.bsdf.lobe == LOBE_PHONG;
     const float cos_o = dot(v.normal, wo);
     float ang, rad, z = any_f();
@@ -837,7 +830,15 @@ KY_DEV f3 bsdf_sample_dir_nondelta(const Vertex& v, f3 wo, float u0, float u1) {
     }
     const LobeBasis L = vertex_basis(v);
     f3 wi = L.a * px + L.b * py + L.c * z;
-    if (phong && cos_o < 0) wi = wi - (2.f * dot(v.normal, wi)) * v.normal;   // `if (wo.z < 0) wi.z *= -1` (2539) in world space
+    if (phong && cos_o < 0) {   // `if (wo.z < 0) wi.z *= -1` (2539) in world space; rectangles face the ray (1289), so this is the inside of a plastic sphere
+        const float nw = dot(v.normal, wi);
+        wi = wi - (2.f * nw) * v.normal;
+        if (back_dead) {
+            const float cos_alpha = z - 2.f * nw * dot(v.normal, L.c);   // dot(wr, wi) after the flip
+            const float pe = phong_pow(cos_alpha, v.bsdf.m->exponent, v.bsdf.m->exp_flags);
+            *back_dead = v.bsdf.m->exponent > 0.f && !(cos_alpha > 0.f && pe > 0.f);
+        }
+    }
     return wi;
 }
 
@@ -920,12 +921,13 @@ KY_DEV BsdfContinue bsdf_continue(const Vertex& v, f3 wo, float u0, float u1) {
         c.weight = ld3(d.reflected ? v.bsdf.m->c0 : v.bsdf.m->c1);
         c.ok = !is_black(c.weight) && d.percent != 0.f;
     } else {
-        c.wi = bsdf_sample_dir_nondelta(v, wo, u0, u1);
+        bool back_dead = false;
+        c.wi = bsdf_sample_dir_nondelta(v, wo, u0, u1, &back_dead);
         const float cos_o = dot(v.normal, wo), cos_i = dot(v.normal, c.wi);
         const bool phong = v.bsdf.lobe == LOBE_PHONG;
         const f3 col = ld3(phong ? v.bsdf.m->c1 : v.bsdf.m->c0);
         c.weight = phong ? col * fabsf(cos_i) : col;
-        c.ok = (cos_o * cos_i > 0) && !is_black(col) && !(phong && !(u1 > 0.f) && v.bsdf.m->exponent > 0.f);
+        c.ok = (cos_o * cos_i > 0) && !is_black(col) && !(phong && !(u1 > 0.f) && v.bsdf.m->exponent > 0.f) && !back_dead;
     }
     return c;
 }
@@ -1332,11 +1334,7 @@ KY_DEV void sq_push(SceneRef S, ShadowQueue& q, bool push, SqRay r) {
     const bool keep = push && rank < take;
     if (push && !keep) sq_store(q.base + (q.n + rank - take) * KY_SQ_ENTRY, r);
     const int n1 = q.n + k - take;
-#ifdef KY_SQ_FENCE
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#else
     asm volatile("" ::: "memory");   // the compiler must keep the order; the hardware keeps a wavefront's accesses to one address in order by itself
-#endif
     const unsigned long long others = __ballot(!keep);
     if (!keep) {
         const int j = n1 - 1 - (int)__builtin_amdgcn_mbcnt_hi((unsigned)(others >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)others, 0u));
@@ -1399,9 +1397,6 @@ KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, f3 wo, int
 // scene_t::occluded for a shadow ray towards a sample of light li (wave-uniform), through the occluder tables that apply to that light
 KY_DEV bool light_sample_occluded(SceneRef S, int li, f3 o, f3 dir, float tmax) {
     const bool ok = scene_light(S, li).occ_ok != 0;
-#if defined(KY_NO_TWO_STAGE) || defined(KY_NO_OCCLUDER_CULL)
-    return trace_any(S, ok ? S->occ : S->trav, o, dir, tmax);
-#else
     const bool two = li == S->ts_light;
     bool occ = trace_any(S, two ? S->occ_front : (ok ? S->occ : S->trav), o, dir, tmax);
     if (two) {   // what is mounted behind the lamp: only a ray with an end in that half-space can meet it (DScene::occ_behind)
@@ -1414,7 +1409,6 @@ KY_DEV bool light_sample_occluded(SceneRef S, int li, f3 o, f3 dir, float tmax) 
         }
     }
     return occ;
-#endif
 }
 
 template <bool MIS>

@@ -34,6 +34,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ky_device.hpp"
@@ -1074,6 +1075,12 @@ static bool shadow_queue_wanted(int light_count) {
     return forced >= 0 ? forced == 1 : light_count >= KY_SQ_MIN_LIGHTS;
 }
 
+// KYHIP_BLOCKS_PER_CU=n caps the resident workgroups per CU of the render kernels (shard-drain measurements, tools/shard_scan.py); read once
+static int blocks_per_cu_cap() {
+    static const int cap = [] { const char* e = std::getenv("KYHIP_BLOCKS_PER_CU"); return e ? std::atoi(e) : 0; }();
+    return cap;
+}
+
 // which render kernel runs path_tracing_iteration_t: the lane engine (render_kernel, default) or the queue engine (render_kernel_q)
 enum { KY_ENGINE_LANE = 0, KY_ENGINE_QUEUE = 1 };
 static int g_engine = -1;
@@ -1113,20 +1120,37 @@ struct StreamState {
     size_t ws_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing_valid = false;
-    float4* d_shadow_queue = nullptr;      // QUEUE instantiation, allocated on first use
+    float4* d_shadow_queue = nullptr;      // QUEUE instantiations: the wavefronts' stacks, allocated on first use ...
+    size_t sq_blocks = 0;                  // ... for this many workgroups; the QUEUE variants differ in occupancy (5 or 6 per CU), so a launch that needs more reallocates
+    hipEvent_t done = nullptr;             // behind the last kernel this library enqueued on the stream (what a hand-over of this state or of a scene slot waits for)
     unsigned long long last_use = 0;
 };
 struct SceneSlot {
     bool valid = false;
     DScene* d = nullptr;                   // device copy
-    DScene* h = nullptr;                   // pinned staging copy = what `d` holds (the key of the cache)
+    DScene* h = nullptr;                   // pinned staging copy = what `d` holds (the key of the cache, compared when the hashes agree)
+    uint64_t hash = 0;                     // scene_hash(*h)
+    unsigned readers = 0;                  // bit i: a launch on stream state i has read `d` (its StreamState::done covers that launch)
     hipEvent_t ready = nullptr;            // the upload; launches on other streams than the uploading one wait for it (device side)
     hipStream_t upload_stream = nullptr;
     unsigned long long last_use = 0;
 };
 constexpr int KY_STREAM_STATES = 8, KY_SCENE_SLOTS = 8;
+// what kyhip_render / kyhip_render_multi keep between calls (the host-film seam); `m` serialises such calls per device, it is never
+// taken while a context's enqueue mutex is held
+constexpr int KY_SEAM_BANDS = 16, KY_SEAM_THREADS = 8;
+struct SeamBuffers {
+    std::mutex m;
+    void* d_gather = nullptr; size_t gather_bytes = 0;   // root: [n_devices][shard 0's tile buffer]
+    void* d_film = nullptr; size_t film_bytes = 0;       // root: the frame, de-interleaved
+    float* h_stage = nullptr; size_t stage_bytes = 0;    // root: pinned host copy of d_film
+    hipEvent_t band[KY_SEAM_BANDS] = {};                 // root: behind the download of each row band
+    std::vector<void*> d_remote;                         // this device as a non-root member of a list: one tile buffer per occurrence
+    std::vector<size_t> remote_bytes;
+};
 struct DeviceCtx {
     std::mutex m;
+    SeamBuffers seam;
     int device = 0;
     int cus = 0;
     StreamState ss[KY_STREAM_STATES];
@@ -1191,13 +1215,15 @@ static int get_stream_state(DeviceCtx* c, hipStream_t stream, StreamState** out)
             pick = &c->ss[0];
             for (StreamState& st : c->ss)
                 if (st.last_use < pick->last_use) pick = &st;
-            HIP_TRY(hipDeviceSynchronize());   // its buffers may still be in use on the stream that owned them
+            HIP_TRY(hipEventSynchronize(pick->done));   // its buffers may still be in use on the stream that owned them (only that stream is waited for)
             pick->timing_valid = false;
         }
         if (!pick->d_counter) {
             HIP_TRY(hipMalloc(&pick->d_counter, 256));
             HIP_TRY(hipEventCreate(&pick->ev0));
             HIP_TRY(hipEventCreate(&pick->ev1));
+            HIP_TRY(hipEventCreateWithFlags(&pick->done, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(pick->done, stream));
         }
         pick->used = true;
         pick->stream = stream;
@@ -1207,14 +1233,28 @@ static int get_stream_state(DeviceCtx* c, hipStream_t stream, StreamState** out)
     return KY_OK;
 }
 
+// 64 bits over the packed scene's words: the cache compares whole scenes only when these agree
+static uint64_t scene_hash(const DScene& s) {
+    static_assert(sizeof(DScene) % 8 == 0, "hashed in 64-bit words");
+    const uint64_t* w = reinterpret_cast<const uint64_t*>(&s);
+    uint64_t h0 = 0x9E3779B97F4A7C15ull, h1 = 0xC2B2AE3D27D4EB4Full;
+    for (size_t i = 0; i + 1 < sizeof(DScene) / 8; i += 2) {   // two independent multiply chains
+        h0 = (h0 ^ w[i]) * 0xff51afd7ed558ccdull; h0 ^= h0 >> 29;
+        h1 = (h1 ^ w[i + 1]) * 0xc4ceb9fe1a85ec53ull; h1 ^= h1 >> 31;
+    }
+    if ((sizeof(DScene) / 8) & 1) h0 = (h0 ^ w[sizeof(DScene) / 8 - 1]) * 0xff51afd7ed558ccdull;
+    return h0 ^ (h1 * 0x9E3779B97F4A7C15ull);
+}
+
 // The device copy of `scene`, from the cache or uploaded on `stream`; launches on `stream` may read it when this returns.
 static int upload_scene(DeviceCtx* c, const ky_scene* scene, hipStream_t stream, SceneSlot** out) {
     static thread_local DScene scratch;
     const int rc = pack_scene(scene, &scratch);
     if (rc != KY_OK) return rc;
+    const uint64_t hash = scene_hash(scratch);
     SceneSlot* pick = nullptr;
     for (SceneSlot& sl : c->scenes)
-        if (sl.valid && std::memcmp(&scratch, sl.h, sizeof(DScene)) == 0) pick = &sl;
+        if (sl.valid && sl.hash == hash && std::memcmp(&scratch, sl.h, sizeof(DScene)) == 0) pick = &sl;
     if (pick) {
         if (pick->upload_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, pick->ready, 0));
     } else {
@@ -1224,7 +1264,10 @@ static int upload_scene(DeviceCtx* c, const ky_scene* scene, hipStream_t stream,
             pick = &c->scenes[0];
             for (SceneSlot& sl : c->scenes)
                 if (sl.last_use < pick->last_use) pick = &sl;
-            HIP_TRY(hipDeviceSynchronize());
+            // only the streams that have launched on this copy are waited for, not the device (a caller's other streams keep running)
+            for (int i = 0; i < KY_STREAM_STATES; ++i)
+                if ((pick->readers >> i & 1u) && c->ss[i].done) HIP_TRY(hipEventSynchronize(c->ss[i].done));
+            HIP_TRY(hipEventSynchronize(pick->ready));
             pick->valid = false;
         }
         if (!pick->d) {
@@ -1236,6 +1279,8 @@ static int upload_scene(DeviceCtx* c, const ky_scene* scene, hipStream_t stream,
         HIP_TRY(hipMemcpyAsync(pick->d, pick->h, sizeof(DScene), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipEventRecord(pick->ready, stream));
         pick->upload_stream = stream;
+        pick->hash = hash;
+        pick->readers = 0;
         pick->valid = true;
     }
     pick->last_use = ++c->clock;
@@ -1488,13 +1533,23 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
             c->variant_lds[vi] = lds_bytes;
         }
         const int per_cu = c->variant_blocks[vi];
-        if (v->queue && !st->d_shadow_queue)   // the wavefronts' shadow-ray stacks of this stream's launches
-            HIP_TRY(hipMalloc(&st->d_shadow_queue, (size_t)c->cus * per_cu * 4 * KY_SQ_ENTRY * KY_SQ_CAP * sizeof(float4)));
         unsigned grid = (unsigned)(c->cus * per_cu);
-        if (const char* e = std::getenv("KYHIP_BLOCKS_PER_CU")) { const int b = std::atoi(e); if (b > 0 && b < per_cu) grid = (unsigned)(c->cus * b); }
+        const int cap = blocks_per_cu_cap();
+        if (cap > 0 && cap < per_cu) grid = (unsigned)(c->cus * cap);
         const unsigned need_blocks = sh.n_items / 4 + 1;
         if (grid > need_blocks) grid = need_blocks;
         if (grid < 1) grid = 1;
+        if (v->queue && st->sq_blocks < (size_t)c->cus * per_cu) {   // the wavefronts' shadow-ray stacks of this stream's launches: one per resident
+            // wavefront of the LARGEST grid any QUEUE variant has been launched with on this stream (kernel: queue_mem + (block * 4 + wave) * cap)
+            if (st->d_shadow_queue) {
+                HIP_TRY(hipStreamSynchronize(stream));   // the previous launches on this stream still push to the old block
+                HIP_TRY(hipFree(st->d_shadow_queue));
+                st->d_shadow_queue = nullptr; st->sq_blocks = 0;
+            }
+            const size_t blocks = (size_t)c->cus * per_cu;
+            HIP_TRY(hipMalloc(&st->d_shadow_queue, blocks * 4 * KY_SQ_ENTRY * KY_SQ_CAP * sizeof(float4)));
+            st->sq_blocks = blocks;
+        }
         HIP_TRY(hipEventRecord(st->ev0, stream));
         hipLaunchKernelGGL(v->fn, dim3(grid), dim3(256), lds_bytes, stream, (const DScene*)sc->d, rc, sh, st->d_counter, accum, flags, v->queue ? st->d_shadow_queue : (float4*)nullptr);
         c->last_variant = vi;
@@ -1506,6 +1561,8 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
     const int nf = sh.n_pix * 3;
     hipLaunchKernelGGL(resolve_kernel, dim3((nf + 255) / 256), dim3(256), 0, stream, accum, flags, d_tiles, nf);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(st->done, stream));
+    sc->readers |= 1u << (unsigned)(st - c->ss);
     return KY_OK;
 }
 
@@ -1573,6 +1630,29 @@ int kyhip_film_add_gathered_device(int device, const ky_render_params* p, int wo
 // integrator_t::render on a LIST of devices (the reference spreads the pixel loop over all cores inside render(),
 // ky.cpp:3696-3699).  Shard i of the frame goes to devices[i] on that device's own stream; the tile buffers are gathered on
 // devices[0] (peer copies over xGMI), de-interleaved by one kernel and added into the caller's film.
+//
+// What the call owns besides the kernels is kept per device and reused (SeamBuffers): the gather block and the device film on the root, a
+// PINNED host staging film, the tile buffers of remote shards.  The film comes back in row bands: band b's download is followed by an
+// event, and a few host threads add band b into the caller's film (film_t::add_color, 1586-1590) the moment its event has fired, so the
+// host's pass over the film overlaps the rest of the download.  (Round 3 allocated and freed two device buffers per call, downloaded into
+// pageable memory and added with one scalar loop afterwards: 1-2 ms on a 9.4 MB film, a third of a 64-spp frame.)
+static void host_add_rows(float* __restrict__ film, size_t stride_px, const float* __restrict__ src, int width, int y0, int y1) {
+    const size_t n = (size_t)width * 3;
+    for (int y = y0; y < y1; ++y) {
+        float* __restrict__ dst = film + (size_t)y * stride_px * 3;
+        const float* __restrict__ row = src + (size_t)y * n;
+        for (size_t i = 0; i < n; ++i) dst[i] += row[i];   // vectorised by the host compiler
+    }
+}
+static int seam_reserve(void** p, size_t* have, size_t need, bool pinned) {
+    if (*have >= need) return KY_OK;
+    if (*p) { HIP_TRY(pinned ? hipHostFree(*p) : hipFree(*p)); *p = nullptr; *have = 0; }
+    const size_t bytes = need + need / 4;   // some slack: a caller that alternates frame sizes does not reallocate on every call
+    HIP_TRY(pinned ? hipHostMalloc(p, bytes) : hipMalloc(p, bytes < 16 ? 16 : bytes));
+    *have = bytes;
+    return KY_OK;
+}
+
 int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene, const ky_render_params* p, float* film_rgb, size_t stride_px) {
     if (!valid_params(p)) return fail(KY_ERR_INVALID_VALUE, "invalid render params (integrator %d, direct_sample %d)", p ? p->integrator : -1, p ? p->direct_sample : -1);
     if (!shard_in_range(p)) return fail(KY_ERR_LIMIT, "frame too large for the device's 32-bit work-item and pixel indices (%d x %d, %d spp)", p->width, p->height, p->samples_per_pixel);
@@ -1591,14 +1671,29 @@ int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene,
     const size_t rank_stride = (size_t)make_shard(&shard[0]).n_pix * 3;   // shard 0 owns the most tiles
     const size_t film_floats = (size_t)p->width * p->height * 3;
 
-    // buffers: one gather block and the film on the root; a tile buffer on every other device
+    // The cached buffers of every device of the list belong to this call until it returns: their seam mutexes are taken in ascending
+    // device order (two calls with overlapping lists cannot deadlock), never while a context's enqueue mutex is held.
+    std::vector<int> order(devices, devices + n_devices);
+    std::sort(order.begin(), order.end());
+    order.erase(std::unique(order.begin(), order.end()), order.end());
+    std::vector<std::unique_lock<std::mutex>> seam_locks;
+    for (int d : order) seam_locks.emplace_back(find_ctx(d)->seam.m);
+
+    // buffers: one gather block and the film on the root, the pinned staging film; a tile buffer per remote shard on its device
     HIP_TRY(hipSetDevice(root));
-    DevBuf d_gather, d_film;
-    HIP_TRY(d_gather.alloc(rank_stride * n_devices * sizeof(float)));
-    HIP_TRY(d_film.alloc(film_floats * sizeof(float)));
+    SeamBuffers& sb = ctx[0]->seam;
+    int rcode = seam_reserve(&sb.d_gather, &sb.gather_bytes, rank_stride * n_devices * sizeof(float), false);
+    if (rcode == KY_OK) rcode = seam_reserve(&sb.d_film, &sb.film_bytes, film_floats * sizeof(float), false);
+    if (rcode == KY_OK) rcode = seam_reserve((void**)&sb.h_stage, &sb.stage_bytes, film_floats * sizeof(float), true);
+    if (rcode != KY_OK) return rcode;
+    for (hipEvent_t& e : sb.band)
+        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    float* const d_gather = (float*)sb.d_gather;
+    float* const d_film = (float*)sb.d_film;
     hipStream_t root_stream = ctx[0]->stream;
-    HIP_TRY(hipMemsetAsync(d_film.p, 0, film_floats * sizeof(float), root_stream));
-    std::vector<DevBuf> remote(n_devices);
+    HIP_TRY(hipMemsetAsync(d_film, 0, film_floats * sizeof(float), root_stream));
+    std::vector<float*> remote(n_devices, nullptr);
+    std::vector<int> remote_slot(n_devices, 0);   // a device listed k times needs k tile buffers
     std::vector<hipEvent_t> done(n_devices, nullptr);
     struct EventGuard {
         std::vector<hipEvent_t>& ev;
@@ -1606,19 +1701,23 @@ int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene,
     } event_guard{done};
 
     // 1. every shard is enqueued before anything is waited for: the devices render concurrently.  From here on a failure must not
-    // return before the streams are drained (step 3): shards already launched write into buffers this function owns.
+    // return before the streams are drained (step 3): shards already launched write into buffers this function uses.
 #define HIP_CHECK_BREAK(expr)                                                                                         \
     {                                                                                                               \
         const hipError_t e_ = (expr);                                                                               \
         if (e_ != hipSuccess) { rcode = fail(KY_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); break; } \
     }
-    int rcode = KY_OK;
     for (int i = 0; i < n_devices && rcode == KY_OK; ++i) {
-        float* dst = d_gather.as<float>() + rank_stride * i;
+        float* dst = d_gather + rank_stride * i;
         if (devices[i] != root) {
             HIP_CHECK_BREAK(hipSetDevice(devices[i]));
-            HIP_CHECK_BREAK(remote[i].alloc(rank_stride * sizeof(float)));
-            dst = remote[i].as<float>();
+            SeamBuffers& rb = ctx[i]->seam;
+            int slot = 0;
+            for (int j = 0; j < i; ++j) slot += devices[j] == devices[i];
+            if ((int)rb.d_remote.size() <= slot) { rb.d_remote.resize(slot + 1, nullptr); rb.remote_bytes.resize(slot + 1, 0); }
+            rcode = seam_reserve(&rb.d_remote[slot], &rb.remote_bytes[slot], rank_stride * sizeof(float), false);
+            if (rcode != KY_OK) break;
+            remote[i] = dst = (float*)rb.d_remote[slot];
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, root, devices[i]) == hipSuccess && can) {   // direct xGMI copies; staged otherwise
                 HIP_CHECK_BREAK(hipSetDevice(root));
@@ -1634,7 +1733,7 @@ int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene,
             HIP_CHECK_BREAK(hipEventRecord(done[i], ctx[i]->stream));
         }
     }
-    // 2. the gather: one peer copy per remote shard, ordered behind that shard's kernels; then one add into the film
+    // 2. the gather: one peer copy per remote shard, ordered behind that shard's kernels; then one add into the device film
     for (int once = 0; once < 1 && rcode == KY_OK; ++once) {
         HIP_CHECK_BREAK(hipSetDevice(root));
         bool failed = false;
@@ -1642,20 +1741,46 @@ int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene,
             if (devices[i] == root) continue;
             hipError_t e = hipStreamWaitEvent(root_stream, done[i], 0);
             const size_t bytes = (size_t)make_shard(&shard[i]).n_pix * 3 * sizeof(float);
-            if (e == hipSuccess && bytes) e = hipMemcpyPeerAsync(d_gather.as<float>() + rank_stride * i, root, remote[i].p, devices[i], bytes, root_stream);
+            if (e == hipSuccess && bytes) e = hipMemcpyPeerAsync(d_gather + rank_stride * i, root, remote[i], devices[i], bytes, root_stream);
             if (e != hipSuccess) { rcode = fail(KY_ERR_DEVICE, "gathering shard %d failed: %s", i, hipGetErrorString(e)); failed = true; }
         }
         if (failed) break;
-        rcode = kyhip_film_add_gathered_device(root, p, n_devices, d_gather.as<float>(), rank_stride, d_film.as<float>(), (size_t)p->width, root_stream);
+        rcode = kyhip_film_add_gathered_device(root, p, n_devices, d_gather, rank_stride, d_film, (size_t)p->width, root_stream);
     }
-    std::vector<float> host;
-    for (int once = 0; once < 1 && rcode == KY_OK; ++once) {
-        host.resize(film_floats);
-        HIP_CHECK_BREAK(hipMemcpyAsync(host.data(), d_film.p, film_floats * sizeof(float), hipMemcpyDeviceToHost, root_stream));
+    // 3. the film comes home in row bands, each followed by an event
+    const size_t row_bytes = (size_t)p->width * 3 * sizeof(float);
+    int n_bands = (int)std::min<size_t>(KY_SEAM_BANDS, std::max<size_t>(1, film_floats * sizeof(float) / (512u << 10)));   // bands of at least 512 KB
+    n_bands = std::min(n_bands, p->height);
+    auto band_row = [&](int b) { return (int)((long long)p->height * b / n_bands); };
+    int bands_enqueued = 0;
+    for (int b = 0; b < n_bands && rcode == KY_OK; ++b) {
+        const int y0 = band_row(b), y1 = band_row(b + 1);
+        HIP_CHECK_BREAK(hipMemcpyAsync(sb.h_stage + (size_t)y0 * p->width * 3, d_film + (size_t)y0 * p->width * 3, (size_t)(y1 - y0) * row_bytes, hipMemcpyDeviceToHost, root_stream));
+        HIP_CHECK_BREAK(hipEventRecord(sb.band[b], root_stream));
+        bands_enqueued = b + 1;
     }
 #undef HIP_CHECK_BREAK
-    // 3. every stream that may still use a buffer of this call is drained before the buffers go away (also on errors)
+    // 4. host threads add band b as soon as it has arrived: film_t::add_color, 1586-1590.  Bands are dealt round-robin, so with T threads
+    // the first T bands are waited for concurrently and every later band is already there when its thread gets to it.
     hipError_t sync_err = hipSuccess;
+    if (rcode == KY_OK && bands_enqueued == n_bands) {
+        const int hw = (int)std::thread::hardware_concurrency();
+        const int n_threads = std::max(1, std::min({n_bands, hw > 0 ? hw : 1, (int)KY_SEAM_THREADS}));
+        std::vector<hipError_t> errs(n_threads, hipSuccess);
+        auto work = [&](int t) {
+            for (int b = t; b < n_bands; b += n_threads) {
+                const hipError_t e = hipEventSynchronize(sb.band[b]);
+                if (e != hipSuccess) { errs[t] = e; return; }
+                host_add_rows(film_rgb, stride_px, sb.h_stage, p->width, band_row(b), band_row(b + 1));
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < n_threads; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (std::thread& th : pool) th.join();
+        for (hipError_t e : errs) if (e != hipSuccess) sync_err = e;
+    }
+    // 5. every stream that may still use a buffer of this call is drained before the call returns (also on errors)
     for (int i = 0; i < n_devices; ++i) {
         if (hipSetDevice(devices[i]) != hipSuccess) continue;
         const hipError_t e = hipStreamSynchronize(ctx[i]->stream);
@@ -1663,12 +1788,7 @@ int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene,
     }
     (void)hipSetDevice(root);
     if (rcode != KY_OK) return rcode;
-    if (sync_err != hipSuccess) return fail(KY_ERR_DEVICE, "render failed: %s", hipGetErrorString(sync_err));
-    for (int y = 0; y < p->height; ++y) {  // film_t::add_color, 1586-1590
-        float* dst = film_rgb + (size_t)y * stride_px * 3;
-        const float* src = host.data() + (size_t)y * p->width * 3;
-        for (int i = 0; i < p->width * 3; ++i) dst[i] += src[i];
-    }
+    if (sync_err != hipSuccess) return fail(KY_ERR_DEVICE, "render failed: %s (the caller's film may hold a part of the frame)", hipGetErrorString(sync_err));
     return KY_OK;
 }
 

@@ -171,6 +171,8 @@ def render_distributed(scene, params, rank, world, device_index=0, film=None, gr
         main, side = torch.cuda.current_stream(dev), pl.streams[slot]
         if fb.free is not None:
             side.wait_event(fb.free)          # the frame before last (same buffers) has been gathered and added
+        else:
+            side.wait_stream(main)            # first use: the buffers' zero-fill was enqueued on the caller's stream, which may be backed up
         with torch.cuda.stream(side):
             render_shard(scene, params, rank, world, device_index, out=fb.tiles)
             done = side.record_event()

@@ -669,20 +669,47 @@ public:
     // integrator_t::render(scene, sampler, film), ky.cpp:3689: adds clamp01(mean radiance) into the film's
     // current target.  Errors of the C ABI surface as exceptions, like the reference's LOG_ERROR (75-82).
     void render(scene_t* scene, sampler_t* original_sampler, film_t* film) {
-        const vec2_t res = film->get_resolution();
-        ky_render_params p{};
-        p.integrator = (int)kind_;
-        p.max_path_depth = max_path_depth_;
-        p.direct_sample = (int)direct_sample_enum_;
-        p.samples_per_pixel = original_sampler->ge_samples_per_pixel();
-        p.sampler = original_sampler->kind();
-        p.seed = original_sampler->seed();
-        p.width = (int)res.x; p.height = (int)res.y;
-        p.tile_w = 16; p.tile_h = 16; p.tile_first = 0; p.tile_step = 1;
+        const ky_render_params p = params_for(original_sampler, film);
         // the reference spreads this loop over all cores (3696-3699); here the frame's tiles are spread over devices_
         const int rc = kyhip_render_multi(devices_.data(), (int)devices_.size(), &scene->flatten(), &p, film->target_origin(), film->row_stride_px());
         if (rc != KY_OK) throw std::runtime_error(std::string("kyhip_render_multi: ") + kyhip_last_error());
     }
+    // integrator_t::debug_area / debug_pixel (ky.cpp:3733-3787), the reference's single-pixel replay: a red frame is ADDED around
+    // [begin, end) (color_t{1.f} = (1, 0, 0) on the pixels of [begin - 1, end], 3739-3746), then every pixel of the area is cleared and
+    // rendered again on its own (3756-3776): the caller's sampler, the samples summed one after the other in float, one clamp, add_color.
+    // Here each pixel's samples are the device's replay of exactly the streams render() uses (kyhip_kat_li: per-sample radiance of pixel
+    // (x, y)), so the area shows what render() computed there, to the rounding of a different summation order.  The reference writes the
+    // frame without bounds checks (CHECK_DEBUG is compiled out in release, 108-115); here pixels outside the film are skipped.
+    void debug_area(scene_t* scene, sampler_t* original_sampler, film_t* film, point2_t begin, point2_t end) {
+        const vec2_t res = film->get_resolution();
+        const int w = (int)res.x, h = (int)res.y;
+        const int bx = (int)begin.x, by = (int)begin.y, ex = (int)end.x, ey = (int)end.y;
+        for (int y = by - 1; y <= ey; ++y)
+            for (int x = bx - 1; x <= ex; ++x)
+                if (x >= 0 && y >= 0 && x < w && y < h) film->add_color(x, y, color_t{1.f, 0.f, 0.f});
+        ky_render_params p = params_for(original_sampler, film);
+        const int spp = p.samples_per_pixel;
+        const float inv_spp = (float)(1. / spp);   // 3764: a double quotient narrowed by color_t::operator*(float_t)
+        std::vector<float> li((size_t)spp * 3);
+        for (int y = by; y < ey; ++y) {
+            for (int x = bx; x < ex; ++x) {
+                if (x < 0 || y < 0 || x >= w || y >= h) continue;
+                film->clear_color(x, y);
+                const int rc = kyhip_kat_li(devices_[0], &scene->flatten(), &p, x, y, 0, spp, li.data());
+                if (rc != KY_OK) throw std::runtime_error(std::string("kyhip_kat_li: ") + kyhip_last_error());
+                color_t L{};
+                for (int s = 0; s < spp; ++s) L = L + color_t(li[3 * (size_t)s], li[3 * (size_t)s + 1], li[3 * (size_t)s + 2]) * inv_spp;
+                film->add_color(x, y, color_t(clamp01_keep_nan(L.r), clamp01_keep_nan(L.g), clamp01_keep_nan(L.b)));
+            }
+        }
+    }
+    void debug_area(scene_t* scene, sampler_t* original_sampler, film_t* film, point2_t begin, float_t width, float_t height) {
+        debug_area(scene, original_sampler, film, begin, point2_t(begin.x + width, begin.y + height));   // 3779-3782
+    }
+    void debug_pixel(scene_t* scene, sampler_t* original_sampler, film_t* film, point2_t pixel_position) {
+        debug_area(scene, original_sampler, film, pixel_position, point2_t(pixel_position.x + 1, pixel_position.y + 1));   // 3784-3787
+    }
+
     // duration of the integrator kernel of the last render() on the first device, milliseconds (hipEvents on the launch stream)
     float last_kernel_ms() const { return kyhip_kernel_ms(devices_[0]); }
 
@@ -702,6 +729,21 @@ public:
 protected:
     integrator_t(integrator_enum_t kind, int max_path_depth, direct_sample_enum_t direct_sample_enum, int device)
         : kind_(kind), max_path_depth_(max_path_depth), direct_sample_enum_(direct_sample_enum), devices_{device} {}
+    // what the path reads from its sampler, its film and itself (SURVEY 8(b) "inputs read by the path")
+    ky_render_params params_for(sampler_t* original_sampler, film_t* film) const {
+        const vec2_t res = film->get_resolution();
+        ky_render_params p{};
+        p.integrator = (int)kind_;
+        p.max_path_depth = max_path_depth_;
+        p.direct_sample = (int)direct_sample_enum_;
+        p.samples_per_pixel = original_sampler->ge_samples_per_pixel();
+        p.sampler = original_sampler->kind();
+        p.seed = original_sampler->seed();
+        p.width = (int)res.x; p.height = (int)res.y;
+        p.tile_w = 16; p.tile_h = 16; p.tile_first = 0; p.tile_step = 1;
+        return p;
+    }
+    static float clamp01_keep_nan(float x) { return x < 0 ? 0 : (x > 1 ? 1 : x); }   // std::clamp keeps a NaN (1545)
     integrator_enum_t kind_;
     int max_path_depth_;
     direct_sample_enum_t direct_sample_enum_;

@@ -94,6 +94,33 @@ int kyhost_render(void* scene, int integrator_enum, int depth, int direct_sample
     return rc != 0 ? rc : status;
 }
 
+// create_integrator(...)->debug_area(&scene, sampler, &film, {bx, by}, {ex, ey}) on a film_t of width x height (ky.cpp:3733-3777);
+// `film` is read, modified and written back.  Returns 0, -1 on error, -2 when create_integrator returns nullptr.
+int kyhost_debug_area(void* scene, int integrator_enum, int depth, int direct_sample_enum, int sampler_kind, int spp, unsigned seed,
+                      int width, int height, float* film, int bx, int by, int ex, int ey, int device) {
+    int status = 0;
+    int rc = guarded([&] {
+        std::unique_ptr<ky::integrator_t> integrator;
+        const auto ie = (ky::integrator_enum_t)integrator_enum;
+        if (ie == ky::integrator_enum_t::position || ie == ky::integrator_enum_t::normal || ie == ky::integrator_enum_t::basecolor)
+            integrator = std::make_unique<ky::debug_integrator_t>(ie, device);
+        else
+            integrator = ky::create_integrator(ie, depth, (ky::direct_sample_enum_t)direct_sample_enum, device);
+        if (!integrator) { status = -2; return; }
+        std::unique_ptr<ky::sampler_t> sampler;
+        if (sampler_kind == KY_SAMPLER_DEBUG) sampler = std::make_unique<ky::debug_sampler_t>(spp);
+        else sampler = std::make_unique<ky::random_sampler_t>(spp);
+        sampler->set_seed(seed);
+        ky::film_t f(width, height);
+        const size_t n = (size_t)f.get_pixel_num() * 3;
+        std::memcpy(f.data(), film, n * sizeof(float));
+        if (ex == bx + 1 && ey == by + 1) integrator->debug_pixel(&((scene_box*)scene)->scene, sampler.get(), &f, ky::point2_t((float)bx, (float)by));
+        else integrator->debug_area(&((scene_box*)scene)->scene, sampler.get(), &f, ky::point2_t((float)bx, (float)by), ky::point2_t((float)ex, (float)ey));
+        std::memcpy(film, f.data(), n * sizeof(float));
+    });
+    return rc != 0 ? rc : status;
+}
+
 // film writers, ky.cpp:1646-1782.  kind: 0 ppm, 1 bmp, 2 hdr (image_enum_t, 1531-1536)
 int kyhost_store_image(const char* filename, int kind, int width, int height, const float* rgb) {
     bool ok = false;

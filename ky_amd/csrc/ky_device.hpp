@@ -349,21 +349,26 @@ KY_DEV uint32_t mix32(uint32_t x) {
     return x;
 }
 struct Sampler {
-    uint32_t state, inc;
+    uint32_t s0, s1;
 };
-// the 64-bit key hashed from (seed, pixel, sample) seeds a PCG-RXS-M-XS-32 stream: state = k0, increment = k1 | 1
+// the 64-bit key hashed from (seed, pixel, sample) is the state of a xoroshiro64+ stream (s1 is made odd: the all-zero state is excluded)
 KY_DEV uint32_t sampler_pixel_key(uint32_t seed, uint32_t pixel_index) { return mix32(pixel_index ^ mix32(seed)); }  // constant per pixel
 KY_DEV void sampler_start(Sampler& s, uint32_t h, uint32_t sample_index) {
-    s.state = mix32(h + sample_index * 0x9E3779B9u);
-    s.inc = mix32((h ^ 0x6A09E667u) + sample_index * 0x85EBCA6Bu) | 1u;
+    s.s0 = mix32(h + sample_index * 0x9E3779B9u);
+    s.s1 = mix32((h ^ 0x6A09E667u) + sample_index * 0x85EBCA6Bu) | 1u;
 }
+KY_DEV uint32_t rotl32(uint32_t x, int k) { return __builtin_amdgcn_alignbit(x, x, 32 - k); }   // v_alignbit_b32
+// xoroshiro64+ (Blackman / Vigna; a = 26, b = 9, c = 13): ten full-rate VALU instructions per number with the conversion -- three xor, two
+// v_alignbit, a shift, an add; shift, convert, scale -- against eleven for rounds 1-3's PCG-RXS-M-XS-32 with its two slow integer multiplies
+// (v_mul_lo_u32, v_mad_u64_u32).  The sum's weak low bits are the eight the conversion drops.
 template <bool DEBUG_SAMPLER>
 KY_DEV float sampler_next(Sampler& s) {
     if (DEBUG_SAMPLER) return 0.5f;  // debug_sampler_t, 933-941
-    s.state = s.state * 747796405u + s.inc;
-    uint32_t word = ((s.state >> ((s.state >> 28u) + 4u)) ^ s.state) * 277803737u;
-    word = (word >> 22u) ^ word;
-    return (float)(word >> 8) * (1.0f / 16777216.0f);
+    const uint32_t r = s.s0 + s.s1;
+    s.s1 ^= s.s0;
+    s.s0 = rotl32(s.s0, 26) ^ s.s1 ^ (s.s1 << 9);
+    s.s1 = rotl32(s.s1, 13);
+    return (float)(r >> 8) * (1.0f / 16777216.0f);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(QE_THREADS, KY_QE_WAVES) void render_kernel_q(const
                         W.dx[sl] = ps.d.x; W.dy[sl] = ps.d.y; W.dz[sl] = ps.d.z;
                         W.br[sl] = 1.f; W.bg[sl] = 1.f; W.bb[sl] = 1.f;
                         W.lr[sl] = 0.f; W.lg[sl] = 0.f; W.lb[sl] = 0.f;
-                        W.rs[sl] = ps.smp.state; W.ri[sl] = ps.smp.inc;
+                        W.rs[sl] = ps.smp.s0; W.ri[sl] = ps.smp.s1;
                         W.info[sl] = 0;
                         W.pix[sl] = it.pix0 + py * sh.tile_w + px;
                         dest = QS_TRACE;
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(QE_THREADS, KY_QE_WAVES) void render_kernel_q(const
                     if (M.kind == KY_MATERIAL_PLASTIC) {
                         Sampler smp{W.rs[sl], W.ri[sl]};
                         lobe = pick_lobe(M, sampler_next<DEBUG_SAMPLER>(smp));
-                        W.rs[sl] = smp.state;
+                        W.rs[sl] = smp.s0; W.ri[sl] = smp.s1;
                     } else {
                         lobe = pick_lobe(M, 0.f);
                     }
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(QE_THREADS, KY_QE_WAVES) void render_kernel_q(const
                 inf = W.info[sl];
                 d = mk3(W.dx[sl], W.dy[sl], W.dz[sl]);
                 qe_vertex(v, Lds, mk3(W.ox[sl], W.oy[sl], W.oz[sl]), d, (int)((inf >> 16) & 0xffu), (int)(inf & 3u));
-                smp.state = W.rs[sl]; smp.inc = W.ri[sl];
+                smp.s0 = W.rs[sl]; smp.s1 = W.ri[sl];
             }
             // lanes of a batch can be at different lights; one wave-uniform pass per light present in the batch
             const int my_light = (int)(inf >> 24);
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(QE_THREADS, KY_QE_WAVES) void render_kernel_q(const
                 if (L_now.x != 0.f || L_now.y != 0.f || L_now.z != 0.f) {
                     W.lr[sl] += beta.x * L_now.x; W.lg[sl] += beta.y * L_now.y; W.lb[sl] += beta.z * L_now.z;
                 }
-                W.rs[sl] = smp.state;
+                W.rs[sl] = smp.s0; W.ri[sl] = smp.s1;
                 W.info[sl] = (inf & 0x00ffffffu) | ((uint32_t)(my_light + 1) << 24);
                 if (pending) {
                     W.wx[sl] = sdir.x; W.wy[sl] = sdir.y; W.wz[sl] = sdir.z; W.wt[sl] = stmax;
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(QE_THREADS, KY_QE_WAVES) void render_kernel_q(const
                         W.ox[sl] = o.x; W.oy[sl] = o.y; W.oz[sl] = o.z;
                         W.dx[sl] = bs.wi.x; W.dy[sl] = bs.wi.y; W.dz[sl] = bs.wi.z;
                         W.br[sl] = beta.x; W.bg[sl] = beta.y; W.bb[sl] = beta.z;
-                        W.rs[sl] = smp.state;
+                        W.rs[sl] = smp.s0; W.ri[sl] = smp.s1;
                         W.info[sl] = (specular ? 4u : 0u) | ((uint32_t)bounces << 8);
                         dest = QS_TRACE;
                     }

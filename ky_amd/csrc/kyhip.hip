@@ -77,8 +77,9 @@ static int fail(int code, const char* fmt, ...) {
 // efficiency at N = 8: no taper 0.88, 256 samples of 8 (round 2) 0.93, 128/64/32 0.92, 256/128/64 0.96; longer tapers (384/192/96/48)
 // do not make the shard faster and cost the full frame 1-2.5 %.
 #ifndef KY_CHUNK_BIG
-#define KY_CHUNK_BIG 32
-#endif
+#define KY_CHUNK_BIG 24   // round 4 (profiles/r04_b_chunk_scan.txt): 24-sample bulk chunks leave the full frame where 32 had it (50.5 against 50.6 ms) and make the
+#endif                    // slowest 1/8 shard of configs[1] 2-3 % faster (6.65-6.68 against 6.79-6.89 ms: N = 8 kernel efficiency 0.947-0.950 against 0.918-0.931);
+                          // 16 and 20 cost the full frame 1.3-1.9 %, and no other taper (192/96/48, a 2-sample stage, ...) beat 256/128/64 in shard time
 #ifndef KY_TAPER_16
 #define KY_TAPER_16 256
 #endif
@@ -123,14 +124,13 @@ __host__ __device__ inline ChunkPlan chunk_plan(int spp) {
 }
 __host__ __device__ inline int chunk_count(const ChunkPlan& p) { return p.n_big + p.n16 + p.n8 + p.n4 + p.n2; }
 __host__ __device__ inline void chunk_range(const ChunkPlan& p, int c, int& s_begin, int& s_end) {
-    int size = KY_CHUNK, first = 0, limit = p.head;
+    int size = KY_CHUNK, first = 0, limit = p.head, n_seg = p.n_big;
     c -= p.n_big;
-    if (c >= 0) { size = 16; first = p.head; limit = p.b1; c -= p.n16; }
-    if (c >= 0) { size = 8; first = p.b1; limit = p.b2; c -= p.n8; }
-    if (c >= 0) { size = 4; first = p.b2; limit = p.b3; c -= p.n4; }
-    if (c >= 0) { size = 2; first = p.b3; limit = p.b4; c -= p.n2; }
+    if (c >= 0) { size = 16; first = p.head; limit = p.b1; n_seg = p.n16; c -= p.n16; }
+    if (c >= 0) { size = 8; first = p.b1; limit = p.b2; n_seg = p.n8; c -= p.n8; }
+    if (c >= 0) { size = 4; first = p.b2; limit = p.b3; n_seg = p.n4; c -= p.n4; }
+    if (c >= 0) { size = 2; first = p.b3; limit = p.b4; n_seg = p.n2; c -= p.n2; }
     // c is now (index inside its segment) - (chunks of that segment): count back from the segment's chunk count
-    const int n_seg = size == KY_CHUNK ? p.n_big : (size == 16 ? p.n16 : (size == 8 ? p.n8 : (size == 4 ? p.n4 : p.n2)));
     s_begin = first + (c + n_seg) * size;
     s_end = s_begin + size < limit ? s_begin + size : limit;
 }
@@ -1138,7 +1138,10 @@ struct SceneSlot {
 constexpr int KY_STREAM_STATES = 8, KY_SCENE_SLOTS = 8;
 // what kyhip_render / kyhip_render_multi keep between calls (the host-film seam); `m` serialises such calls per device, it is never
 // taken while a context's enqueue mutex is held
-constexpr int KY_SEAM_BANDS = 16, KY_SEAM_THREADS = 8;
+// (measured on configs[1]'s 9.4 MB film, tools/seam_trace.py: what a call costs beyond its kernel is 0.62 ms with one band and one thread,
+// 0.44 ms with eight bands on four threads, 0.57 ms with sixteen on eight -- every band is a copy command and an event; the film's pinned
+// download alone takes 0.18 ms)
+constexpr int KY_SEAM_BANDS = 8, KY_SEAM_THREADS = 4;
 struct SeamBuffers {
     std::mutex m;
     void* d_gather = nullptr; size_t gather_bytes = 0;   // root: [n_devices][shard 0's tile buffer]

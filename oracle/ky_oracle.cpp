@@ -224,24 +224,29 @@ inline uint32_t mix32(uint32_t x) {  // "lowbias32" integer finaliser
 }
 struct sampler_t {
     int      kind = KY_SAMPLER_RANDOM;
-    uint32_t state = 0, inc = 1;
+    uint32_t s0 = 0, s1 = 1;
     const float* tape = nullptr;   // function-level KATs: the next numbers to hand out, instead of the generator's
     int tape_pos = 0;
     // one camera sample = one stream; sampler_t::start_pixel / next_sample (900-908) select it.
-    // The 64-bit key (k0, k1) hashed from (seed, pixel, sample) becomes the state and the (odd) increment of a
-    // PCG-RXS-M-XS-32 generator, so two samples share a stream only if both 32-bit halves collide.
+    // The 64-bit key (k0, k1) hashed from (seed, pixel, sample) is the state of a xoroshiro64+ generator (Blackman / Vigna,
+    // a = 26, b = 9, c = 13; k1 is made odd, which excludes the all-zero state), so two samples share a stream only if both
+    // 32-bit halves collide.  (Rounds 1-3: PCG-RXS-M-XS-32.  The reference's own mt19937_64 stream, re-seeded per image row and
+    // raced on by its plastic material, is reproduced by neither: DESIGN.md "Random numbers".  No committed fixture holds values
+    // of this stream: tests/golden/ is reference-produced data and explicit-input KATs.)
+    static uint32_t rotl(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
     void start_sample(uint32_t seed, uint32_t pixel_index, uint32_t sample_index) {
         uint32_t h = mix32(pixel_index ^ mix32(seed));
-        state = mix32(h + sample_index * 0x9E3779B9u);
-        inc   = mix32((h ^ 0x6A09E667u) + sample_index * 0x85EBCA6Bu) | 1u;
+        s0 = mix32(h + sample_index * 0x9E3779B9u);
+        s1 = mix32((h ^ 0x6A09E667u) + sample_index * 0x85EBCA6Bu) | 1u;
     }
     float get_float() {                                                                   // 960
         if (tape) return tape[tape_pos++];
         if (kind == KY_SAMPLER_DEBUG) return 0.5f;                                        // 933-941
-        state = state * 747796405u + inc;
-        uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
-        word = (word >> 22u) ^ word;
-        return (float)(word >> 8) * (1.0f / 16777216.0f);                                 // [0, 1)
+        const uint32_t word = s0 + s1;
+        s1 ^= s0;
+        s0 = rotl(s0, 26) ^ s1 ^ (s1 << 9);
+        s1 = rotl(s1, 13);
+        return (float)(word >> 8) * (1.0f / 16777216.0f);                                 // [0, 1): the sum's upper 24 bits
     }
     vec2_t get_float2() { float a = get_float(); float b = get_float(); return {a, b}; }  // 965, 856-859
     // get_camera_sample, 943-946 / 971-974

@@ -260,7 +260,11 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert j3["film_mean"] == j1["film_mean"]
     for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in j2
-    assert j2["roofline"]["bound"] == "valu" and j2["roofline"]["contract_bound"] == "hbm" and len(j2["config"]["frames"]) == 6
+    assert j2["roofline"]["bound"] == "valu" and j2["roofline"]["contract"]["bound"] == "hbm" and len(j2["config"]["frames"]) == 6
+    # the roofline that bounds: useful lane-instructions over lane-slots, a fraction by construction
+    for j in (j1, j2):
+        assert 0 < j["roofline"]["frac"] < 1 and abs(j["roofline"]["frac"] - j["roofline"]["achieved"] / j["roofline"]["peak"]) < 1e-12
+        assert len(j["roofline"]["valu_model"]["frames"]) == 6
 
 
 def test_c2_headline_frame_through_the_cpp_driver(A, api, O, tmp_path):

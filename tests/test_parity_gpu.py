@@ -11,7 +11,7 @@ Tolerances (fp32 path; the GPU contracts a*b+c into FMAs and uses the ROCm devic
 import numpy as np
 import pytest
 
-from helpers import random_rays, rmse, unit
+from helpers import explain_pixel, random_rays, rmse, rmse_with_explained_flips, unit
 
 pytestmark = pytest.mark.gpu
 
@@ -60,6 +60,21 @@ def test_kat_shape_intersect(name, A, api, O, rng):
     disagree = g[:, 0] != c[:, 0]
     assert both.sum() > 200
     assert disagree.mean() < 2e-3, disagree.sum()
+    # every hit-flag disagreement must be a TIE: the oracle itself gives the GPU's flag when the ray is moved by 3e-5 (an edge of the shape, a
+    # silhouette, a hit at epsilon or at tmax, a ray in the shape's plane) -- nothing else may differ
+    eps = 3e-5
+    for i in np.flatnonzero(disagree):
+        found = False
+        for _ in range(64):
+            r = rays[i].copy()
+            r[0:3] += eps * rng.uniform(-1, 1, 3).astype(np.float32)
+            r[3:6] = unit(r[3:6] + eps * rng.uniform(-1, 1, 3)).astype(np.float32)
+            if np.isfinite(r[6]):
+                r[6] *= 1 + eps * rng.uniform(-1, 1)
+            if O.kat_intersect(shape, r[None])[0, 0] == g[i, 0]:
+                found = True
+                break
+        assert found, ("hit flag differs away from any threshold", name, rays[i], g[i], c[i])
     assert_close_q(g[both, 1:], c[both, 1:], 2e-5)
 
 
@@ -91,7 +106,9 @@ def test_kat_bsdf(which, A, api, O, rng):
          "plastic5000": vs.c.materials[2]}[which]
     x = bsdf_inputs(rng, 4096)
     g, c = api.kat_bsdf(m, x), O.kat_bsdf(m, x)
-    assert np.array_equal(g[:, 7], c[:, 7]) or (g[:, 7] != c[:, 7]).mean() < 1e-3   # sampled lobe flags
+    # sampled lobe flags: identical, except where one random number sits on a branch probability (glass: u0 against the Fresnel term, which the two
+    # arithmetics round differently in the last bit; plastic: lobe_u against P_spec).  Measured: 0 of 4096 rows for every material.
+    assert (g[:, 7] != c[:, 7]).mean() <= (1e-3 if which in ("glass", "plastic90", "plastic5000") else 0.0), (which, int((g[:, 7] != c[:, 7]).sum()))
     assert np.array_equal(g[:, 12], c[:, 12])                                        # is_delta
     same = g[:, 7] == c[:, 7]
     rtol = 2e-2 if which == "plastic5000" else (2e-3 if which == "plastic90" else 2e-4)
@@ -102,8 +119,9 @@ def test_kat_bsdf(which, A, api, O, rng):
     err = np.abs(g[fin] - c[fin]) / scale
     cols = [0, 1, 2, 6, 8, 9, 10, 11]
     assert np.quantile(err[:, cols], 0.999) < rtol, np.quantile(err[:, cols], 0.999)
-    if which == "glass":
-        assert (c[:, 6] == 0).sum() > 0 or True  # TIR rows are allowed (f = 0, pdf = 0)
+    if which == "glass":   # total internal reflection in the refraction branch (f = 0, pdf = 0, 2404-2409) must be the same rows on both sides
+        tir_c, tir_g = (c[:, 6] == 0) & (c[:, 7] == c[:, 7]), (g[:, 6] == 0)
+        assert np.array_equal(tir_c[same], tir_g[same])
 
 
 def light_inputs(rng, n, box=1.2):
@@ -421,8 +439,14 @@ def test_general_shapes_scene(strategy, A, api, O):
     params = api.make_params(W, H, 128, direct_sample=strategy)
     pixels = [(24, 20), (6, 30), (40, 30), (24, 4), (10, 10), (36, 12), (30, 34), (16, 26)]
     bad, tot, sg, sc = li_agreement(api, O, scene, params, pixels)
-    assert bad <= 0.03 * tot, (bad, tot)
-    assert abs(sg - sc) <= 0.03 * max(sc, 1.0)
+    # measured (round 4, tools/measure_tolerances.py): 0 of 1024 samples differ for every strategy, the sums agree to 1e-8: the bound is 0.2 %,
+    # and whatever differs must be explained vertex by vertex (helpers.explain_pixel: a recorded decision differs first, or the difference
+    # starts at a specular / Phong vertex; a sample that is merely off fails there)
+    assert bad <= 0.002 * tot, (bad, tot)
+    assert abs(sg - sc) <= 1e-3 * max(sc, 1.0)
+    if bad:
+        for (x, y) in pixels:
+            explain_pixel(api, O, scene, params, x, y)
     if strategy == 48:
         p = api.make_params(W, H, 512, tile_w=16, tile_h=8)
         g, c = api.render(scene, p), O.render(scene, p)
@@ -459,8 +483,11 @@ def test_recursive_integrators(flag, integrator, A, api, O):
         pixels = [(32, 32), (5, 5), (21, 42), (44, 45), (60, 61), (32, 4), (18, 50), (46, 52)]
     params = api.make_params(W, H, 128, integrator=integrator)
     bad, tot, sg, sc = li_agreement(api, O, scene, params, pixels)
-    assert bad <= 0.03 * tot, (bad, tot)
-    assert abs(sg - sc) <= 0.03 * max(sc, 1.0)
+    # measured (round 4, tools/measure_tolerances.py): Cornell 0 or 1 of 1024 samples, sums to 3e-6; Veach up to 8 of 768 (1.04 %: the sphere lights'
+    # self-occlusion threshold, quirk 1, like the iterative integrator's 0.9 %), sums to 2.2e-4.  Bounds: measured + 0.2 %.  (The vertex trace that
+    # explains single samples follows path_tracing_iteration_t only; tests/test_mismatch_gpu.py does that for the estimators these integrators share.)
+    assert bad <= (0.0125 if flag == "veach" else 0.003) * tot, (bad, tot)
+    assert abs(sg - sc) <= 1e-3 * max(sc, 1.0)
     if flag in ("area", "veach"):
         p = api.make_params(W, H, 256, integrator=integrator, tile_w=16, tile_h=8)
         g, c = api.render(scene, p), O.render(scene, p)
@@ -512,9 +539,10 @@ def test_engines_agree(A, api):
             assert np.array_equal(b, b2)                       # scheduling does not show in the image
             # same arithmetic per sample, but the two kernels inline it into different surroundings (fp contraction can differ
             # by an ulp per term) and sum a pixel's samples (unclamped, up to the light's radiance) in different orders: ~1e-5 on the clamped mean.
-            # The Veach planks' exponent-5000 lobe turns an ulp of cos(alpha) into 6e-4 of its value: 1e-4 there (measured 6.8e-5)
+            # The Veach planks' exponent-5000 lobe turns an ulp of cos(alpha) into 6e-4 of its value, and one such sample is 1 / spp of a pixel
+            # that sees up to 900 of radiance: 4e-4 there (measured: 6.8e-5 on the streams of rounds 1-3, 1.8e-4 -- the 24-spp bsdf_mis frame -- on round 4's)
             veach = scene.c.light_count == 5
-            assert np.abs(a - b).max() <= (1e-4 if veach else 2e-5), (p.samples_per_pixel, p.direct_sample, float(np.abs(a - b).max()))
+            assert np.abs(a - b).max() <= (4e-4 if veach else 2e-5), (p.samples_per_pixel, p.direct_sample, float(np.abs(a - b).max()))
             if p.integrator != A.INTEGRATOR_PATH_TRACING_ITERATION:
                 assert np.array_equal(a, b)
     finally:
@@ -577,10 +605,13 @@ def test_edge_cases(A, api, O):
     # three such pixels, RMSE 5.6e-3; without them 6e-5).  Sample-by-sample explanations are the business of tests/test_mismatch_gpu.py on
     # scenes whose spheres are not 0.05 across; here: the film tolerance without the (at most 8) pixels that are off by more than 0.05,
     # and twice the tolerance with them.
-    d = np.abs(g.astype(np.float64) - c).max(axis=2)
-    flips = d > 0.05
-    assert g.mean() > 0.05 and flips.sum() <= 8, int(flips.sum())
-    assert rmse(g[~flips], c[~flips]) < film_tolerance(64) and rmse(g, c) < 2 * film_tolerance(64), (rmse(g[~flips], c[~flips]), rmse(g, c))
+    # Every pixel set aside is examined sample by sample (helpers.explain_pixel): each differing sample must differ first in a recorded decision or
+    # at / after a specular or Phong vertex.  Tolerances for equal decisions are wide here: a sphere 0.05 across turns the 1e-5 rounding of a hit
+    # point into 2e-4 of its normal and a bounce between two of them squares that (measured: a sample that takes the same decisions at every
+    # vertex and ends 0.4 % apart), so "the same path" means 1 % on throughput and radiance, 5e-3 on geometry.
+    e_without, e_with, n_exempt = rmse_with_explained_flips(api, O, full, p, g, c, max_exempt=12, threshold=0.05, value_tol=1e-2, geom_tol=5e-3)
+    assert g.mean() > 0.05 and (np.abs(g.astype(np.float64) - c).max(axis=2) > 0.05).sum() <= 12
+    assert e_without < film_tolerance(64) and e_with < 2 * film_tolerance(64), (e_without, e_with, n_exempt)
     assert "scene-sized LDS block" in lib.kyhip_last_kernel(0).decode()
     too_many = CustomScene(A, cam40, shapes, mats, lights, surfaces)
     film = np.zeros((24, 40, 3), np.float32)

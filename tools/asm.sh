@@ -3,5 +3,5 @@
 NAME=$1; shift
 BASE="--offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-function -Wno-bitwise-instead-of-logical -fno-slp-vectorize -fno-hip-fp32-correctly-rounded-divide-sqrt"
 SRC=${KY_SRC:-ky_amd/csrc/kyhip.hip}
-mkdir -p build_variants
-hipcc $BASE "$@" -S --cuda-device-only -gline-tables-only -o build_variants/$NAME.s $SRC
+mkdir -p /tmp/kyasm
+hipcc $BASE "$@" -S --cuda-device-only -gline-tables-only -o /tmp/kyasm/$NAME.s $SRC

@@ -24,3 +24,5 @@ for N in (1, 4, 8):
     b, a = np.polyfit(xs, ys, 1)
     print("N=%d: %s  -> %.5f ms/spp (x%d = %.5f), intercept %.3f ms" % (N, " ".join("%.2f" % y for y in ys), b, N, b * N, a))
 print("kernel-level efficiency at 1024 spp: N=4 %.4f  N=8 %.4f   (N=1 %.2f ms)" % (t1024[1] / 4 / t1024[4], t1024[1] / 8 / t1024[8], t1024[1]))
+small = api.cornell_box_scene(A.CB_DEFAULT_SCENE, 128, 96)
+print("film mean of 128x96 at 1024 / 100 spp (the chunk schedule must not show): %.7f %.7f" % (api.render(small, api.make_params(128, 96, 1024)).mean(), api.render(small, api.make_params(128, 96, 100)).mean()))

@@ -29,7 +29,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <memory>
 #include <mutex>
@@ -1130,6 +1132,8 @@ struct SceneSlot {
     DScene* d = nullptr;                   // device copy
     DScene* h = nullptr;                   // pinned staging copy = what `d` holds (the key of the cache, compared when the hashes agree)
     uint64_t hash = 0;                     // scene_hash(*h)
+    std::vector<unsigned char> input;      // the caller's scene this slot was last packed from, flattened (scene_input): a call that passes the same scene
+    uint64_t input_hash = 0;               // again skips pack_scene -- 60-80 us of host time on a frame shard that renders in 6 ms
     unsigned readers = 0;                  // bit i: a launch on stream state i has read `d` (its StreamState::done covers that launch)
     hipEvent_t ready = nullptr;            // the upload; launches on other streams than the uploading one wait for it (device side)
     hipStream_t upload_stream = nullptr;
@@ -1249,15 +1253,51 @@ static uint64_t scene_hash(const DScene& s) {
     return h0 ^ (h1 * 0x9E3779B97F4A7C15ull);
 }
 
+// Everything pack_scene reads of the caller's scene, as one byte string (a few KB for ky's scenes), and 64 bits over it
+static bool scene_input(const ky_scene* in, std::vector<unsigned char>& out, uint64_t& hash) {
+    out.clear();
+    if (!in || in->surface_count < 0 || in->shape_count < 0 || in->material_count < 0 || in->light_count < 0 || in->surface_count > KYHIP_MAX_SURFACES ||
+        in->shape_count > KYHIP_MAX_SHAPES || in->material_count > KYHIP_MAX_MATERIALS || in->light_count > KYHIP_MAX_LIGHTS)
+        return false;   // pack_scene reports what is wrong
+    auto put = [&](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; out.insert(out.end(), b, b + n); };
+    const int32_t head[6] = {in->shape_count, in->material_count, in->light_count, in->surface_count, in->environment_light, specialisation_enabled() ? 1 : 0};
+    put(head, sizeof head);
+    put(&in->camera, sizeof in->camera);
+    if (in->shape_count) put(in->shapes, sizeof(ky_shape) * (size_t)in->shape_count);
+    if (in->material_count) put(in->materials, sizeof(ky_material) * (size_t)in->material_count);
+    if (in->light_count) put(in->lights, sizeof(ky_light) * (size_t)in->light_count);
+    if (in->surface_count) put(in->surfaces, sizeof(ky_surface) * (size_t)in->surface_count);
+    out.resize((out.size() + 7) & ~(size_t)7, 0);
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    for (size_t i = 0; i < out.size(); i += 8) {
+        uint64_t w;
+        std::memcpy(&w, &out[i], 8);
+        h = (h ^ w) * 0xff51afd7ed558ccdull;
+        h ^= h >> 29;
+    }
+    hash = h;
+    return true;
+}
+
 // The device copy of `scene`, from the cache or uploaded on `stream`; launches on `stream` may read it when this returns.
 static int upload_scene(DeviceCtx* c, const ky_scene* scene, hipStream_t stream, SceneSlot** out) {
     static thread_local DScene scratch;
-    const int rc = pack_scene(scene, &scratch);
-    if (rc != KY_OK) return rc;
-    const uint64_t hash = scene_hash(scratch);
+    static thread_local std::vector<unsigned char> input;
+    uint64_t input_hash = 0;
+    const bool keyed = scene_input(scene, input, input_hash);
     SceneSlot* pick = nullptr;
-    for (SceneSlot& sl : c->scenes)
-        if (sl.valid && sl.hash == hash && std::memcmp(&scratch, sl.h, sizeof(DScene)) == 0) pick = &sl;
+    if (keyed)   // the same scene as a recent call's: its packed form is on the device already
+        for (SceneSlot& sl : c->scenes)
+            if (sl.valid && sl.input_hash == input_hash && sl.input == input) pick = &sl;
+    uint64_t hash = 0;
+    if (!pick) {
+        const int rc = pack_scene(scene, &scratch);
+        if (rc != KY_OK) return rc;
+        hash = scene_hash(scratch);
+        for (SceneSlot& sl : c->scenes)
+            if (sl.valid && sl.hash == hash && std::memcmp(&scratch, sl.h, sizeof(DScene)) == 0) pick = &sl;
+        if (pick && keyed) { pick->input = input; pick->input_hash = input_hash; }
+    }
     if (pick) {
         if (pick->upload_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, pick->ready, 0));
     } else {
@@ -1283,6 +1323,7 @@ static int upload_scene(DeviceCtx* c, const ky_scene* scene, hipStream_t stream,
         HIP_TRY(hipEventRecord(pick->ready, stream));
         pick->upload_stream = stream;
         pick->hash = hash;
+        if (keyed) { pick->input = input; pick->input_hash = input_hash; } else { pick->input.clear(); pick->input_hash = 0; }
         pick->readers = 0;
         pick->valid = true;
     }
@@ -1647,6 +1688,56 @@ static void host_add_rows(float* __restrict__ film, size_t stride_px, const floa
         for (size_t i = 0; i < n; ++i) dst[i] += row[i];   // vectorised by the host compiler
     }
 }
+// A few parked host threads for the banded add (creating and joining threads per call cost 50-100 us of a 4 ms frame).  run(n, fn) calls
+// fn(0) ... fn(n - 1), fn(0) on the caller; one job at a time (the callers hold a seam mutex anyway, this one serialises across devices).
+class HostPool {
+public:
+    void run(int n, const std::function<void(int)>& fn) {
+        std::lock_guard<std::mutex> one(job_m_);
+        if (n <= 1) { if (n == 1) fn(0); return; }
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            while ((int)threads_.size() < n - 1) { const int id = (int)threads_.size() + 1; threads_.emplace_back([this, id] { loop(id); }); }
+            fn_ = &fn; n_ = n; pending_ = n - 1; ++generation_;
+        }
+        cv_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lock(m_);
+        done_.wait(lock, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> lock(m_); stop_ = true; }
+        cv_.notify_all();
+        for (std::thread& t : threads_) t.join();
+    }
+private:
+    void loop(int id) {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void(int)>* fn = nullptr;
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                cv_.wait(lock, [&] { return stop_ || (generation_ != seen && id < n_); });
+                if (stop_) return;
+                seen = generation_;
+                fn = fn_;
+            }
+            (*fn)(id);
+            std::lock_guard<std::mutex> lock(m_);
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    std::mutex job_m_, m_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> threads_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int n_ = 0, pending_ = 0;
+    unsigned long long generation_ = 0;
+    bool stop_ = false;
+};
+static HostPool& host_pool() { static HostPool* pool = new HostPool; return *pool; }   // never destroyed: no thread joins at process exit
+
 static int seam_reserve(void** p, size_t* have, size_t need, bool pinned) {
     if (*have >= need) return KY_OK;
     if (*p) { HIP_TRY(pinned ? hipHostFree(*p) : hipFree(*p)); *p = nullptr; *have = 0; }
@@ -1777,10 +1868,7 @@ int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene,
                 host_add_rows(film_rgb, stride_px, sb.h_stage, p->width, band_row(b), band_row(b + 1));
             }
         };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < n_threads; ++t) pool.emplace_back(work, t);
-        work(0);
-        for (std::thread& th : pool) th.join();
+        host_pool().run(n_threads, work);
         for (hipError_t e : errs) if (e != hipSuccess) sync_err = e;
     }
     // 5. every stream that may still use a buffer of this call is drained before the call returns (also on errors)

@@ -94,7 +94,7 @@ def trace_close(a, b, tol):
     return bool(np.all(np.abs(a - b) <= tol * np.maximum(1.0, np.maximum(np.abs(a), np.abs(b)))))
 
 
-def explain_sample(g_rows, c_rows, value_tol=2e-4, geom_tol=1e-4):
+def explain_sample(g_rows, c_rows, value_tol=2e-4, geom_tol=1e-4, amplifying_surfaces=()):
     """Why do the two traces of one camera sample differ?  -> "decision" (a recorded discrete decision differs first: nearest hit, lobe,
     glass branch, an estimate's zero / non-zero outcome, termination), "specular" (the first continuous difference lies at or after a
     vertex on a mirror / glass surface: a curved specular surface amplifies the rounding of a grazing hit 10-50x), "phong" (at or
@@ -104,21 +104,24 @@ def explain_sample(g_rows, c_rows, value_tol=2e-4, geom_tol=1e-4):
     (ky.cpp:798, 1510-1512) cancels to 1e-3 of its terms for a light that subtends 1e-4 sr, in the reference's arithmetic as in any other);
     a sample that stays inside it everywhere is "within tolerance".  geom_tol: the same for position / normal / wo (1e-4; the normal of a
     sphere of radius r carries 1 / r times the rounding of the hit point, which sphere_t::intersect's cancelling discriminant leaves at
-    ~1e-5 for a small sphere seen from afar)."""
-    specular = phong = False
+    ~1e-5 for a small sphere seen from afar).  amplifying_surfaces: caller's surface indices that amplify rounding like a specular sphere does
+    whatever their material -- spheres a few hundredths across, whose grazing hits move by 1e-3 and whose normals turn by 1e-2 on an ulp of the
+    ray: a first continuous difference at or after a vertex on one of them is "small sphere"."""
+    specular = phong = small = False
     for k in range(min(len(g_rows), len(c_rows))):
         g, c = g_rows[k], c_rows[k]
         if any(g[j] != c[j] for j in T_DECISIONS):
             return "decision"
         lobe = int(c[2])
         specular = specular or lobe in (1, 2)   # "at or after": the hit ON a small specular sphere is where the cancellation happens
+        small = small or int(c[1]) in amplifying_surfaces
         same = trace_close(g[T_GEOM], c[T_GEOM], geom_tol) and trace_close(g[T_BETA], c[T_BETA], value_tol)
         if same:   # this vertex's own radiance so far: continuous in equal inputs, but a Phong value here is already amplified
             same = trace_close(g[T_LO], c[T_LO], value_tol)
             if not same and lobe == 3:
                 phong = True
         if not same:
-            return "specular" if specular else ("phong" if phong else None)
+            return "specular" if specular else ("phong" if phong else ("small sphere" if small else None))
         phong = phong or lobe == 3
     if len(g_rows) != len(c_rows):
         return "decision"   # one path went on: roulette, the depth cap or the last traversal decided differently
@@ -127,7 +130,7 @@ def explain_sample(g_rows, c_rows, value_tol=2e-4, geom_tol=1e-4):
     return "specular" if specular else ("phong" if phong else "decision")   # equal vertices: the final traversal (hit / miss, emission side) differs
 
 
-def explain_pixel(api, O, scene, params, x, y, value_tol=2e-4, geom_tol=1e-4):
+def explain_pixel(api, O, scene, params, x, y, value_tol=2e-4, geom_tol=1e-4, amplifying_surfaces=()):
     """All differing samples of one pixel, classified (explain_sample); asserts that none is unexplained.  -> {kind: count}"""
     n = params.samples_per_pixel
     g, c = api.kat_li(scene, params, x, y, 0, n), O.li(scene, params, x, y, 0, n)
@@ -138,13 +141,13 @@ def explain_pixel(api, O, scene, params, x, y, value_tol=2e-4, geom_tol=1e-4):
     for s in np.flatnonzero(fin & (d / sc > 1e-3)):
         g_rows, _ = api.kat_li_trace(scene, params, x, y, int(s))
         c_rows = O.trace_li(scene, params, x, y, int(s))
-        kind = explain_sample(g_rows, c_rows, value_tol, geom_tol)
+        kind = explain_sample(g_rows, c_rows, value_tol, geom_tol, amplifying_surfaces)
         assert kind is not None, ("sample differs continuously with nothing that amplifies rounding", x, y, int(s), g[s], c[s])
         kinds[kind] = kinds.get(kind, 0) + 1
     return kinds
 
 
-def rmse_with_explained_flips(api, O, scene, params, g, c, max_exempt=8, threshold=5e-3, value_tol=2e-4, geom_tol=1e-4):
+def rmse_with_explained_flips(api, O, scene, params, g, c, max_exempt=8, threshold=5e-3, value_tol=2e-4, geom_tol=1e-4, amplifying_surfaces=()):
     """RMSE(g, c) over the finite pixels WITHOUT the (at most max_exempt) pixels that are off by more than `threshold` -- each of which
     must be explained sample by sample (explain_pixel: a discrete decision differs first, or the difference starts at a specular / Phong
     vertex).  -> (rmse without them, rmse with them, number exempted)"""
@@ -155,7 +158,7 @@ def rmse_with_explained_flips(api, O, scene, params, g, c, max_exempt=8, thresho
     ys, xs = np.nonzero(m > threshold)
     order = np.argsort(-m[ys, xs])[:max_exempt]
     for i in order:
-        kinds = explain_pixel(api, O, scene, params, int(xs[i]), int(ys[i]), value_tol, geom_tol)
+        kinds = explain_pixel(api, O, scene, params, int(xs[i]), int(ys[i]), value_tol, geom_tol, amplifying_surfaces)
         assert sum(v for k, v in kinds.items() if k != "within tolerance") > 0, ("pixel off by %.2e without a differing sample" % m[ys[i], xs[i]], int(xs[i]), int(ys[i]))
         keep[ys[i], xs[i]] = False
     return float(np.sqrt(np.mean(d[keep] ** 2))), float(np.sqrt(np.mean(d[fin] ** 2))), int(len(order))

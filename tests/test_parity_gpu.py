@@ -606,12 +606,17 @@ def test_edge_cases(A, api, O):
     # scenes whose spheres are not 0.05 across; here: the film tolerance without the (at most 8) pixels that are off by more than 0.05,
     # and twice the tolerance with them.
     # Every pixel set aside is examined sample by sample (helpers.explain_pixel): each differing sample must differ first in a recorded decision or
-    # at / after a specular or Phong vertex.  Tolerances for equal decisions are wide here: a sphere 0.05 across turns the 1e-5 rounding of a hit
-    # point into 2e-4 of its normal and a bounce between two of them squares that (measured: a sample that takes the same decisions at every
-    # vertex and ends 0.4 % apart), so "the same path" means 1 % on throughput and radiance, 5e-3 on geometry.
-    e_without, e_with, n_exempt = rmse_with_explained_flips(api, O, full, p, g, c, max_exempt=12, threshold=0.05, value_tol=1e-2, geom_tol=5e-3)
+    # at / after a specular or Phong vertex -- or, in this scene, at / after a vertex on one of its spheres 0.05 across, whatever the material:
+    # such a sphere turns the 1e-5 rounding of a hit point into 2e-4 of its normal, a grazing hit into far more, and a bounce between two of them
+    # compounds it (measured: samples that take the same decisions at every vertex and end 0.4 % and 34 % apart).  A path that only ever touches
+    # the five walls must agree like anywhere else.
+    small = set(range(5, A.MAX_SURFACES))
+    e_without, e_with, n_exempt = rmse_with_explained_flips(api, O, full, p, g, c, max_exempt=12, threshold=0.05, value_tol=2e-3, geom_tol=2e-3, amplifying_surfaces=small)
     assert g.mean() > 0.05 and (np.abs(g.astype(np.float64) - c).max(axis=2) > 0.05).sum() <= 12
-    assert e_without < film_tolerance(64) and e_with < 2 * film_tolerance(64), (e_without, e_with, n_exempt)
+    # with the explained pixels left in, the film may be off by no more than those flips can account for: each is one camera sample of 64
+    # deciding differently, worth at most the brightest emitter's 20 / 64 in its pixel
+    n_pix = g.shape[0] * g.shape[1]
+    assert e_without < film_tolerance(64) and e_with ** 2 <= e_without ** 2 + n_exempt * (20.0 / 64) ** 2 / n_pix, (e_without, e_with, n_exempt)
     assert "scene-sized LDS block" in lib.kyhip_last_kernel(0).decode()
     too_many = CustomScene(A, cam40, shapes, mats, lights, surfaces)
     film = np.zeros((24, 40, 3), np.float32)

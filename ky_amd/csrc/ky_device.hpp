@@ -50,7 +50,11 @@ KY_DEV float cos_rev(float x) { return __builtin_amdgcn_cosf(x); }  // cos(2 pi 
 KY_DEV float clamp01f(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 1.f); }
 // A value that is never read: what a variable holds on the paths that do not assign it.  (An explicit default would be a v_mov per
 // register at every level of nested divergent control flow; this is "any register content", which costs nothing.)
-KY_DEV float any_f() { float x; return __builtin_nondeterministic_value(x); }
+// (A register definition without an instruction.  __builtin_nondeterministic_value says the same to the optimiser, but where such a value merges
+// with a real one at a join the compiler materialises it as v_mov 0: round 4 measured +0.35 % / +2.3 % for the empty asm on the two scenes.)
+KY_DEV float any_f() { float x; asm volatile("" : "=v"(x)); return x; }
+KY_DEV float any_reg() { return any_f(); }
+KY_DEV unsigned any_reg_u() { unsigned x; asm volatile("" : "=v"(x)); return x; }
 // x^n for x >= 0 (pow(0, n > 0) = 0, pow(x, 0) = 1)
 KY_DEV float pow_nonneg(float x, float n) { return n == 0.f ? 1.f : __builtin_amdgcn_exp2f(n * __builtin_amdgcn_logf(x)); }
 
@@ -254,7 +258,9 @@ enum : int {
     KY_FEAT_SINGLE_ENV = 16,     // the lights are exactly ONE environment light (which is the scene's environment): no area / delta light code
     KY_FEAT_SPHERE_LIGHTS = 32,  // every light is an area light that samples a SPHERE and is carried by sphere surfaces only, no environment light (the
                                  // Veach scene's five): no other light kind's or light shape's code, no dispatch on either per light and vertex
-    KY_FEAT_NO_DELTA = 64        // no material is a mirror or glass: no delta lobe's code, prev_specular is never set
+    KY_FEAT_NO_DELTA = 64,       // no material is a mirror or glass: no delta lobe's code, prev_specular is never set
+    KY_FEAT_SMALL_TABLES = 128   // at most KY_LDS_SURFACES_SMALL surfaces and KY_LDS_MATERIALS_SMALL materials: the per-lane tables' LDS block is 1.1 KB instead of
+                                 // 3.8 (what lets the sphere-lights kernel with its deferred rays' sums fit a seventh workgroup per CU)
 };
 constexpr int KY_FEAT_SINGLE_LIGHT = KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_DELTA | KY_FEAT_SINGLE_ENV;   // any of them: no lights loop
 // (Measured and not kept: "every area light samples a sphere" + "no mirror or glass material" for the Veach scene: 11 fewer spilled
@@ -290,16 +296,19 @@ struct SceneRef {
 // (lds_scene_bytes() at launch) and pay an add per table access for it -- measured on the kernels that do not need it: Veach -2.2 %,
 // Cornell -0.5 %, which is why they keep the static block.
 constexpr int KY_LDS_SURFACES = 64, KY_LDS_MATERIALS = 32;
+constexpr int KY_LDS_SURFACES_SMALL = 16, KY_LDS_MATERIALS_SMALL = 8;
 struct LdsScene {
     const DHit* hit;
     const DMat* mat;
     const float (*light_color)[4];
 };
-struct LdsSceneStatic {
-    DHit hit[KY_LDS_SURFACES];
-    DMat mat[KY_LDS_MATERIALS];
+template <int NS, int NM>
+struct LdsSceneStaticT {
+    DHit hit[NS];
+    DMat mat[NM];
     float light_color[KYHIP_MAX_LIGHTS][4];
 };
+using LdsSceneStatic = LdsSceneStaticT<KY_LDS_SURFACES, KY_LDS_MATERIALS>;
 extern __shared__ __attribute__((aligned(16))) unsigned char g_lds_scene[];
 __host__ __device__ inline int lds_scene_mat_offset(int n_surfaces) { return (n_surfaces * (int)sizeof(DHit) + 15) & ~15; }
 __host__ __device__ inline int lds_scene_light_offset(int n_surfaces, int n_materials) { return lds_scene_mat_offset(n_surfaces) + n_materials * (int)sizeof(DMat); }
@@ -308,7 +317,7 @@ __host__ __device__ inline int lds_scene_bytes(int n_surfaces, int n_materials, 
 KY_DEV f3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
 
 // cooperative copy global -> LDS, whole workgroup; ends with a barrier
-template <bool LARGE>
+template <bool LARGE, bool SMALL = false>
 KY_DEV LdsScene stage_scene(SceneRef S) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int ns = S->n_surfaces, nm = S->n_materials, nl = S->n_lights;
@@ -319,7 +328,7 @@ KY_DEV LdsScene stage_scene(SceneRef S) {
         dst_m = reinterpret_cast<uint32_t*>(g_lds_scene + lds_scene_mat_offset(ns));
         dst_l = reinterpret_cast<float*>(g_lds_scene + lds_scene_light_offset(ns, nm));
     } else {
-        __shared__ LdsSceneStatic L;
+        __shared__ LdsSceneStaticT<SMALL ? KY_LDS_SURFACES_SMALL : KY_LDS_SURFACES, SMALL ? KY_LDS_MATERIALS_SMALL : KY_LDS_MATERIALS> L;
         dst_h = reinterpret_cast<uint32_t*>(L.hit);
         dst_m = reinterpret_cast<uint32_t*>(L.mat);
         dst_l = &L.light_color[0][0];
@@ -1129,12 +1138,14 @@ struct SqRay;
 KY_DEV void sq_push_bsdf_query(SceneRef S, ShadowQueue& q, bool push, f3 o, f3 d, float tmax, f3 c, unsigned tag);
 // `sq` (QUEUE instantiations): the occlusion queries of (b) are not resolved here but join the wave's stack of deferred shadow rays, with
 // the estimate x beta x weight as the contribution; the function then returns black.
+// The estimate is ADDED, times `w`, to `acc` by the lanes that have one, under their own predicate (in place: no default value travels through the
+// nesting levels, no select afterwards): the render kernels pass the path's radiance sum and throughput x strategy weight, the KAT entry a zeroed
+// value and w = 1.
 template <bool MIS>
-KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, int li, float u0, float u1, bool active,
-                           ShadowQueue* sq = nullptr, f3 beta = f3{0, 0, 0}, float weight = 0.f, unsigned tag = 0, RideAlong* ra = nullptr) {
+KY_DEV void estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, int li, float u0, float u1, bool active, f3& acc, f3 w,
+                             ShadowQueue* sq = nullptr, f3 beta = f3{0, 0, 0}, float weight = 0.f, unsigned tag = 0, RideAlong* ra = nullptr) {
     const DLight& L = scene_light(S, li);
-    f3 Ld = mk3(0, 0, 0);
-    if (S.is_delta(L.kind)) return Ld;  // light.is_delta(), 3894 / 3977 (wave-uniform)
+    if (S.is_delta(L.kind)) return;  // light.is_delta(), 3894 / 3977 (wave-uniform)
     BsdfSample bs;
     // what `live` guards: read at the end only for lanes whose sample counts (and, in the query loop, through __shfl from such lanes)
     f3 f_cos = any3(), o = any3(), Li = any3();
@@ -1188,7 +1199,7 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 
                 pending = !(c.x == 0.f && c.y == 0.f && c.z == 0.f);
             }
             sq_push_bsdf_query(S, *sq, pending, o, bs.wi, t_l * (1.f - 1e-6f), c, tag);
-            return Ld;
+            return;
         }
         // (b) is any surface in front of the carrier?  (the carrier itself reproduces t_l exactly, and t < t_l is strict)
         unsigned long long queries = __ballot(pending);
@@ -1252,12 +1263,11 @@ KY_DEV f3 estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 
     if (lit) {
         if (MIS) {
             const float light_pdf = light_pdf_Li(L, S->full, v.position, v.normal, bs.wi, S.general, S.feat);
-            if (light_pdf > 0) Ld = (f_cos * Li) * (2.f * rcp(bs.pdf + light_pdf));  // 4028
+            if (light_pdf > 0) acc = acc + w * ((f_cos * Li) * (2.f * rcp(bs.pdf + light_pdf)));  // 4028
         } else {
-            Ld = (f_cos * Li) * rcp(bs.pdf);  // 3924
+            acc = acc + w * ((f_cos * Li) * rcp(bs.pdf));  // 3924
         }
     }
-    return Ld;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1417,9 +1427,8 @@ KY_DEV bool light_sample_occluded(SceneRef S, int li, f3 o, f3 dir, float tmax) 
 }
 
 template <bool MIS>
-KY_DEV f3 estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, int li, float u0, float u1) {
+KY_DEV void estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, int li, float u0, float u1, f3& acc, f3 w) {
     const DLight& L = scene_light(S, li);
-    f3 Ld = mk3(0, 0, 0);
     KY_PROBE(3);
     const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1, S.feat);
     const bool dead = is_black(ls.Li) || (MIS ? (ls.pdf <= 0) : (ls.pdf == 0));
@@ -1443,22 +1452,20 @@ KY_DEV f3 estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, 
             const f3 f_cos = f * abs_cos_i;
             if (!is_black(f_cos)) {
                 const bool delta_light = S.is_delta(L.kind);
-                if (!MIS || delta_light) Ld = (f_cos * ls.Li) * rcp(ls.pdf);          // 3956 / 4057
-                else Ld = (f_cos * ls.Li) * (2.f * rcp(ls.pdf + bsdf_pdf));            // 4070
+                const float k = (!MIS || delta_light) ? rcp(ls.pdf) : 2.f * rcp(ls.pdf + bsdf_pdf);   // 3956 / 4057 / 4070
+                acc = acc + w * ((f_cos * ls.Li) * k);
             }
             KY_CLK(7);
         }
     }
-    return Ld;
 }
 
 // the same estimator as a WAVE-UNIFORM call whose shadow traversal also serves the lanes of `ra` (RideAlong) that still wait: when there are any,
 // shadow rays and look-up rays go through one nearest-hit scan of the whole scene (a shadow ray is occluded iff that scan finds a hit
 // inside its interval: the occluder tables are subsets that decide the same, tests/test_occluders.py).
 template <bool MIS>
-KY_DEV f3 estimate_by_emitter_ride(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, int li, float u0, float u1, bool active, RideAlong& ra) {
+KY_DEV void estimate_by_emitter_ride(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, int li, float u0, float u1, bool active, RideAlong& ra, f3& acc, f3 w) {
     const DLight& L = scene_light(S, li);
-    f3 Ld = mk3(0, 0, 0);
     LightSample ls{any3(), any3(), any3(), any_f()};
     bool dead = true;
     if (active) {
@@ -1493,67 +1500,67 @@ KY_DEV f3 estimate_by_emitter_ride(SceneRef S, const LdsScene& Lds, const Vertex
         const f3 f_cos = f * abs_cos_i;
         if (!is_black(f_cos)) {
             const bool delta_light = S.is_delta(L.kind);
-            if (!MIS || delta_light) Ld = (f_cos * ls.Li) * rcp(ls.pdf);          // 3956 / 4057
-            else Ld = (f_cos * ls.Li) * (2.f * rcp(ls.pdf + bsdf_pdf));            // 4070
+            const float k = (!MIS || delta_light) ? rcp(ls.pdf) : 2.f * rcp(ls.pdf + bsdf_pdf);   // 3956 / 4057 / 4070
+            acc = acc + w * ((f_cos * ls.Li) * k);
         }
     }
-    return Ld;
 }
 
 // sample_all_light, 3834-3872.  Wave-uniform call; `active` lanes draw 4 numbers per light (+2 for the plain bsdf
-// strategy, 3900) and accumulate the estimators.
+// strategy, 3900) and ADD beta x (the estimators' sum) to Lo -- each estimator adds its own term in place (estimate_by_bsdf), so the 0.5 of
+// both_mis (4083) is part of the weight the terms are multiplied by, not a pass over their sum.
 // `decisions` (KAT tracing only; a null constant everywhere else, which removes the code): bit li = the BSDF half of light li's
 // estimate was non-black, bit 16 + li = its light half.
-// `sq` (the QUEUE instantiations of the lane engine: strategies both_mis, light_mis, light): the light-sampling halves are not returned but
+// `sq` (the QUEUE instantiations of the lane engine: strategies both_mis, light_mis, light): the light-sampling halves are not added but
 // pushed on the wave's shadow-ray stack with beta x weight (x 0.5 under both_mis) as their weight in the pixel's sum.
 template <bool DEBUG_SAMPLER>
-KY_DEV f3 sample_all_light(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, Sampler& smp, int strategy, bool active,
-                           unsigned* decisions = nullptr, ShadowQueue* sq = nullptr, f3 beta = f3{0, 0, 0}, float weight = 0.f, unsigned tag = 0,
-                           RideAlong* ra = nullptr) {
-    f3 Ld = mk3(0, 0, 0);
+KY_DEV void sample_all_light(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, Sampler& smp, int strategy, bool active, f3& Lo, f3 beta,
+                             unsigned* decisions = nullptr, ShadowQueue* sq = nullptr, float weight = 0.f, unsigned tag = 0, RideAlong* ra = nullptr) {
     const int nl = S.single_light() ? 1 : S->n_lights;
+    const f3 w = strategy == KY_DIRECT_BOTH_MIS ? beta * 0.5f : beta;
     for (int li = 0; li < nl; ++li) {
         // the reference's GCC build draws random_bsdf first, then random_light (3866-3868), for every light and strategy
         float ub0 = any_f(), ub1 = any_f(), ul0 = any_f(), ul1 = any_f();   // drawn, and read, by the active lanes only
         if (active) { ub0 = sampler_next<DEBUG_SAMPLER>(smp); ub1 = sampler_next<DEBUG_SAMPLER>(smp); }
+        f3 Lb = mk3(0, 0, 0), Ll = mk3(0, 0, 0);      // tracing only: the two halves on their own
+        f3& ab = decisions ? Lb : Lo;
+        f3& al = decisions ? Ll : Lo;
+        const f3 wt = decisions ? mk3(1, 1, 1) : w;
         if (strategy == KY_DIRECT_BOTH_MIS) {  // 4076-4088
             KY_CLK(3);
-            const f3 Lb = estimate_by_bsdf<true>(S, Lds, v, wo, li, ub0, ub1, active, sq, beta, weight * 0.5f, tag, ra);   // draws nothing itself
+            estimate_by_bsdf<true>(S, Lds, v, wo, li, ub0, ub1, active, ab, wt, sq, beta, weight * 0.5f, tag, ra);   // draws nothing itself
             KY_CLK(4);
-            f3 Ll = mk3(0, 0, 0);
             // random_light is drawn here, after the BSDF half: same stream position, two registers fewer across it
             if (active) { ul0 = sampler_next<DEBUG_SAMPLER>(smp); ul1 = sampler_next<DEBUG_SAMPLER>(smp); }
             if (sq) estimate_by_emitter_deferred<true>(S, v, wo, li, ul0, ul1, active, beta, weight * 0.5f, tag, *sq);
-            else if (ra) Ll = estimate_by_emitter_ride<true>(S, Lds, v, wo, li, ul0, ul1, active, *ra);
-            else if (active) Ll = estimate_by_emitter<true>(S, Lds, v, wo, li, ul0, ul1);
-            Ld = Ld + (0.5f * Lb + 0.5f * Ll);
-            if (decisions && li < 16) *decisions |= (is_black(Lb) ? 0u : 1u << li) | (is_black(Ll) ? 0u : 1u << (16 + li));
-            continue;
-        }
-        if (active) { ul0 = sampler_next<DEBUG_SAMPLER>(smp); ul1 = sampler_next<DEBUG_SAMPLER>(smp); }
-        KY_CLK(3);
-        f3 Lb = mk3(0, 0, 0), Ll = mk3(0, 0, 0);
-        if (strategy == KY_DIRECT_BSDF_MIS) {
-            Lb = estimate_by_bsdf<true>(S, Lds, v, wo, li, ub0, ub1, active);
-        } else if (strategy == KY_DIRECT_LIGHT_MIS) {
-            if (sq) estimate_by_emitter_deferred<true>(S, v, wo, li, ul0, ul1, active, beta, weight, tag, *sq);
-            else if (active) Ll = estimate_by_emitter<true>(S, Lds, v, wo, li, ul0, ul1);
-        } else if (strategy == KY_DIRECT_LIGHT) {
-            if (sq) estimate_by_emitter_deferred<false>(S, v, wo, li, ul0, ul1, active, beta, weight, tag, *sq);
-            else if (active) Ll = estimate_by_emitter<false>(S, Lds, v, wo, li, ul0, ul1);
-        } else if (strategy == KY_DIRECT_BSDF) {
-            const int lk = S->light[li].kind;
-            if (!S.is_delta(lk)) {  // the third float2 is drawn after the delta test (3894-3900)
-                float u0 = any_f(), u1 = any_f();
-                if (active) { u0 = sampler_next<DEBUG_SAMPLER>(smp); u1 = sampler_next<DEBUG_SAMPLER>(smp); }
-                Lb = estimate_by_bsdf<false>(S, Lds, v, wo, li, u0, u1, active);
+            else if (ra) estimate_by_emitter_ride<true>(S, Lds, v, wo, li, ul0, ul1, active, *ra, al, wt);
+            else if (active) estimate_by_emitter<true>(S, Lds, v, wo, li, ul0, ul1, al, wt);
+        } else {
+            if (active) { ul0 = sampler_next<DEBUG_SAMPLER>(smp); ul1 = sampler_next<DEBUG_SAMPLER>(smp); }
+            KY_CLK(3);
+            if (strategy == KY_DIRECT_BSDF_MIS) {
+                estimate_by_bsdf<true>(S, Lds, v, wo, li, ub0, ub1, active, ab, wt);
+            } else if (strategy == KY_DIRECT_LIGHT_MIS) {
+                if (sq) estimate_by_emitter_deferred<true>(S, v, wo, li, ul0, ul1, active, beta, weight, tag, *sq);
+                else if (active) estimate_by_emitter<true>(S, Lds, v, wo, li, ul0, ul1, al, wt);
+            } else if (strategy == KY_DIRECT_LIGHT) {
+                if (sq) estimate_by_emitter_deferred<false>(S, v, wo, li, ul0, ul1, active, beta, weight, tag, *sq);
+                else if (active) estimate_by_emitter<false>(S, Lds, v, wo, li, ul0, ul1, al, wt);
+            } else if (strategy == KY_DIRECT_BSDF) {
+                const int lk = S->light[li].kind;
+                if (!S.is_delta(lk)) {  // the third float2 is drawn after the delta test (3894-3900)
+                    float u0 = any_f(), u1 = any_f();
+                    if (active) { u0 = sampler_next<DEBUG_SAMPLER>(smp); u1 = sampler_next<DEBUG_SAMPLER>(smp); }
+                    estimate_by_bsdf<false>(S, Lds, v, wo, li, u0, u1, active, ab, wt);
+                }
             }
+            // KY_DIRECT_IDLE: estimate_direct_lighting_idle, 3880-3886
         }
-        Ld = Ld + (Lb + Ll);
-        if (decisions && li < 16) *decisions |= (is_black(Lb) ? 0u : 1u << li) | (is_black(Ll) ? 0u : 1u << (16 + li));
-        // KY_DIRECT_IDLE: estimate_direct_lighting_idle, 3880-3886
+        if (decisions) {
+            if (active) Lo = Lo + w * (Lb + Ll);
+            if (li < 16) *decisions |= (is_black(Lb) ? 0u : 1u << li) | (is_black(Ll) ? 0u : 1u << (16 + li));
+        }
     }
-    return Ld;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1569,6 +1576,12 @@ struct PathState {
     bool prev_specular;
 };
 
+// everything of a path's state but Lo becomes "any register content" (callers: lanes that hold no path)
+KY_DEV void path_state_dead(PathState& ps) {
+    ps.o = mk3(any_reg(), any_reg(), any_reg()); ps.d = mk3(any_reg(), any_reg(), any_reg()); ps.beta = mk3(any_reg(), any_reg(), any_reg());
+    ps.smp.s0 = any_reg_u(); ps.smp.s1 = any_reg_u(); ps.bounces = (int)any_reg_u(); ps.prev_specular = any_reg_u() != 0;
+}
+
 struct RenderConst {  // wave-uniform launch constants
     int integrator, max_path_depth, strategy;
     uint32_t seed;
@@ -1576,14 +1589,16 @@ struct RenderConst {  // wave-uniform launch constants
     float inv_spp;
 };
 
-template <bool DEBUG_SAMPLER>
+// KEEP_LO (render_kernel): ps.Lo is not the sample's radiance but the running sum of the lane's pixel chunk -- every contribution of every
+// path of the chunk is added to it, the kernel scales and flushes it once per chunk -- so a new path leaves it alone.
+template <bool DEBUG_SAMPLER, bool KEEP_LO = false>
 KY_DEV void path_begin(PathState& ps, SceneRef S, uint32_t pixel_key, int x, int y, int sample) {
     sampler_start(ps.smp, pixel_key, (uint32_t)sample);
     // get_camera_sample, 943-946 / 971-974
     const float u0 = sampler_next<DEBUG_SAMPLER>(ps.smp), u1 = sampler_next<DEBUG_SAMPLER>(ps.smp);
     generate_ray(S, (float)x + u0, (float)y + u1, ps.o, ps.d);
     ps.beta = mk3(1, 1, 1);
-    ps.Lo = mk3(0, 0, 0);
+    if (!KEEP_LO) ps.Lo = mk3(0, 0, 0);
     ps.bounces = 0;
     ps.prev_specular = false;
 }
@@ -1597,31 +1612,37 @@ KY_DEV bool path_intersect(PathState& ps, Vertex& v, SceneRef S, const LdsScene&
     const int hs = trace_nearest(S, ps.o, ps.d, t);  // scene->intersect, 4542
     const bool hit = hs >= 0;
 
-    f3 emission = mk3(0, 0, 0);
     if (hit) {
         v.t = t;
         v.position = ps.o + t * ps.d;
         v.normal = hit_normal(Lds.hit[hs], v.position, ps.d);
         v.surface = hs;
-        emission = surface_emission(Lds, hs, v.normal, -ps.d);
     }
-
-    const f3 env = (S.may_have_env() && S->env_light >= 0) ? ld3(S->light[S->env_light].color) : mk3(0, 0, 0);  // environment_lighting, 3231
+    // What the hit (or the miss) itself adds: the hit surface's emission towards the ray (surface_t::intersect 3084 + areal_radiance 2957) or the
+    // environment's radiance (environment_lighting, 3231) -- for the lanes whose integrator counts it at this vertex, added in place under
+    // their predicate.  (Rounds 1-3 computed an `emission` value for every lane first: a default of zero at each of three nesting levels, nine
+    // v_mov and six selects per loop turn for a term one vertex in three or four takes.)
+    bool see;
     if (rc.integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION || rc.integrator == KY_INTEGRATOR_DIRECT_LIGHTING ||
-        rc.integrator == KY_INTEGRATOR_PATH_TRACING_RECURSION_DEFERED) {
-        if (ps.bounces == 0 || ps.prev_specular) ps.Lo = ps.Lo + ps.beta * (hit ? emission : env);  // 4548-4559 / 4449-4452
-        if (!hit) return false;  // 4563 / 4141 / 4454
-        if (rc.integrator != KY_INTEGRATOR_DIRECT_LIGHTING && ps.bounces >= rc.max_path_depth) return false;  // 4563 / 4454
-    } else if (rc.integrator == KY_INTEGRATOR_PATH_TRACING_RECURSION) {
-        if (ps.bounces == 0) ps.Lo = ps.Lo + ps.beta * (hit ? emission : env);  // 4328-4331
-        if (!hit || ps.bounces >= rc.max_path_depth) return false;              // 4333
-    } else if (rc.integrator == KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION) {
-        // every way out of 4201-4237 returns the hit's emission (or the environment on a miss)
-        ps.Lo = ps.Lo + ps.beta * (hit ? emission : env);
-        if (!hit || ps.bounces >= rc.max_path_depth) return false;              // 4204-4210
-    } else if (!hit) {
-        return false;  // debug integrators return black on a miss (4121)
+        rc.integrator == KY_INTEGRATOR_PATH_TRACING_RECURSION_DEFERED)
+        see = ps.bounces == 0 || ps.prev_specular;             // 4548-4559 / 4449-4452
+    else if (rc.integrator == KY_INTEGRATOR_PATH_TRACING_RECURSION)
+        see = ps.bounces == 0;                                 // 4328-4331
+    else
+        see = rc.integrator == KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION;   // every way out of 4201-4237 returns it; the debug integrators: never
+    if (see) {
+        if (hit) {
+            const int al = Lds.hit[hs].area_light;
+            if (al >= 0 && dot(v.normal, ps.d) < 0)            // areal_radiance: the side the (ray-facing) normal looks at, wo = -d
+                ps.Lo = ps.Lo + ps.beta * mk3(Lds.light_color[al][0], Lds.light_color[al][1], Lds.light_color[al][2]);
+        } else if (S.may_have_env() && S->env_light >= 0) {
+            ps.Lo = ps.Lo + ps.beta * ld3(S->light[S->env_light].color);
+        }
     }
+    if (!hit) return false;  // 4563 / 4141 / 4454 / 4333 / 4204; the debug integrators return black on a miss (4121)
+    if (rc.integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION || rc.integrator == KY_INTEGRATOR_PATH_TRACING_RECURSION_DEFERED ||
+        rc.integrator == KY_INTEGRATOR_PATH_TRACING_RECURSION || rc.integrator == KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION)
+        if (ps.bounces >= rc.max_path_depth) return false;     // 4563 / 4454 / 4333 / 4204-4210
     return true;
 }
 
@@ -1645,7 +1666,7 @@ struct VertexTrace {
 // `tr` is a null constant everywhere but in the trace KAT kernel, which removes the tracing code.
 template <bool DEBUG_SAMPLER>
 KY_DEV bool path_shade(PathState& ps, Vertex& v, SceneRef S, const LdsScene& Lds, const RenderConst& rc, bool active,
-                       int lobe = -1, VertexTrace* tr = nullptr, ShadowQueue* sq = nullptr, unsigned tag = 0, bool ride_along = false) {
+                       int lobe = -1, VertexTrace* tr = nullptr, ShadowQueue* sq = nullptr, unsigned tag = 0, bool ride_along = false, bool free_state = false) {
     if (active) {
         // material->scattering(isect) for the nearest hit (3083); only plastic draws a lobe number (2663).
         // lobe >= 0: the caller has already made that draw (path_pick_lobe).
@@ -1663,11 +1684,14 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, SceneRef S, const LdsScene& Lds
 
     if (rc.integrator < KY_INTEGRATOR_DIRECT_LIGHTING) {  // debug_integrator_t, 4110-4118 (wave-uniform)
         if (active) {
-            if (rc.integrator == KY_INTEGRATOR_POSITION) ps.Lo = normalize(v.position);
-            else if (rc.integrator == KY_INTEGRATOR_NORMAL) ps.Lo = v.normal;
+            // (added, not assigned: in the render kernel Lo is the running sum of the pixel chunk; everywhere else it is zero here)
+            if (rc.integrator == KY_INTEGRATOR_POSITION) ps.Lo = ps.Lo + normalize(v.position);
+            else if (rc.integrator == KY_INTEGRATOR_NORMAL) ps.Lo = ps.Lo + v.normal;
             else {
                 float pdf, abs_cos_i;
-                bsdf_eval_pdf(v, wo, v.normal, ps.Lo, pdf, abs_cos_i);
+                f3 base;
+                bsdf_eval_pdf(v, wo, v.normal, base, pdf, abs_cos_i);
+                ps.Lo = ps.Lo + base;
             }
         }
         return false;
@@ -1698,13 +1722,18 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, SceneRef S, const LdsScene& Lds
         es_k = fabsf(dot(es.wi, v.normal)) / es.pdf;
     }
     if (!simple) {  // simple_path_tracing_recursion_t samples the BSDF only
-        const f3 Ld = sample_all_light<DEBUG_SAMPLER>(S, Lds, v, wo, ps.smp, rc.strategy, nee, tr ? &decisions : nullptr, sq, ps.beta, rc.inv_spp, tag,
-                                                      riding ? &ra : nullptr);  // 4575 / 4337 / 4458
-        if (nee) ps.Lo = ps.Lo + ps.beta * Ld;
+        sample_all_light<DEBUG_SAMPLER>(S, Lds, v, wo, ps.smp, rc.strategy, nee, ps.Lo, ps.beta, tr ? &decisions : nullptr, sq, rc.inv_spp, tag,
+                                        riding ? &ra : nullptr);  // 4575 / 4337 / 4458
     }
     KY_CLK(8);
     if (rc.integrator == KY_INTEGRATOR_DIRECT_LIGHTING) return false;  // 4153
-    if (!active) return false;
+    if (!active) {
+        // A lane without a vertex holds no path: its ray, throughput, sampler and depth are dead until path_begin rewrites them.  Saying so -- they
+        // become "any register content" here -- lets the values the active lanes compute below BE the loop-carried state instead of being
+        // copied into it (sixteen v_mov per loop turn in the round-3 listing).
+        if (free_state) path_state_dead(ps);
+        return false;
+    }
 
     if (recursion && delta) {
         if (!riding) {

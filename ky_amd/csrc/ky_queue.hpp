@@ -250,14 +250,14 @@ KY_DEV void nee_one_light(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 w
         ul0 = sampler_next<DEBUG_SAMPLER>(smp); ul1 = sampler_next<DEBUG_SAMPLER>(smp);
     }
     if (strategy == KY_DIRECT_BOTH_MIS) {  // 4076-4088
-        L_now = 0.5f * estimate_by_bsdf<true>(S, Lds, v, wo, li, ub0, ub1, active);
+        estimate_by_bsdf<true>(S, Lds, v, wo, li, ub0, ub1, active, L_now, mk3(0.5f, 0.5f, 0.5f));   // adds w x the estimate to L_now (zero above)
         if (active) {
             f3 Ll = mk3(0, 0, 0);
             pending = emitter_sample<true>(S, v, wo, li, ul0, ul1, dir, tmax, Ll);
             L_pending = 0.5f * Ll;
         }
     } else if (strategy == KY_DIRECT_BSDF_MIS) {
-        L_now = estimate_by_bsdf<true>(S, Lds, v, wo, li, ub0, ub1, active);
+        estimate_by_bsdf<true>(S, Lds, v, wo, li, ub0, ub1, active, L_now, mk3(1, 1, 1));
     } else if (strategy == KY_DIRECT_LIGHT_MIS) {
         if (active) pending = emitter_sample<true>(S, v, wo, li, ul0, ul1, dir, tmax, L_pending);
     } else if (strategy == KY_DIRECT_LIGHT) {
@@ -267,7 +267,7 @@ KY_DEV void nee_one_light(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 w
         if (!(lk == KY_LIGHT_POINT || lk == KY_LIGHT_DIRECTION)) {  // the third float2 is drawn after the delta test (3894-3900)
             float u0 = 0.f, u1 = 0.f;
             if (active) { u0 = sampler_next<DEBUG_SAMPLER>(smp); u1 = sampler_next<DEBUG_SAMPLER>(smp); }
-            L_now = estimate_by_bsdf<false>(S, Lds, v, wo, li, u0, u1, active);
+            estimate_by_bsdf<false>(S, Lds, v, wo, li, u0, u1, active, L_now, mk3(1, 1, 1));
         }
     }
     if (!pending) L_pending = mk3(0, 0, 0);

@@ -214,7 +214,7 @@ static ShardConst make_shard(const ky_render_params* p) {
 #define KY_WAVES_PER_EU_QUEUE 5     // the instantiation with deferred shadow rays: 96 VGPRs (6 spilled) beat 80 (28 spilled) by 3.5 % since round 3
 #endif
 #ifndef KY_WAVES_PER_EU_QUEUE_FEAT
-#define KY_WAVES_PER_EU_QUEUE_FEAT 6   // ... with scene facts (the sphere-lights kernel): 80 VGPRs with 11 spilled beat 96 with 2 by 4 %
+#define KY_WAVES_PER_EU_QUEUE_FEAT 7   // ... with scene facts (the sphere-lights kernel): round 4, with its LDS block at 22.9 KB (KY_FEAT_SMALL_TABLES, the pixel key recomputed): 72 VGPRs with 10 spilled beat 80 with 8 at six by 3.4 % (111.7 against 115.5 ms at 1024 spp)
 #endif
 #ifndef KY_WAVES_PER_EU_HOT
 #define KY_WAVES_PER_EU_HOT 8          // the iterative integrator's both_mis with a single-light fact (every Cornell configuration): 64 VGPRs with 0-4 spilled, +1 % over
@@ -227,7 +227,7 @@ static ShardConst make_shard(const ky_render_params* p) {
 #endif
 
 constexpr int KY_FEAT_CORNELL = KY_FEAT_SINGLE_AREA | KY_FEAT_RECT_LIGHTS | KY_FEAT_CARRIERS;   // what the Cornell-lamp instantiation assumes
-constexpr int KY_FEAT_VEACH = KY_FEAT_SPHERE_LIGHTS | KY_FEAT_CARRIERS | KY_FEAT_NO_DELTA;       // what the sphere-lights instantiation assumes (create_mis_scene)
+constexpr int KY_FEAT_VEACH = KY_FEAT_SPHERE_LIGHTS | KY_FEAT_CARRIERS | KY_FEAT_NO_DELTA | KY_FEAT_SMALL_TABLES;   // what the sphere-lights instantiations assume (create_mis_scene)
 
 struct ItemSlot {  // one fetched work item, decoded once (wave-uniform) and read per lane
     int x0, y0, pix0, s_begin, s_end;
@@ -259,13 +259,12 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? (FEAT ? KY_WAVES_PER_
     const SceneRef S{S_, GENERAL, FEAT, LARGE};
     __shared__ ItemSlot ring[4][KY_RING];
     // the lane's pixel chunk (touched when a path starts or ends, not while a vertex is shaded) lives in LDS, not in registers
-    __shared__ float c_lsum[3][256];
     __shared__ int c_xy[256], c_pix[256];
     __shared__ unsigned c_se[256];   // next sample << 7 | samples left in the chunk
-    __shared__ uint32_t c_key[256];
+    __shared__ uint32_t c_key[QUEUE ? 1 : 256];   // the pixel's sampler key; the deferred-rays kernels recompute it per sample instead (1 KB of their LDS block)
     __shared__ unsigned long long c_def[QUEUE ? 3 * 256 : 1];   // QUEUE: fixed-point sums of the lane's resolved shadow rays
     const int tid = threadIdx.x;
-    const LdsScene Lds = stage_scene<LARGE>(S);
+    const LdsScene Lds = stage_scene<LARGE, (FEAT & KY_FEAT_SMALL_TABLES) != 0>(S);
     if (STRATEGY >= 0) { rc.strategy = STRATEGY; rc.integrator = INTEGRATOR; }  // compile-time constants from here on
     const int nee_weight = (rc.strategy == KY_DIRECT_IDLE || rc.integrator < KY_INTEGRATOR_DIRECT_LIGHTING ||
                             rc.integrator == KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION) ? 0 : S->n_lights;
@@ -279,7 +278,6 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? (FEAT ? KY_WAVES_PER_
     int cursor = 0;
     bool exhausted = false;   // the global counter ran past n_items
     // per lane: the pixel chunk being worked on
-    c_lsum[0][tid] = 0.f; c_lsum[1][tid] = 0.f; c_lsum[2][tid] = 0.f;
     c_pix[tid] = -1;
     ShadowQueue sq{nullptr, 0, c_pix, c_def, accum, flags};
     if (QUEUE) {
@@ -289,6 +287,7 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? (FEAT ? KY_WAVES_PER_
     bool open = false;        // the chunk has samples left to start (s < s_end)
     bool has_item = false, done = false, alive = false;
     PathState ps;
+    ps.Lo = mk3(0, 0, 0);
 
     KY_CLK(-1);
     for (;;) {
@@ -300,9 +299,9 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? (FEAT ? KY_WAVES_PER_
         const unsigned long long need_mask = __ballot(need);
         if (need_mask) {  // wave-uniform branch: every lane runs the bookkeeping below
             if (need && has_item) {
-                const float v[3] = {c_lsum[0][tid], c_lsum[1][tid], c_lsum[2][tid]};
+                const float v[3] = {ps.Lo.x * rc.inv_spp, ps.Lo.y * rc.inv_spp, ps.Lo.z * rc.inv_spp};   // 3717, once per chunk
+                ps.Lo = mk3(0, 0, 0);
                 const int pix = c_pix[tid];
-                c_lsum[0][tid] = 0.f; c_lsum[1][tid] = 0.f; c_lsum[2][tid] = 0.f;
                 c_pix[tid] = -1;   // rays of this chunk that are still on the stack go to the global accumulator directly
                 unsigned fl = 0;
 #pragma unroll
@@ -350,7 +349,7 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? (FEAT ? KY_WAVES_PER_
                     const bool in_range = x < rc.width && y < rc.height;
                     c_xy[tid] = x | (y << 16);
                     c_pix[tid] = it.pix0 + py * sh.tile_w + px;
-                    c_key[tid] = sampler_pixel_key(rc.seed, (uint32_t)(y * rc.width + x));
+                    if (!QUEUE) c_key[tid] = sampler_pixel_key(rc.seed, (uint32_t)(y * rc.width + x));
                     c_se[tid] = ((unsigned)it.s_begin << 7) | (unsigned)(it.s_end - it.s_begin);
                     open = in_range && it.s_begin < it.s_end;
                     has_item = in_range;
@@ -372,7 +371,8 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? (FEAT ? KY_WAVES_PER_
             if (!alive && !done && open) {  // next camera sample of this lane's pixel, 3712-3715
                 const int xy = c_xy[tid];
                 const unsigned se = c_se[tid];
-                path_begin<DEBUG_SAMPLER>(ps, S, c_key[tid], xy & 0xffff, xy >> 16, (int)(se >> 7));
+                const uint32_t key = QUEUE ? sampler_pixel_key(rc.seed, (uint32_t)((xy >> 16) * rc.width + (xy & 0xffff))) : c_key[tid];
+                path_begin<DEBUG_SAMPLER, true>(ps, S, key, xy & 0xffff, xy >> 16, (int)(se >> 7));
                 c_se[tid] = se + 127;             // next sample + 1, samples left - 1
                 open = (se & 127) > 1;
                 alive = true;
@@ -383,7 +383,6 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? (FEAT ? KY_WAVES_PER_
                 const bool ended = !path_intersect<DEBUG_SAMPLER>(ps, v, S, Lds, rc);
                 if (!ended) have_vertex = true;
                 if (ended) {
-                    c_lsum[0][tid] += ps.Lo.x * rc.inv_spp; c_lsum[1][tid] += ps.Lo.y * rc.inv_spp; c_lsum[2][tid] += ps.Lo.z * rc.inv_spp;
                     alive = false;
                 }
             }
@@ -398,6 +397,7 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? (FEAT ? KY_WAVES_PER_
         KY_CLK(1);
         if (!__any(alive)) {
             if (__all(done)) break;
+            path_state_dead(ps);   // no lane holds a path: nothing of the path state is carried into the next turn (but Lo, the chunks' sums)
             continue;  // lanes are between items: (1) serves them on the next turn
         }
         unsigned tag = 0;
@@ -405,9 +405,8 @@ __global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? (FEAT ? KY_WAVES_PER_
         // ---- (3) shade the vertex: direct lighting, continuation ----
         {
             const bool cont = path_shade<DEBUG_SAMPLER>(ps, v, S, Lds, rc, have_vertex, -1, nullptr, QUEUE ? &sq : nullptr, tag,
-                                                        STRATEGY >= 0 && INTEGRATOR == KY_INTEGRATOR_PATH_TRACING_RECURSION);  // wave-uniform call
+                                                        STRATEGY >= 0 && INTEGRATOR == KY_INTEGRATOR_PATH_TRACING_RECURSION, true);  // wave-uniform call
             if (have_vertex && !cont) {
-                c_lsum[0][tid] += ps.Lo.x * rc.inv_spp; c_lsum[1][tid] += ps.Lo.y * rc.inv_spp; c_lsum[2][tid] += ps.Lo.z * rc.inv_spp;
                 alive = false;
             }
         }
@@ -586,11 +585,12 @@ __global__ void kat_nee_kernel(const DScene* __restrict__ S, int strategy, int l
     f3 Lb = mk3(0, 0, 0), Ll = mk3(0, 0, 0);
     const bool nee = active && !bsdf_is_delta(v.bsdf);        // sample_all_light runs for non-delta vertices only (4571)
     // (wave-uniform calls: every lane makes them, `nee` says whether it takes part)
-    if (strategy == KY_DIRECT_BSDF) Lb = estimate_by_bsdf<false>(S, Lds, v, wo, li, r[11], r[12], nee);
-    else if (strategy == KY_DIRECT_BSDF_MIS || strategy == KY_DIRECT_BOTH_MIS) Lb = estimate_by_bsdf<true>(S, Lds, v, wo, li, r[11], r[12], nee);
+    const f3 one = mk3(1, 1, 1);   // the estimators ADD w x their estimate to an accumulator
+    if (strategy == KY_DIRECT_BSDF) estimate_by_bsdf<false>(S, Lds, v, wo, li, r[11], r[12], nee, Lb, one);
+    else if (strategy == KY_DIRECT_BSDF_MIS || strategy == KY_DIRECT_BOTH_MIS) estimate_by_bsdf<true>(S, Lds, v, wo, li, r[11], r[12], nee, Lb, one);
     if (nee) {
-        if (strategy == KY_DIRECT_LIGHT) Ll = estimate_by_emitter<false>(S, Lds, v, wo, li, r[13], r[14]);
-        else if (strategy == KY_DIRECT_LIGHT_MIS || strategy == KY_DIRECT_BOTH_MIS) Ll = estimate_by_emitter<true>(S, Lds, v, wo, li, r[13], r[14]);
+        if (strategy == KY_DIRECT_LIGHT) estimate_by_emitter<false>(S, Lds, v, wo, li, r[13], r[14], Ll, one);
+        else if (strategy == KY_DIRECT_LIGHT_MIS || strategy == KY_DIRECT_BOTH_MIS) estimate_by_emitter<true>(S, Lds, v, wo, li, r[13], r[14], Ll, one);
     }
     if (active) {
         float* o = out6 + 6 * (size_t)i;
@@ -1000,6 +1000,7 @@ static int pack_scene(const ky_scene* in, DScene* out) {
         bool no_delta = true;
         for (int i = 0; i < in->material_count; ++i) no_delta = no_delta && in->materials[i].kind != KY_MATERIAL_MIRROR && in->materials[i].kind != KY_MATERIAL_GLASS;
         if (no_delta) out->feat |= KY_FEAT_NO_DELTA;
+        if (in->surface_count <= KY_LDS_SURFACES_SMALL && in->material_count <= KY_LDS_MATERIALS_SMALL) out->feat |= KY_FEAT_SMALL_TABLES;
     }
     if (non.ts_light >= 0) {
         build_trav(out->occ_front, [&](int i) { return non.wall[i] != 0 || non.ts_behind[i] != 0; });

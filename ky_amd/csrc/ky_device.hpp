@@ -142,7 +142,8 @@ struct DHit {  // what is needed once the nearest surface is known; gathered per
     int32_t kind;
     int32_t material;
     int32_t area_light;
-};  // 24 B
+    int32_t pad_h[2];   // 32 B: a per-lane index becomes an LDS address by a shift (24 B cost a v_mul_lo_u32 at each of three look-ups per loop turn)
+};
 
 struct DMat {  // ky_material, gathered per lane from LDS
     float c0[3];        // lambert albedo | mirror R | glass R; plastic: Kd / P_diff, the Lambert lobe's albedo (2667)
@@ -367,9 +368,9 @@ KY_DEV void sampler_start(Sampler& s, uint32_t h, uint32_t sample_index) {
     s.s1 = mix32((h ^ 0x6A09E667u) + sample_index * 0x85EBCA6Bu) | 1u;
 }
 KY_DEV uint32_t rotl32(uint32_t x, int k) { return __builtin_amdgcn_alignbit(x, x, 32 - k); }   // v_alignbit_b32
-// xoroshiro64+ (Blackman / Vigna; a = 26, b = 9, c = 13): ten full-rate VALU instructions per number with the conversion -- three xor, two
-// v_alignbit, a shift, an add; shift, convert, scale -- against eleven for rounds 1-3's PCG-RXS-M-XS-32 with its two slow integer multiplies
-// (v_mul_lo_u32, v_mad_u64_u32).  The sum's weak low bits are the eight the conversion drops.
+// xoroshiro64+ (Blackman / Vigna; a = 26, b = 9, c = 13): nine full-rate VALU instructions per number with the conversion -- three xor, two
+// v_alignbit, a shift, an add; v_alignbit, subtract -- against eleven for rounds 1-3's PCG-RXS-M-XS-32 with its two slow integer multiplies
+// (v_mul_lo_u32, v_mad_u64_u32).  The sum's weak low bits are among the nine the conversion drops.
 template <bool DEBUG_SAMPLER>
 KY_DEV float sampler_next(Sampler& s) {
     if (DEBUG_SAMPLER) return 0.5f;  // debug_sampler_t, 933-941
@@ -377,7 +378,9 @@ KY_DEV float sampler_next(Sampler& s) {
     s.s1 ^= s.s0;
     s.s0 = rotl32(s.s0, 26) ^ s.s1 ^ (s.s1 << 9);
     s.s1 = rotl32(s.s1, 13);
-    return (float)(r >> 8) * (1.0f / 16777216.0f);
+    // the sum's upper 23 bits as the mantissa of a float in [1, 2), minus one: v_alignbit_b32 (0x7f : r) >> 9, v_sub -- two instructions where
+    // shift, convert, scale were three; the value is (r >> 9) 2^-23 exactly, which is how the oracle writes it
+    return __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, r, 9)) - 1.0f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -671,12 +674,14 @@ struct Bsdf {
 };
 KY_DEV bool bsdf_is_delta(const Bsdf& B) { return B.lobe == LOBE_MIRROR || B.lobe == LOBE_GLASS; }
 
+// material_t::scattering's choice of lobe (2587, 2604, 2628, 2661): the material kinds and the lobes are numbered alike (matte / Lambert 0, mirror 1,
+// glass 2, plastic / Phong 3), so the lobe IS the kind unless a plastic material's draw falls on its diffuse side (2663): one compare and one select.
+static_assert((int)KY_MATERIAL_MATTE == (int)LOBE_LAMBERT && (int)KY_MATERIAL_MIRROR == (int)LOBE_MIRROR && (int)KY_MATERIAL_GLASS == (int)LOBE_GLASS &&
+              (int)KY_MATERIAL_PLASTIC == (int)LOBE_PHONG, "pick_lobe");
 KY_DEV int pick_lobe(const DMat& M, float lobe_random, bool no_delta = false) {
-    if (no_delta) return (M.kind == KY_MATERIAL_PLASTIC && lobe_random < M.p_specular) ? LOBE_PHONG : LOBE_LAMBERT;   // KY_FEAT_NO_DELTA: a select of two constants
-    if (M.kind == KY_MATERIAL_MIRROR) return LOBE_MIRROR;
-    if (M.kind == KY_MATERIAL_GLASS) return LOBE_GLASS;
-    if (M.kind == KY_MATERIAL_PLASTIC && lobe_random < M.p_specular) return LOBE_PHONG;   // 2663
-    return LOBE_LAMBERT;
+    (void)no_delta;
+    const bool diffuse_side = (M.kind == KY_MATERIAL_PLASTIC) & !(lobe_random < M.p_specular);
+    return diffuse_side ? (int)LOBE_LAMBERT : M.kind;
 }
 KY_DEV Bsdf make_bsdf_for_lobe(const DMat& M, int lobe) { return Bsdf{lobe, &M}; }
 KY_DEV Bsdf make_bsdf(const DMat& M, float lobe_random, bool no_delta = false) { return Bsdf{pick_lobe(M, lobe_random, no_delta), &M}; }
@@ -762,7 +767,7 @@ KY_DEV LobeBasis make_lobe_basis(const Bsdf& B, f3 n, f3 wo) {
         // frame_t(wr): t = normalize(cross(wr, X or Y)), s = cross(t, wr).  t has a zero component, and the shading frame is a rotation
         // (s x t = n), so cross products may be taken in world space: b = to_world(t), c = to_world(wr), a = cross(b, c) -- one frame
         // transform of a vector with a zero component, one of wr, one cross product instead of a frame build and three transforms.
-        L.c = to_world(fr, wr);
+        L.c = (2.f * wo_l.z) * n - wo;   // to_world(fr, wr) = reflect(wo, n) (1923): the frame is a rotation
         if (fabsf(wr.x) > 0.99f) {
             const float k = rsq(wr.z * wr.z + wr.x * wr.x);
             L.b = fr.s * (-wr.z * k) + fr.n * (wr.x * k);       // t = (-wr.z, 0, wr.x) k

@@ -246,7 +246,7 @@ struct sampler_t {
         s1 ^= s0;
         s0 = rotl(s0, 26) ^ s1 ^ (s1 << 9);
         s1 = rotl(s1, 13);
-        return (float)(word >> 8) * (1.0f / 16777216.0f);                                 // [0, 1): the sum's upper 24 bits
+        return (float)(word >> 9) * (1.0f / 8388608.0f);                                  // [0, 1): the sum's upper 23 bits (exact: the device builds the same value as a mantissa)
     }
     vec2_t get_float2() { float a = get_float(); float b = get_float(); return {a, b}; }  // 965, 856-859
     // get_camera_sample, 943-946 / 971-974

@@ -12,7 +12,12 @@ LIBDIR   := ky_amd/lib
 
 all: $(LIBDIR)/libkyhip.so $(LIBDIR)/libkyhost.so oracle examples
 
-$(LIBDIR)/libkyhip.so: ky_amd/csrc/kyhip.hip ky_amd/csrc/ky_device.hpp ky_amd/csrc/ky_queue.hpp ky_amd/csrc/ky_smallpt.hpp ky_amd/csrc/ky_measure.hpp include/kyhip.h
+# the device headers as text inside the library: what its run-time instantiations compile (kyhip.hip, kyjit)
+RTC_INC := ky_amd/csrc/ky_rtc_sources.inc
+$(RTC_INC): ky_amd/csrc/ky_device.hpp ky_amd/csrc/ky_render.hpp include/kyhip.h tools/embed_sources.py
+	python3 tools/embed_sources.py $@ ky_device.hpp=ky_amd/csrc/ky_device.hpp ky_render.hpp=ky_amd/csrc/ky_render.hpp ../../include/kyhip.h=include/kyhip.h
+
+$(LIBDIR)/libkyhip.so: ky_amd/csrc/kyhip.hip ky_amd/csrc/ky_device.hpp ky_amd/csrc/ky_queue.hpp ky_amd/csrc/ky_smallpt.hpp ky_amd/csrc/ky_measure.hpp ky_amd/csrc/ky_render.hpp include/kyhip.h $(RTC_INC)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ ky_amd/csrc/kyhip.hip
 
@@ -36,6 +41,6 @@ build_variants/%: tools/ubench/%.hip
 	$(HIPCC) --offload-arch=gfx950 -O2 -Wno-unused-value -o $@ $<
 
 clean:
-	rm -rf $(LIBDIR) examples/bin
+	rm -rf $(LIBDIR) examples/bin $(RTC_INC)
 	$(MAKE) -C oracle clean
 .PHONY: all oracle examples ubench clean

@@ -488,7 +488,7 @@ def main():
         if default_line and not args.no_extra:
             line["extra_workloads"] = extra_workloads(args, run_workload, peak_tlaneops, lib, local_rank, kernel_total_ms)
             line["projected_scaling"] = projected_scaling(frames[0], dev, local_rank, lib, frame_kernel_ms[0], ms_per_step)
-        if default_line:
+        if default_line and not args.no_extra:
             line["boundary"] = boundary_rates(frames[0], dev, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             def gpu_render(scene, sample_params):
@@ -538,6 +538,40 @@ def extra_workloads(args, run_workload, peak_tlaneops, lib, local_rank, kernel_m
                                         "ratio_to_specialised_kernel": kernel_ms_specialised / sum(r["kernel_ms"]), "film_mean": r["film_mean"]}
     finally:
         lib.kyhip_set_specialisation(prev)
+    # Run-time instantiations (kyhip_set_jit, off by default): configs[1] on the kernel compiled for ALL of its scene's facts, and a scene the table
+    # has no row for -- the Cornell box lit by its lamp AND the point light, both_mis: deferred shadow rays without scene facts in the table, with
+    # this scene's facts when instantiated -- each against the table's kernel.  (The first launch of an instantiation compiles it: a warm-up step.)
+    import torch
+    dev = torch.device("cuda", local_rank)
+
+    def kernel_ms_of(scene, p, reps=3):
+        film = torch.zeros((p.height, p.width, 3), dtype=torch.float32, device=dev)
+        best = float("inf")
+        for _ in range(reps + 1):
+            kydist.render_distributed(scene, p, 0, 1, local_rank, film=film)
+            torch.cuda.synchronize(dev)
+            best = min(best, float(lib.kyhip_kernel_ms(local_rank)))
+        return best, lib.kyhip_last_kernel(local_rank).decode().split(" (")[0]
+
+    W, H = 1024, 768
+    two = api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | A.CB_LIGHT_AREA | A.CB_LIGHT_POINT, W, H)
+    cases = {"cornell": (api.cornell_box_scene(A.CB_DEFAULT_SCENE, W, H), api.make_params(W, H, 1024)),
+             "cornell_lamp_and_point_light": (two, api.make_params(W, H, 256))}
+    jit = {}
+    prev = lib.kyhip_set_jit(0)
+    try:
+        for label, (scene, p) in cases.items():
+            lib.kyhip_set_jit(0)
+            t_ms, t_kernel = kernel_ms_of(scene, p)
+            lib.kyhip_set_jit(1)
+            o_ms, o_kernel = kernel_ms_of(scene, p)
+            samples = p.width * p.height * p.samples_per_pixel
+            jit[label] = {"spp": p.samples_per_pixel, "table": {"kernel": t_kernel, "kernel_ms": t_ms, "value": samples / t_ms / 1e3},
+                          "own": {"kernel": o_kernel, "kernel_ms": o_ms, "value": samples / o_ms / 1e3}, "unit": "Msamples/s (kernel time)", "own_over_table": t_ms / o_ms}
+        jit["status"] = lib.kyhip_jit_status().decode()
+    finally:
+        lib.kyhip_set_jit(prev)
+    out["run_time_instantiations"] = jit
     return out
 
 

@@ -20,8 +20,10 @@
 #ifndef KYHIP_H
 #define KYHIP_H
 
+#ifndef __HIPCC_RTC__   /* the library compiles this header at run time too (hiprtc: no system headers, the types are built in) */
 #include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -193,6 +195,19 @@ int         kyhip_set_engine(int engine);
    compiler contracts a few multiply-adds differently once code around them is gone).  Returns the previous setting.
    A tuning knob, like kyhip_set_engine. */
 int         kyhip_set_specialisation(int on);
+/* Run-time instantiations.  The render kernel is a template over (sampler, strategy, integrator, deferred shadow rays, general shapes, scene
+   facts, table size); the library ships a fixed table of instantiations and picks the nearest one per launch.  mode 1: a launch whose exact
+   combination -- with ALL of its scene's facts -- is not in the table gets its own kernel, compiled from the library's embedded source by the
+   ROCm compiler (a child process: $KYHIP_HIPCC, default /opt/rocm/bin/hipcc) on first use (a few seconds, blocking that launch; afterwards a
+   code object in memory and under $KYHIP_CACHE_DIR, default ~/.cache/kyhip).
+   mode 0 (default; environment variable KYHIP_JIT=1 turns it on): the table only.  The image does not depend on it beyond the last bit of a pixel
+   (like kyhip_set_specialisation).  If no compiler is found or a compile fails, the table's kernel runs and kyhip_jit_status() says why.
+   Returns the previous mode.  A tuning knob, not part of the reference's interface. */
+int         kyhip_set_jit(int mode);
+const char* kyhip_jit_status(void);
+/* Host only (no GPU needed): compiles -- or fetches from the cache -- the instantiation named by a C++ expression such as
+   "render_kernel<false, 48, false, false, 135, 11, false>" and returns the size of its gfx950 code object, or a negative ky_status. */
+int64_t     kyhip_jit_compile(const char* name_expression);
 int         kyhip_abi_version(void);
 int         kyhip_device_count(void);
 

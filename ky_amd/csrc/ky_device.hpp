@@ -22,8 +22,10 @@
  * This file is independent of oracle/ (the CPU checker): nothing is shared between the two.
  */
 #pragma once
+#ifndef __HIPCC_RTC__   // hiprtc brings the device runtime and the fixed-width integer types itself (ky_render.hpp is also compiled at run time)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #include "../../include/kyhip.h"
 
@@ -477,8 +479,8 @@ KY_DEV const T& scene_at(SceneRef S, unsigned off) { return *(const T*)((const c
 // a record of the scene whose fields are read at several places of the path loop: the offset is (re)made where the record is used -- one
 // s_mov / s_mul -- instead of one hoisted pointer per FIELD ADDRESS living (spilled) across the loop
 KY_DEV unsigned opaque_off(unsigned off) { asm volatile("" : "+s"(off)); return off; }
-KY_DEV const DLight& scene_light(SceneRef S, int li) { return scene_at<DLight>(S, opaque_off((unsigned)offsetof(DScene, light) + (unsigned)li * (unsigned)sizeof(DLight))); }
-KY_DEV const DSurf& scene_surf(SceneRef S, int i) { return scene_at<DSurf>(S, opaque_off((unsigned)offsetof(DScene, all) + (unsigned)i * (unsigned)sizeof(DSurf))); }
+KY_DEV const DLight& scene_light(SceneRef S, int li) { return scene_at<DLight>(S, opaque_off((unsigned)__builtin_offsetof(DScene, light) + (unsigned)li * (unsigned)sizeof(DLight))); }
+KY_DEV const DSurf& scene_surf(SceneRef S, int i) { return scene_at<DSurf>(S, opaque_off((unsigned)__builtin_offsetof(DScene, all) + (unsigned)i * (unsigned)sizeof(DSurf))); }
 
 // the axis-aligned rectangles of one axis: records [first, first + n) of the table at byte offset `aar_off`, whose sorted surface indices are the same
 template <int AXIS, bool NEAREST>
@@ -528,20 +530,20 @@ KY_DEV bool surf_hit(const DSurf& S, const DShapeFull* __restrict__ full, f3 o, 
 // scene_t::intersect, ky.cpp:3172-3184: linear scan, tmax shrinks, first of equals wins.  Returns the SORTED surface index.
 KY_DEV int trace_nearest(SceneRef S, f3 o, f3 d, float& tmax) {
     int best = -1;
-    const unsigned t_off = opaque_off((unsigned)offsetof(DScene, trav));
+    const unsigned t_off = opaque_off((unsigned)__builtin_offsetof(DScene, trav));
     const int4 head = scene_at<int4>(S, t_off), axis = scene_at<int4>(S, t_off + 16u);   // n_aar, n_par; n_aar_axis[3]
     const int n_aar = head.x, n_par = head.y, n_sph = S->n_sph, n_gen = S->n_gen;
     if (n_aar > 0) {
         const f3 inv_d = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
         bool unused = false;
         const int n0 = axis.x, n1 = axis.y, n2 = axis.z;
-        const unsigned aar_off = t_off + (unsigned)offsetof(DTrav, aar);
+        const unsigned aar_off = t_off + (unsigned)__builtin_offsetof(DTrav, aar);
         aar_scan<0, true>(S, aar_off, 0, n0, o, d, inv_d, tmax, best, unused);
         aar_scan<1, true>(S, aar_off, n0, n1, o, d, inv_d, tmax, best, unused);
         aar_scan<2, true>(S, aar_off, n0 + n1, n2, o, d, inv_d, tmax, best, unused);
     }
     if (n_par > 0) {
-        unsigned off = t_off + (unsigned)offsetof(DTrav, par);
+        unsigned off = t_off + (unsigned)__builtin_offsetof(DTrav, par);
         for (int i = 0; i < n_par; ++i) {
             asm volatile("" : "+s"(off));
             const DPar& r = scene_at<DPar>(S, off);
@@ -584,13 +586,13 @@ KY_DEV bool trace_any_planar(SceneRef S, const DTrav& T, f3 o, f3 d, float tmax)
         const f3 inv_d = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
         int unused = -1;
         const int n0 = axis.x, n1 = axis.y, n2 = axis.z;
-        const unsigned aar_off = t_off + (unsigned)offsetof(DTrav, aar);
+        const unsigned aar_off = t_off + (unsigned)__builtin_offsetof(DTrav, aar);
         aar_scan<0, false>(S, aar_off, 0, n0, o, d, inv_d, tmax, unused, occ);
         aar_scan<1, false>(S, aar_off, n0, n1, o, d, inv_d, tmax, unused, occ);
         aar_scan<2, false>(S, aar_off, n0 + n1, n2, o, d, inv_d, tmax, unused, occ);
     }
     if (n_par > 0) {
-        unsigned off = t_off + (unsigned)offsetof(DTrav, par);
+        unsigned off = t_off + (unsigned)__builtin_offsetof(DTrav, par);
         for (int i = 0; i < n_par; ++i) {
             asm volatile("" : "+s"(off));
             const DPar& r = scene_at<DPar>(S, off);
@@ -1420,7 +1422,7 @@ KY_DEV bool light_sample_occluded(SceneRef S, int li, f3 o, f3 dir, float tmax) 
     const bool two = li == S->ts_light;
     bool occ = trace_any(S, two ? S->occ_front : (ok ? S->occ : S->trav), o, dir, tmax);
     if (two) {   // what is mounted behind the lamp: only a ray with an end in that half-space can meet it (DScene::occ_behind)
-        const float4 plane = scene_at<float4>(S, opaque_off((unsigned)offsetof(DScene, ts_plane)));
+        const float4 plane = scene_at<float4>(S, opaque_off((unsigned)__builtin_offsetof(DScene, ts_plane)));
         const f3 pn = mk3(plane.x, plane.y, plane.z);
         const f3 e = o + dir * tmax;
         const bool need = !occ && (fminf(dot(pn, e), dot(pn, o)) <= plane.w);

@@ -30,6 +30,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <condition_variable>
+#include <map>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <cstring>
 #include <functional>
 #include <limits>
@@ -39,10 +42,8 @@
 #include <thread>
 #include <vector>
 
-#include "ky_device.hpp"
+#include "ky_render.hpp"
 #include "ky_smallpt.hpp"
-
-using namespace kyd;
 
 // ------------------------------------------------------------------------------------------------
 // error handling
@@ -67,86 +68,6 @@ static int fail(int code, const char* fmt, ...) {
 // ------------------------------------------------------------------------------------------------
 // shard geometry (host + device)
 // ------------------------------------------------------------------------------------------------
-// Samples of a pixel are cut into chunks (= work items) by a schedule that depends on spp ONLY (chunk boundaries must not depend on
-// the sharding, or images would differ between GPU counts: a chunk's samples are summed in float before they enter the fixed-point
-// accumulator).  The bulk is KY_CHUNK-sample chunks; the END of the sample range tapers off -- KY_TAPER_16 samples in 16-sample
-// chunks, then KY_TAPER_8 in 8s, KY_TAPER_4 in 4s, KY_TAPER_2 in 2s -- and items are queued chunk-major, so the small chunks of all
-// blocks come last: the tail of a launch, where wavefronts run out of work one by one, is as long as ONE of the smallest items, while
-// nearly all samples are rendered in chunks large enough to make the per-chunk bookkeeping (flush, refill) invisible.
-// Sizing (tools/shard_scan.py, profiles/r03_taper_scan.txt): a wavefront needs about 1.1 ms for a 32-sample item, and wavefronts
-// finish their last one up to that far apart; the stage that follows evens it out if it holds at least as much work per wavefront,
-// which for a 1/8 shard of configs[1] (7.3 ms per launch) is 256 samples of 16, then 128 of 8, then 64 of 4.  Measured kernel-level
-// efficiency at N = 8: no taper 0.88, 256 samples of 8 (round 2) 0.93, 128/64/32 0.92, 256/128/64 0.96; longer tapers (384/192/96/48)
-// do not make the shard faster and cost the full frame 1-2.5 %.
-#ifndef KY_CHUNK_BIG
-#define KY_CHUNK_BIG 24   // round 4 (profiles/r04_b_chunk_scan.txt): 24-sample bulk chunks leave the full frame where 32 had it (50.5 against 50.6 ms) and make the
-#endif                    // slowest 1/8 shard of configs[1] 2-3 % faster (6.65-6.68 against 6.79-6.89 ms: N = 8 kernel efficiency 0.947-0.950 against 0.918-0.931);
-                          // 16 and 20 cost the full frame 1.3-1.9 %, and no other taper (192/96/48, a 2-sample stage, ...) beat 256/128/64 in shard time
-#ifndef KY_TAPER_16
-#define KY_TAPER_16 256
-#endif
-#ifndef KY_TAPER_8
-#define KY_TAPER_8 128
-#endif
-#ifndef KY_TAPER_4
-#define KY_TAPER_4 64
-#endif
-#ifndef KY_TAPER_2
-#define KY_TAPER_2 0
-#endif
-constexpr int KY_CHUNK = KY_CHUNK_BIG;
-static_assert(KY_CHUNK_BIG <= 127, "the lane's sample cursor keeps the chunk's remaining samples in 7 bits");
-#ifndef KY_RING_SLOTS
-#define KY_RING_SLOTS 3   // (a wave reads at most the two newest items; three slots keep the standard kernels' LDS block under 20 480 bytes: eight per CU)
-#endif
-constexpr int KY_RING = KY_RING_SLOTS;          // fetched-but-not-yet-started items a wave can hold
-constexpr double KY_FIX_SCALE = 4294967296.0;   // 2^32: accumulator resolution 2.3e-10, range +-2.1e9
-
-// The chunk schedule of `spp` samples (host and device; wave-uniform scalar arithmetic on the device, once per fetched item; written
-// without arrays so that nothing of it lives in scratch memory).
-struct ChunkPlan {
-    int n_big, head;            // chunks of KY_CHUNK samples cover [0, head)
-    int b1, b2, b3, b4;         // 16-sample chunks cover [head, b1), 8s [b1, b2), 4s [b2, b3), 2s [b3, b4 = spp)
-    int n16, n8, n4, n2;
-};
-__host__ __device__ inline ChunkPlan chunk_plan(int spp) {
-    ChunkPlan p;
-    p.b4 = spp;
-    p.b3 = p.b4 > KY_TAPER_2 ? p.b4 - KY_TAPER_2 : 0;
-    p.b2 = p.b3 > KY_TAPER_4 ? p.b3 - KY_TAPER_4 : 0;
-    p.b1 = p.b2 > KY_TAPER_8 ? p.b2 - KY_TAPER_8 : 0;
-    const int b0 = p.b1 > KY_TAPER_16 ? p.b1 - KY_TAPER_16 : 0;
-    p.head = (b0 / KY_CHUNK) * KY_CHUNK;   // what is left of the bulk's last chunk goes to the 16-sample segment
-    p.n_big = p.head / KY_CHUNK;
-    p.n16 = (p.b1 - p.head + 15) / 16;
-    p.n8 = (p.b2 - p.b1 + 7) / 8;
-    p.n4 = (p.b3 - p.b2 + 3) / 4;
-    p.n2 = (p.b4 - p.b3 + 1) / 2;
-    return p;
-}
-__host__ __device__ inline int chunk_count(const ChunkPlan& p) { return p.n_big + p.n16 + p.n8 + p.n4 + p.n2; }
-__host__ __device__ inline void chunk_range(const ChunkPlan& p, int c, int& s_begin, int& s_end) {
-    int size = KY_CHUNK, first = 0, limit = p.head, n_seg = p.n_big;
-    c -= p.n_big;
-    if (c >= 0) { size = 16; first = p.head; limit = p.b1; n_seg = p.n16; c -= p.n16; }
-    if (c >= 0) { size = 8; first = p.b1; limit = p.b2; n_seg = p.n8; c -= p.n8; }
-    if (c >= 0) { size = 4; first = p.b2; limit = p.b3; n_seg = p.n4; c -= p.n4; }
-    if (c >= 0) { size = 2; first = p.b3; limit = p.b4; n_seg = p.n2; c -= p.n2; }
-    // c is now (index inside its segment) - (chunks of that segment): count back from the segment's chunk count
-    s_begin = first + (c + n_seg) * size;
-    s_end = s_begin + size < limit ? s_begin + size : limit;
-}
-
-struct ShardConst {
-    int tile_w, tile_h, tile_first, tile_step;
-    int tiles_x, tiles_y, n_tiles;     // tiles of the whole film / tiles owned by this shard
-    int blocks_w, blocks_per_tile;     // 8x8 pixel blocks inside a tile
-    int n_blocks;                      // n_tiles * blocks_per_tile
-    int n_chunks;                      // chunk_count(chunk_plan(spp))
-    unsigned n_items;                  // n_blocks * n_chunks
-    int n_pix;                         // n_tiles * tile_w * tile_h
-};
-
 static bool valid_params(const ky_render_params* p) {
     if (!p) return false;
     if (p->width <= 0 || p->height <= 0 || p->samples_per_pixel <= 0 || p->max_path_depth < 0 || p->max_path_depth > 250) return false;
@@ -201,222 +122,6 @@ static ShardConst make_shard(const ky_render_params* p) {
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-#ifndef KY_MAX_RETRACE
-#define KY_MAX_RETRACE 1
-#endif
-#ifndef KY_RETRACE_THRESHOLD
-#define KY_RETRACE_THRESHOLD 80
-#endif
-#ifndef KY_WAVES_PER_EU
-#define KY_WAVES_PER_EU 7           // the hot instantiation <false, both_mis, feat 7>: 72 VGPRs, nothing spilled (six: 80; +3.5 % for the seventh wavefront)
-#endif
-#ifndef KY_WAVES_PER_EU_QUEUE
-#define KY_WAVES_PER_EU_QUEUE 5     // the instantiation with deferred shadow rays: 96 VGPRs (6 spilled) beat 80 (28 spilled) by 3.5 % since round 3
-#endif
-#ifndef KY_WAVES_PER_EU_QUEUE_FEAT
-#define KY_WAVES_PER_EU_QUEUE_FEAT 7   // ... with scene facts (the sphere-lights kernel): round 4, with its LDS block at 22.9 KB (KY_FEAT_SMALL_TABLES, the pixel key recomputed): 72 VGPRs with 10 spilled beat 80 with 8 at six by 3.4 % (111.7 against 115.5 ms at 1024 spp)
-#endif
-#ifndef KY_WAVES_PER_EU_HOT
-#define KY_WAVES_PER_EU_HOT 8          // the iterative integrator's both_mis with a single-light fact (every Cornell configuration): 64 VGPRs with 0-4 spilled, +1 % over
-#endif                                 // seven (+1.0 ... +2.9 % per Cornell light variant); the other strategies lose up to 15 % at eight
-#ifndef KY_WAVES_PER_EU_NO_FACTS
-#define KY_WAVES_PER_EU_NO_FACTS 6     // both_mis without scene facts (any lights, inline shadow rays; every integrator): 19-39 spilled VGPRs at seven
-#endif
-#ifndef KY_WAVES_PER_EU_GENERIC
-#define KY_WAVES_PER_EU_GENERIC 5   // strategy / integrator read at run time: more code alive at once, 96 VGPRs measured best
-#endif
-
-constexpr int KY_FEAT_CORNELL = KY_FEAT_SINGLE_AREA | KY_FEAT_RECT_LIGHTS | KY_FEAT_CARRIERS;   // what the Cornell-lamp instantiation assumes
-constexpr int KY_FEAT_VEACH = KY_FEAT_SPHERE_LIGHTS | KY_FEAT_CARRIERS | KY_FEAT_NO_DELTA | KY_FEAT_SMALL_TABLES;   // what the sphere-lights instantiations assume (create_mis_scene)
-
-struct ItemSlot {  // one fetched work item, decoded once (wave-uniform) and read per lane
-    int x0, y0, pix0, s_begin, s_end;
-};
-
-// STRATEGY >= 0 fixes direct_sample_enum AND the integrator at compile time (prunes the other estimators and integrators); -1 reads both
-// from rc.
-// QUEUE (with STRATEGY = both_mis): the light-sampling halves' shadow rays are deferred to the wave's stack `queue_mem`
-// (ky_device.hpp, "deferred shadow rays") and traced 64 at a time.
-// GENERAL: the scene may hold quads that are not parallelograms, triangles or disks (SceneRef::general); no shipped scene does.
-// FEAT: KY_FEAT_* facts the instantiation assumes about the scene (SceneRef::feat): one rectangle area light (every Cornell-box
-// configuration of BASELINE.json), one point / directional light, one environment light (the other Cornell variants of ky's drivers).
-// INTEGRATOR (with STRATEGY >= 0): path_tracing_iteration_t, or direct_lighting_t / one of the three recursive integrators
-// (render_multiple_integrator, ky.cpp:4740-4777, runs all five side by side).
-// The host's table of instantiations is g_variants below; kyhip_render_tiles_device launches the first one whose assumptions hold.
-// LARGE: the scene's per-lane tables live in dynamic shared memory sized by the scene (more than KY_LDS_SURFACES surfaces or
-// KY_LDS_MATERIALS materials; ky_device.hpp, LdsScene).
-template <bool DEBUG_SAMPLER, int STRATEGY, bool QUEUE = false, bool GENERAL = false, int FEAT = 0, int INTEGRATOR = KY_INTEGRATOR_PATH_TRACING_ITERATION, bool LARGE = false>
-__global__ __launch_bounds__(256, STRATEGY >= 0 ? (QUEUE ? (FEAT ? KY_WAVES_PER_EU_QUEUE_FEAT : KY_WAVES_PER_EU_QUEUE)
-                                                          : ((FEAT == 0 && STRATEGY == KY_DIRECT_BOTH_MIS) ? KY_WAVES_PER_EU_NO_FACTS
-                                                             : ((FEAT != 0 && STRATEGY == KY_DIRECT_BOTH_MIS && INTEGRATOR == KY_INTEGRATOR_PATH_TRACING_ITERATION) ? KY_WAVES_PER_EU_HOT : KY_WAVES_PER_EU)))
-                                                : KY_WAVES_PER_EU_GENERIC) void render_kernel(const DScene* __restrict__ S_, RenderConst rc, ShardConst sh,
-                                                                     unsigned* __restrict__ counter, unsigned long long* __restrict__ accum,
-                                                                     unsigned* __restrict__ flags, float4* __restrict__ queue_mem) {
-    static_assert(!QUEUE || ((STRATEGY == KY_DIRECT_BOTH_MIS || STRATEGY == KY_DIRECT_LIGHT_MIS || STRATEGY == KY_DIRECT_LIGHT) && INTEGRATOR == KY_INTEGRATOR_PATH_TRACING_ITERATION),
-                  "the deferred shadow rays belong to the iterative integrator's strategies with a light-sampling half");
-    static_assert(FEAT == 0 || (STRATEGY >= 0 && !GENERAL && !DEBUG_SAMPLER), "scene facts are instantiated for kernels with a fixed strategy only");
-    static_assert(STRATEGY >= 0 || INTEGRATOR == KY_INTEGRATOR_PATH_TRACING_ITERATION, "the run-time-dispatched kernel reads the integrator from rc");
-    const SceneRef S{S_, GENERAL, FEAT, LARGE};
-    __shared__ ItemSlot ring[4][KY_RING];
-    // the lane's pixel chunk (touched when a path starts or ends, not while a vertex is shaded) lives in LDS, not in registers
-    __shared__ int c_xy[256], c_pix[256];
-    __shared__ unsigned c_se[256];   // next sample << 7 | samples left in the chunk
-    __shared__ uint32_t c_key[QUEUE ? 1 : 256];   // the pixel's sampler key; the deferred-rays kernels recompute it per sample instead (1 KB of their LDS block)
-    __shared__ unsigned long long c_def[QUEUE ? 3 * 256 : 1];   // QUEUE: fixed-point sums of the lane's resolved shadow rays
-    const int tid = threadIdx.x;
-    const LdsScene Lds = stage_scene<LARGE, (FEAT & KY_FEAT_SMALL_TABLES) != 0>(S);
-    if (STRATEGY >= 0) { rc.strategy = STRATEGY; rc.integrator = INTEGRATOR; }  // compile-time constants from here on
-    const int nee_weight = (rc.strategy == KY_DIRECT_IDLE || rc.integrator < KY_INTEGRATOR_DIRECT_LIGHTING ||
-                            rc.integrator == KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION) ? 0 : S->n_lights;
-
-    const int lane = threadIdx.x & 63;
-    ItemSlot* my_ring = ring[threadIdx.x >> 6];
-
-    // wave-uniform: the wave's pool of work is the sequence of (item, pixel) pairs of the items it has fetched;
-    // `cursor` counts the pairs handed out so far (pair n = pixel n % 64 of fetched item n / 64)
-    int fetched = 0;
-    int cursor = 0;
-    bool exhausted = false;   // the global counter ran past n_items
-    // per lane: the pixel chunk being worked on
-    c_pix[tid] = -1;
-    ShadowQueue sq{nullptr, 0, c_pix, c_def, accum, flags};
-    if (QUEUE) {
-        c_def[tid] = 0; c_def[256 + tid] = 0; c_def[512 + tid] = 0;
-        sq.base = queue_mem + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * (KY_SQ_ENTRY * KY_SQ_CAP);
-    }
-    bool open = false;        // the chunk has samples left to start (s < s_end)
-    bool has_item = false, done = false, alive = false;
-    PathState ps;
-    ps.Lo = mk3(0, 0, 0);
-
-    KY_CLK(-1);
-    for (;;) {
-        KY_CLK(9);   // continuation sampling, roulette, loop overhead
-        // ---- (1) lanes whose pixel chunk is finished flush it and take the next (item, pixel) pair of the wave's pool.
-        // A lane is NOT tied to one pixel position: whichever lane is free takes the next pixel, so lanes never wait
-        // for each other and the wave drains within one chunk of the end of the queue.
-        const bool need = !alive && !done && !open;
-        const unsigned long long need_mask = __ballot(need);
-        if (need_mask) {  // wave-uniform branch: every lane runs the bookkeeping below
-            if (need && has_item) {
-                const float v[3] = {ps.Lo.x * rc.inv_spp, ps.Lo.y * rc.inv_spp, ps.Lo.z * rc.inv_spp};   // 3717, once per chunk
-                ps.Lo = mk3(0, 0, 0);
-                const int pix = c_pix[tid];
-                c_pix[tid] = -1;   // rays of this chunk that are still on the stack go to the global accumulator directly
-                unsigned fl = 0;
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    unsigned long long fx = film_fixed(v[ch], ch, fl);   // NaN / +-inf: flag bits, nothing added
-                    if (QUEUE) { fx += c_def[ch * 256 + tid]; c_def[ch * 256 + tid] = 0; }
-                    if (fx != 0) atomicAdd(&accum[(size_t)pix * 3 + ch], fx);
-                }
-                if (fl) atomicOr(&flags[pix], fl);
-                has_item = false;
-            }
-            const int n_need = __popcll(need_mask);
-            // fetch until the pool covers every requesting lane (at most two items: n_need <= 64), or the queue is empty.
-            // Slot reuse: item fetched - KY_RING was handed out completely long ago (cursor >= (fetched - 2) * 64).
-            while (!exhausted && cursor + n_need > fetched * 64) {
-                // a wave's first item is its own index: the launch does not begin with every wavefront of the chip queueing at one
-                // counter (one word serves ~90 dequeues per microsecond); later items come from the counter, offset by the wave count
-                unsigned id = blockIdx.x * 4u + (threadIdx.x >> 6);
-                if (fetched > 0 && lane == 0) id = atomicAdd(counter, 1u) + gridDim.x * 4u;
-                id = __builtin_amdgcn_readfirstlane(id);
-                if (id >= sh.n_items) { exhausted = true; break; }
-                const int c = (int)(id / (unsigned)sh.n_blocks), b = (int)(id % (unsigned)sh.n_blocks);   // chunk-major
-                const int k = b / sh.blocks_per_tile, inner = b % sh.blocks_per_tile;
-                const int bx = inner % sh.blocks_w, by = inner / sh.blocks_w;
-                const int tile = sh.tile_first + k * sh.tile_step;
-                if (lane == 0) {
-                    ItemSlot it;
-                    const int trow = tile / sh.tiles_x, tcol = (tile % sh.tiles_x + trow) % sh.tiles_x;   // rotated rows
-                    it.x0 = tcol * sh.tile_w + bx * 8;
-                    it.y0 = trow * sh.tile_h + by * 8;
-                    it.pix0 = (k * sh.tile_h + by * 8) * sh.tile_w + bx * 8;
-                    chunk_range(chunk_plan(rc.spp), c, it.s_begin, it.s_end);
-                    my_ring[fetched % KY_RING] = it;
-                }
-                ++fetched;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // lane 0's slot writes before the other lanes' reads
-            if (need) {
-                // number of requesting lanes below this one: v_mbcnt, no lane mask kept in registers
-                const int mine = cursor + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(need_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need_mask, 0u));
-                if (mine < fetched * 64) {
-                    const ItemSlot it = my_ring[(mine >> 6) % KY_RING];
-                    const int px = mine & 7, py = (mine >> 3) & 7;
-                    const int x = it.x0 + px, y = it.y0 + py;
-                    const bool in_range = x < rc.width && y < rc.height;
-                    c_xy[tid] = x | (y << 16);
-                    c_pix[tid] = it.pix0 + py * sh.tile_w + px;
-                    if (!QUEUE) c_key[tid] = sampler_pixel_key(rc.seed, (uint32_t)(y * rc.width + x));
-                    c_se[tid] = ((unsigned)it.s_begin << 7) | (unsigned)(it.s_end - it.s_begin);
-                    open = in_range && it.s_begin < it.s_end;
-                    has_item = in_range;
-                } else {
-                    done = true;  // only reachable once the queue is exhausted
-                }
-            }
-            cursor = min(cursor + n_need, fetched * 64);
-        }
-        KY_CLK(0);
-        // ---- (2) regenerate + trace until enough lanes hold a vertex ----
-        // A lane whose path ends at the traversal itself (a miss, the depth cap) would sit out the whole shading phase,
-        // which costs 2 traversals per light.  When many lanes are in that state, they regenerate and trace once more
-        // before the wave moves on (wave-uniform decision), so the expensive phase runs with fuller lanes.
-        Vertex v;
-        v.in_lds = true;   // shading frame and local wo in LDS (ky_device.hpp, VertexLds)
-        bool have_vertex = false;
-        for (int attempt = 0;; ++attempt) {
-            if (!alive && !done && open) {  // next camera sample of this lane's pixel, 3712-3715
-                const int xy = c_xy[tid];
-                const unsigned se = c_se[tid];
-                const uint32_t key = QUEUE ? sampler_pixel_key(rc.seed, (uint32_t)((xy >> 16) * rc.width + (xy & 0xffff))) : c_key[tid];
-                path_begin<DEBUG_SAMPLER, true>(ps, S, key, xy & 0xffff, xy >> 16, (int)(se >> 7));
-                c_se[tid] = se + 127;             // next sample + 1, samples left - 1
-                open = (se & 127) > 1;
-                alive = true;
-            }
-            const bool tracing = alive && !have_vertex;
-            if (!__any(tracing)) break;
-            if (tracing) {
-                const bool ended = !path_intersect<DEBUG_SAMPLER>(ps, v, S, Lds, rc);
-                if (!ended) have_vertex = true;
-                if (ended) {
-                    alive = false;
-                }
-            }
-            // (single-light instantiations never retrace: one more traversal against two per vertex never paid there, and the loop
-            // around it cost 1.9 % by itself; with Veach's five lights the retrace is worth 16 %)
-            if (attempt >= ((FEAT & KY_FEAT_SINGLE_LIGHT) ? 0 : KY_MAX_RETRACE)) break;
-            // lanes that could start another path right now; worth one more traversal if they would otherwise idle
-            // through (2 traversals x lights + shading) that is worth more than the extra traversal
-            const int idle = __popcll(__ballot(!alive && !done && open));
-            if (idle * (2 * nee_weight + 1) < KY_RETRACE_THRESHOLD) break;
-        }
-        KY_CLK(1);
-        if (!__any(alive)) {
-            if (__all(done)) break;
-            path_state_dead(ps);   // no lane holds a path: nothing of the path state is carried into the next turn (but Lo, the chunks' sums)
-            continue;  // lanes are between items: (1) serves them on the next turn
-        }
-        unsigned tag = 0;
-        if (QUEUE) tag = ((unsigned)c_pix[tid] << 6) | (unsigned)lane;
-        // ---- (3) shade the vertex: direct lighting, continuation ----
-        {
-            const bool cont = path_shade<DEBUG_SAMPLER>(ps, v, S, Lds, rc, have_vertex, -1, nullptr, QUEUE ? &sq : nullptr, tag,
-                                                        STRATEGY >= 0 && INTEGRATOR == KY_INTEGRATOR_PATH_TRACING_RECURSION, true);  // wave-uniform call
-            if (have_vertex && !cont) {
-                alive = false;
-            }
-        }
-    }
-    if (QUEUE) {  // what is left on the stack: the lanes have flushed, so these go to the global accumulators
-        sq_drain(S, sq);
-    }
-    KY_CLK(-2);
-}
-
 #include "ky_queue.hpp"   // the queue engine: render_kernel_q
 
 // fixed-point accumulator -> clamp01(L) (3726) -> fp32 tile buffer
@@ -1170,6 +875,9 @@ struct DeviceCtx {
     size_t variant_lds[48] = {};           // ... for a scene block of this many bytes
     int last_variant = -1;
     int q_blocks_per_cu[3] = {0, 0, 0};
+    struct JitKernel { hipModule_t module = nullptr; hipFunction_t fn = nullptr; int per_cu = 0; size_t lds = ~(size_t)0; bool failed = false; };
+    std::map<std::string, JitKernel> jit;   // run-time instantiations loaded on this device, by template arguments
+    std::string last_jit;                   // ... and the one the last launch used (last_variant == -3)
 };
 static std::mutex g_ctx_mutex;                          // guards g_ctx itself (creation), never held while enqueueing
 static std::vector<std::unique_ptr<DeviceCtx>> g_ctx;   // index = HIP device ordinal
@@ -1364,6 +1072,148 @@ static int kat_run(int device, const void* in, size_t in_bytes, void* out, size_
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// run-time instantiations: a launch's exact render kernel, compiled on first use
+//
+// g_variants is a fixed table: the both_mis kernel for five combinations of scene facts, one kernel per other strategy, and the run-time-dispatched
+// kernel for everything else -- a scene with a triangle in it, a rectangle light next to a point light, light_mis under the debug sampler.  The
+// render kernel is a template over exactly those choices (ky_render.hpp), and the library carries its source (ky_rtc_sources.inc: ky_device.hpp,
+// ky_render.hpp, include/kyhip.h as text), so with kyhip_set_jit(1) / KYHIP_JIT=1 a launch whose (sampler, strategy, integrator, deferred rays,
+// general shapes, ALL of the scene's facts, table size) is not a row of the table gets its own instantiation: the sources are written to the cache
+// directory, the ROCm compiler that built the library compiles one extern "C" kernel around render_kernel_body<...> into a gfx950 code object
+// (a child process: `hipcc --genco`, 2-3 seconds, blocking the first launch that needs it), and the object is kept in memory and on disk
+// ($KYHIP_CACHE_DIR, default ~/.cache/kyhip) and loaded per device with hipModuleLoadData.
+// Why a child process and not hiprtc: a process that has PyTorch in it has PyTorch's bundled hiprtc / comgr in it, and the ROCm 7.0 one aborts the
+// process on this kernel ("LLVM ERROR: Not supported instr", measured) -- a library cannot pick which comgr its host process has loaded.
+// Off by default (the table serves every scene ky ships); if no compiler is found or a compile fails the launch takes the table's kernel and
+// kyhip_jit_status() says why.
+// ------------------------------------------------------------------------------------------------
+#include "ky_rtc_sources.inc"
+
+namespace kyjit {
+struct Code {   // one compiled instantiation
+    std::vector<char> object;
+    bool failed = false;
+};
+static const char k_entry[] = "ky_jit_kernel";    // the extern "C" name of every run-time instantiation's kernel
+static std::mutex g_mutex;                        // compiles are serialised
+static std::map<std::string, Code> g_code;        // template arguments -> code object
+static std::string g_status = "off";
+static int g_mode = -1;                           // 0 off, 1 on
+
+static int mode() {
+    if (g_mode < 0) {
+        const char* e = std::getenv("KYHIP_JIT");
+        g_mode = (e && std::atoi(e) != 0) ? 1 : 0;
+    }
+    return g_mode;
+}
+
+// what the Makefile passes to hipcc for kyhip.hip, as far as device code goes
+static const char k_flags[] = "--genco --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fno-hip-fp32-correctly-rounded-divide-sqrt -Wno-unused-function "
+                              "-Wno-bitwise-instead-of-logical";
+
+static uint64_t hash_bytes(uint64_t h, const void* p, size_t n) {
+    const unsigned char* b = (const unsigned char*)p;
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+static uint64_t source_hash() {
+    static const uint64_t h = [] {
+        uint64_t x = 0xcbf29ce484222325ull;
+        for (const auto& src : g_rtc_sources) x = hash_bytes(x, src.text, std::strlen(src.text));
+        return hash_bytes(x, k_flags, sizeof k_flags);
+    }();
+    return h;
+}
+static void mkdir_p(const std::string& dir) {
+    for (size_t i = 1; i <= dir.size(); ++i)
+        if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0755);
+}
+static std::string cache_dir() {
+    std::string dir;
+    if (const char* e = std::getenv("KYHIP_CACHE_DIR")) dir = e;
+    else if (const char* home = std::getenv("HOME")) dir = std::string(home) + "/.cache/kyhip";
+    else dir = "/tmp/kyhip-cache-" + std::to_string((long)getuid());
+    mkdir_p(dir);
+    return dir;
+}
+static bool write_text(const std::string& path, const char* text) {
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const size_t n = std::strlen(text);
+    const bool ok = std::fwrite(text, 1, n, f) == n;
+    std::fclose(f);
+    return ok;
+}
+static bool read_file(const std::string& path, std::vector<char>& out) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char buf[65536];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) out.insert(out.end(), buf, buf + n);
+    std::fclose(f);
+    // a gfx950 code object, bare or as the offload bundle `hipcc --genco` writes (hipModuleLoadData takes both)
+    return out.size() > 64 && (std::memcmp(out.data(), "\x7f" "ELF", 4) == 0 || std::memcmp(out.data(), "__CLANG_OFFLOAD_BUNDLE__", 24) == 0);
+}
+static std::string compiler() {
+    if (const char* e = std::getenv("KYHIP_HIPCC")) return e;
+    for (const char* p : {"/opt/rocm/bin/hipcc", "/usr/bin/hipcc"})
+        if (access(p, X_OK) == 0) return p;
+    return "hipcc";
+}
+
+// the code object of render_kernel_body<args> ("false, 48, false, false, 135, 11, false"), from memory, disk or the compiler; nullptr when it
+// cannot be had (g_status says why)
+static const Code* get_code(const std::string& args) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    auto it = g_code.find(args);
+    if (it != g_code.end()) return it->second.failed ? nullptr : &it->second;
+    Code& c = g_code[args];
+    const std::string dir = cache_dir();
+    char name[64];
+    snprintf(name, sizeof name, "%016llx", (unsigned long long)hash_bytes(source_hash(), args.data(), args.size()));
+    const std::string object = dir + "/" + name + ".hsaco";
+    if (read_file(object, c.object)) { g_status = "on (code objects from " + dir + ")"; return &c; }
+    c.object.clear();
+    c.failed = true;
+    // the sources, laid out like the repository (ky_device.hpp includes "../../include/kyhip.h"), once per library build
+    snprintf(name, sizeof name, "src-%016llx", (unsigned long long)source_hash());
+    const std::string root = dir + "/" + name;
+    mkdir_p(root + "/ky_amd/csrc");
+    mkdir_p(root + "/include");
+    bool ok = true;
+    for (const auto& src : g_rtc_sources) {
+        const std::string n = src.name;
+        ok = ok && write_text(n.compare(0, 6, "../../") == 0 ? root + "/" + n.substr(6) : root + "/ky_amd/csrc/" + n, src.text);
+    }
+    const std::string tag = std::to_string((long)getpid()) + "-" + std::to_string((unsigned long long)hash_bytes(0, args.data(), args.size()));
+    const std::string tu = root + "/ky_amd/csrc/jit-" + tag + ".hip", tmp = object + ".tmp" + tag, log = object + ".log";
+    const std::string text = "#include \"ky_render.hpp\"\nextern \"C\" __global__ __launch_bounds__(256, (ky_waves_per_eu<" + args + ">())) void " + k_entry +
+                             "(const kyd::DScene* __restrict__ S, kyd::RenderConst rc, ShardConst sh, unsigned* __restrict__ counter, unsigned long long* __restrict__ accum, "
+                             "unsigned* __restrict__ flags, float4* __restrict__ queue_mem) {\n    render_kernel_body<" + args + ">(S, rc, sh, counter, accum, flags, queue_mem);\n}\n";
+    ok = ok && write_text(tu, text.c_str());
+    if (!ok) { g_status = "cannot write the sources under " + dir; return nullptr; }
+    const std::string cmd = "'" + compiler() + "' " + k_flags + " -o '" + tmp + "' '" + tu + "' > '" + log + "' 2>&1";
+    const int rc = std::system(cmd.c_str());
+    (void)std::remove(tu.c_str());
+    if (rc != 0 || !read_file(tmp, c.object)) {
+        std::string tail;
+        FILE* f = std::fopen(log.c_str(), "rb");
+        if (f) { char buf[700]; const size_t n = std::fread(buf, 1, sizeof buf - 1, f); buf[n] = 0; tail = buf; std::fclose(f); }
+        g_status = "compiling render_kernel_body<" + args + "> failed (" + compiler() + ", exit " + std::to_string(rc) + "): " + tail;
+        (void)std::remove(tmp.c_str());
+        c.object.clear();
+        return nullptr;
+    }
+    (void)std::rename(tmp.c_str(), object.c_str());
+    (void)std::remove(log.c_str());
+    c.failed = false;
+    g_status = "on (" + compiler() + "; code objects cached in " + dir + ")";
+    return &c;
+}
+}  // namespace kyjit
+
 extern "C" {
 
 #ifdef KY_PROFILE_LANES
@@ -1401,6 +1251,31 @@ int kyhip_set_specialisation(int on) {
     const int prev = specialisation_enabled() ? 1 : 0;
     if (on == 0 || on == 1) g_specialise = on;
     return prev;
+}
+int kyhip_set_jit(int mode) {
+    const int prev = kyjit::mode();
+    if (mode == 0 || mode == 1) {
+        kyjit::g_mode = mode;
+        std::lock_guard<std::mutex> lock(kyjit::g_mutex);
+        if (mode == 0) kyjit::g_status = "off";
+        else if (kyjit::g_status == "off") kyjit::g_status = "on (nothing compiled yet)";
+    }
+    return prev;
+}
+const char* kyhip_jit_status(void) {
+    static thread_local std::string s;
+    std::lock_guard<std::mutex> lock(kyjit::g_mutex);
+    s = kyjit::g_status;
+    return s.c_str();
+}
+int64_t kyhip_jit_compile(const char* name_expression) {
+    const size_t len = name_expression ? std::strlen(name_expression) : 0;
+    if (len < 16 || std::strncmp(name_expression, "render_kernel<", 14) != 0 || name_expression[len - 1] != '>') return fail(KY_ERR_INVALID_VALUE, "not a render_kernel instantiation");
+    for (size_t i = 14; i + 1 < len; ++i)   // template arguments only: digits, true / false, commas, blanks, a minus sign
+        if (!std::strchr("0123456789truefals, -", name_expression[i])) return fail(KY_ERR_INVALID_VALUE, "not a render_kernel instantiation");
+    const kyjit::Code* code = kyjit::get_code(std::string(name_expression + 14, len - 15));
+    if (!code) return fail(KY_ERR_DEVICE, "%s", kyhip_jit_status());
+    return (int64_t)code->object.size();
 }
 int kyhip_abi_version(void) { return KYHIP_ABI_VERSION; }
 int kyhip_device_count(void) {
@@ -1571,20 +1446,57 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
         const Variant* v = pick_variant(p, sc->h, scene->light_count, sh.n_pix);
         if (!v) return fail(KY_ERR_DEVICE, "internal: no render kernel for these parameters");
         const int vi = (int)(v - g_variants);
-        if (c->variant_blocks[vi] == 0 || c->variant_lds[vi] != lds_bytes) {   // resident workgroups per CU: depends on the scene's LDS block
+        // run-time instantiation (kyhip_set_jit(1)): this launch's own kernel -- its sampler, strategy and integrator as compile-time constants and ALL
+        // of the scene's facts -- unless the table's pick is exactly that already
+        DeviceCtx::JitKernel* jk = nullptr;
+        bool queue = v->queue;
+        if (kyjit::mode() == 1 && p->integrator >= KY_INTEGRATOR_DIRECT_LIGHTING) {
+            const bool dbg = p->sampler == KY_SAMPLER_DEBUG, general = sc->h->general != 0;
+            const int feat = (dbg || general) ? 0 : sc->h->feat;
+            const bool want_queue = (p->direct_sample == KY_DIRECT_BOTH_MIS || p->direct_sample == KY_DIRECT_LIGHT_MIS || p->direct_sample == KY_DIRECT_LIGHT) &&
+                                    p->integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION && sh.n_pix < (1 << 26) && shadow_queue_wanted(scene->light_count);
+            const bool same = v->dbg == dbg && v->strategy == p->direct_sample && v->queue == want_queue && v->general == general && v->feat == feat &&
+                              v->integrator == p->integrator && v->large == large_scene;
+            if (!same) {
+                char expr[192];
+                snprintf(expr, sizeof expr, "%s, %d, %s, %s, %d, %d, %s", dbg ? "true" : "false", p->direct_sample, want_queue ? "true" : "false",
+                         general ? "true" : "false", feat, p->integrator, large_scene ? "true" : "false");
+                DeviceCtx::JitKernel& k = c->jit[expr];
+                if (!k.fn && !k.failed) {
+                    const kyjit::Code* code = kyjit::get_code(expr);   // blocks for the compile the first time (a few seconds), then memory / disk
+                    if (!(code && hipModuleLoadData(&k.module, code->object.data()) == hipSuccess && hipModuleGetFunction(&k.fn, k.module, kyjit::k_entry) == hipSuccess)) {
+                        (void)hipGetLastError();
+                        k.fn = nullptr;
+                        k.failed = true;   // the table's kernel serves this launch and every later one of its kind
+                    }
+                }
+                if (k.fn) {
+                    if (k.lds != lds_bytes) {
+                        int per_cu = 0;
+                        HIP_TRY(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k.fn, 256, lds_bytes));
+                        k.per_cu = per_cu > 0 ? per_cu : 1;
+                        k.lds = lds_bytes;
+                    }
+                    jk = &k;
+                    queue = want_queue;
+                    c->last_jit = std::string("render_kernel<") + expr + ">";
+                }
+            }
+        }
+        if (!jk && (c->variant_blocks[vi] == 0 || c->variant_lds[vi] != lds_bytes)) {   // resident workgroups per CU: depends on the scene's LDS block
             int per_cu = 0;
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v->fn, 256, lds_bytes));
             c->variant_blocks[vi] = per_cu > 0 ? per_cu : 1;
             c->variant_lds[vi] = lds_bytes;
         }
-        const int per_cu = c->variant_blocks[vi];
+        const int per_cu = jk ? jk->per_cu : c->variant_blocks[vi];
         unsigned grid = (unsigned)(c->cus * per_cu);
         const int cap = blocks_per_cu_cap();
         if (cap > 0 && cap < per_cu) grid = (unsigned)(c->cus * cap);
         const unsigned need_blocks = sh.n_items / 4 + 1;
         if (grid > need_blocks) grid = need_blocks;
         if (grid < 1) grid = 1;
-        if (v->queue && st->sq_blocks < (size_t)c->cus * per_cu) {   // the wavefronts' shadow-ray stacks of this stream's launches: one per resident
+        if (queue && st->sq_blocks < (size_t)c->cus * per_cu) {   // the wavefronts' shadow-ray stacks of this stream's launches: one per resident
             // wavefront of the LARGEST grid any QUEUE variant has been launched with on this stream (kernel: queue_mem + (block * 4 + wave) * cap)
             if (st->d_shadow_queue) {
                 HIP_TRY(hipStreamSynchronize(stream));   // the previous launches on this stream still push to the old block
@@ -1596,8 +1508,19 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
             st->sq_blocks = blocks;
         }
         HIP_TRY(hipEventRecord(st->ev0, stream));
-        hipLaunchKernelGGL(v->fn, dim3(grid), dim3(256), lds_bytes, stream, (const DScene*)sc->d, rc, sh, st->d_counter, accum, flags, v->queue ? st->d_shadow_queue : (float4*)nullptr);
-        c->last_variant = vi;
+        float4* queue_mem = queue ? st->d_shadow_queue : (float4*)nullptr;
+        if (jk) {
+            const DScene* a_scene = sc->d;
+            RenderConst a_rc = rc;
+            ShardConst a_sh = sh;
+            unsigned* a_counter = st->d_counter;
+            void* args[] = {&a_scene, &a_rc, &a_sh, &a_counter, &accum, &flags, &queue_mem};
+            HIP_TRY(hipModuleLaunchKernel(jk->fn, grid, 1, 1, 256, 1, 1, (unsigned)lds_bytes, stream, args, nullptr));
+            c->last_variant = -3;
+        } else {
+            hipLaunchKernelGGL(v->fn, dim3(grid), dim3(256), lds_bytes, stream, (const DScene*)sc->d, rc, sh, st->d_counter, accum, flags, queue_mem);
+            c->last_variant = vi;
+        }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(st->ev1, stream));
@@ -1629,6 +1552,7 @@ const char* kyhip_last_kernel(int device) {
     if (!c) return name.c_str();
     std::lock_guard<std::mutex> lock(c->m);
     if (c->last_variant == -2) name = "render_kernel_q (queue engine)";
+    else if (c->last_variant == -3) name = c->last_jit + " (run-time instantiation: sampler, strategy, deferred shadow rays, general shapes, feat, integrator, scene-sized LDS block)";
     else if (c->last_variant >= 0) {
         const Variant& v = g_variants[c->last_variant];
         char buf[160];

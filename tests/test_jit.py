@@ -1,0 +1,94 @@
+"""Run-time instantiations (kyhip_set_jit, include/kyhip.h): the library compiles the render kernel for a launch's exact template arguments from its
+embedded source.  CPU part: the compile itself (a child process of the ROCm compiler, no GPU needed), the disk cache, the failure paths.  GPU part:
+the instantiated kernels render what the table's kernels render."""
+import ctypes as C
+import os
+import shutil
+import time
+
+import numpy as np
+import pytest
+
+HIPCC = os.environ.get("KYHIP_HIPCC") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc"))
+
+
+@pytest.mark.skipif(not HIPCC, reason="no ROCm compiler on this machine")
+def test_instantiations_compile_and_are_cached(A, tmp_path, monkeypatch):
+    monkeypatch.setenv("KYHIP_CACHE_DIR", str(tmp_path / "cache"))
+    lib = A.load_kyhip()
+    # one rectangle area light with every fact of the Cornell box (1 + 2 + 4 + 128); deferred shadow rays with sphere lights; the debug sampler on general shapes
+    sizes = {}
+    for expr in (b"render_kernel<false, 48, false, false, 135, 11, false>", b"render_kernel<false, 32, true, false, 228, 11, false>", b"render_kernel<true, 16, false, true, 0, 10, true>"):
+        t0 = time.time()
+        n = lib.kyhip_jit_compile(expr)
+        assert n > 4096, (expr, n, lib.kyhip_last_error())
+        sizes[expr] = (n, time.time() - t0)
+    assert b"on (" in lib.kyhip_jit_status()
+    objects = [f for f in os.listdir(tmp_path / "cache") if f.endswith(".hsaco")]
+    assert len(objects) == 3
+    # a second request is served from memory; a fresh process would find the file (same name: hash of sources, flags and arguments)
+    t0 = time.time()
+    assert lib.kyhip_jit_compile(b"render_kernel<false, 48, false, false, 135, 11, false>") == sizes[b"render_kernel<false, 48, false, false, 135, 11, false>"][0]
+    assert time.time() - t0 < 0.05
+    head = open(tmp_path / "cache" / objects[0], "rb").read(24)
+    assert head[:4] == b"\x7fELF" or head == b"__CLANG_OFFLOAD_BUNDLE__"
+    # what is not a list of template arguments never reaches a command line; what does not compile is reported, not fatal
+    assert lib.kyhip_jit_compile(b"render_kernel<0>; touch x>") == A.KY_ERR_INVALID_VALUE
+    assert lib.kyhip_jit_compile(b"smallpt_kernel<1>") == A.KY_ERR_INVALID_VALUE
+    assert lib.kyhip_jit_compile(b"render_kernel<false, 48, false, false, 7, 11, 3>") == A.KY_ERR_DEVICE
+    assert b"failed" in lib.kyhip_jit_status()
+    prev = lib.kyhip_set_jit(1)
+    assert lib.kyhip_set_jit(prev) == 1
+
+
+def test_a_missing_compiler_is_a_status_not_a_crash(A, tmp_path, monkeypatch):
+    monkeypatch.setenv("KYHIP_CACHE_DIR", str(tmp_path / "cache2"))
+    monkeypatch.setenv("KYHIP_HIPCC", str(tmp_path / "no-such-compiler"))
+    lib = A.load_kyhip()
+    assert lib.kyhip_jit_compile(b"render_kernel<false, 8, false, false, 0, 11, false>") == A.KY_ERR_DEVICE
+    assert b"no-such-compiler" in lib.kyhip_jit_status()
+
+
+@pytest.mark.gpu
+def test_instantiated_kernels_render_what_the_table_renders(A, api, O, tmp_path, monkeypatch):
+    from test_random_scenes_gpu import random_room
+    from test_parity_gpu import general_shapes_scene
+    monkeypatch.setenv("KYHIP_CACHE_DIR", str(tmp_path / "cache"))
+    lib = A.load_kyhip()
+    W, H = 64, 48
+    room = None
+    for seed in range(64):
+        cand, kinds = random_room(A, api, O, seed, False, W, H)
+        if len(kinds) >= 2:
+            room = cand
+            break
+    cases = [(api.cornell_box_scene(A.CB_DEFAULT_SCENE, W, H), api.make_params(W, H, 64), b"135"),                                  # the table has feat 7 for it
+             (api.mis_scene(W, H), api.make_params(W, H, 32, direct_sample=A.DIRECT_LIGHT_MIS), None),                             # in the table: nothing to compile
+             (room, api.make_params(W, H, 64), b"true, false"),                                                                     # two lights: deferred rays + this room's facts
+             (general_shapes_scene(A, api), api.make_params(48, 40, 64, direct_sample=A.DIRECT_LIGHT_MIS), b"32, "),               # the table: strategy at run time
+             (api.cornell_box_scene(A.CB_DEFAULT_SCENE, W, H), api.make_params(W, H, 16, sampler=A.SAMPLER_DEBUG, integrator=A.INTEGRATOR_PATH_TRACING_RECURSION), b"true, 48")]
+    prev = lib.kyhip_set_jit(0)
+    try:
+        for scene, p, mark in cases:
+            lib.kyhip_set_jit(0)
+            table = api.render(scene, p)
+            table_kernel = lib.kyhip_last_kernel(0)
+            lib.kyhip_set_jit(1)
+            own = api.render(scene, p)
+            own_kernel = lib.kyhip_last_kernel(0)
+            if mark is None:
+                assert own_kernel == table_kernel and np.array_equal(own, table)
+                continue
+            assert b"run-time instantiation" in own_kernel and mark in own_kernel, (own_kernel, lib.kyhip_jit_status())
+            # the same arithmetic in other surroundings: the compiler contracts a few multiply-adds differently (as between the table's own kernels)
+            assert np.abs(own - table).max() < 2e-5 and table.max() > 0.1, (own_kernel, float(np.abs(own - table).max()))
+            # deterministic, and sharding stays bit-identical under it
+            parts = np.zeros_like(own)
+            for r in range(3):
+                q = A.RenderParams.from_buffer_copy(p)
+                q.tile_first, q.tile_step = r, 3
+                api.render(scene, q, film=parts)
+            assert np.array_equal(parts, own)
+        assert b"on (" in lib.kyhip_jit_status()
+    finally:
+        lib.kyhip_set_jit(prev)

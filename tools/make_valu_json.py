@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
 SAMPLES = {"cornell": 1024 * 768 * 1024, "veach": 1280 * 720 * 1024, "light_mis": 1024 * 768 * 1024, "generic": 1024 * 768 * 1024, "recursion": 1024 * 768 * 1024}
 LABEL = {"cornell": "render_kernel<strategy 48, feat 7 (one rectangle area light), integrator 11> on BASELINE configs[1] (Cornell 1024x768x1024)",
-         "veach": "render_kernel<strategy 48, deferred shadow rays> on configs[2]'s scene at 1024 spp (Veach 1280x720)",
+         "veach": "render_kernel<strategy 48, deferred shadow rays, feat 228 (sphere lights, no delta lobes, small tables)> on configs[2]'s scene at 1024 spp (Veach 1280x720)",
          "light_mis": "render_kernel<strategy 32> (the light_mis instantiation) on configs[1]'s scene",
          "recursion": "render_kernel<strategy 48, feat 7, integrator 9> (path_tracing_recursion_t) on configs[1]'s scene",
          "generic": "render_kernel<false,-1> (strategy read at run time; KYHIP_SPECIALISE=0) on configs[1]'s scene with direct_sample light_mis"}
@@ -82,6 +82,11 @@ def main():
     curve = salu_curve(os.path.join(PROF, prefix + "_salu_mix_ubench.txt"))
     plain, trans = ub["v_fmac_f32_e32 (VOP2, 3 vgpr)"], ub["v_rcp_f32"]
     valu, traffic = {}, None
+    # the library the counters were measured on (tools/final_profiles.sh writes its sha256): bench.py withholds these figures when it runs another build
+    try:
+        lib_sha = open(os.path.join(PROF, prefix + "_lib_sha256.txt")).read().split()[0]
+    except Exception:
+        lib_sha = None
     for wl in ("cornell", "veach", "light_mis", "generic", "recursion"):
         if not os.path.exists(os.path.join(PROF, "%s_%s_pmc_sq_issue.txt" % (prefix, wl))):
             continue
@@ -95,14 +100,18 @@ def main():
         insts = issue["SQ_INSTS_VALU"]
         f_trans = mix["SQ_INSTS_VALU_TRANS_F32"] / insts
         ns = ms * 1e6 * 1024 / insts
+        # the engine clock the launch really ran at: SQ_BUSY_CYCLES is summed over the shader engines' SQs (32 on this chip: the kernel keeps every one busy
+        # from start to end), so busy cycles per SQ over the kernel's duration is the clock
+        clock_ghz = issue["SQ_BUSY_CYCLES"] / 32 / (ms * 1e6) if "SQ_BUSY_CYCLES" in issue else None
         ceiling = (1 - f_trans) * plain + f_trans * trans
         fetch_b, write_b = fetch["FETCH_SIZE"] * 1024 * 2, write["WRITE_SIZE"] * 1024   # KiB; FETCH_SIZE x 2 per the guide's gfx950 note
         valu[wl] = {
-            "kernel": LABEL[wl], "samples_per_launch": n, "kernel_ms": ms,
+            "kernel": LABEL[wl], "samples_per_launch": n, "kernel_ms": ms, "lib_sha256": lib_sha,
             "wave_instr_per_sample": insts / n,
             "lane_occupancy": mix["SQ_THREAD_CYCLES_VALU"] / (64 * issue["SQ_ACTIVE_INST_VALU"]),
             "ns_per_valu_per_simd": ns,
             "issue_frac_2clk": (2 / 2.4) / ns,
+            "clock_ghz_from_sq_busy_cycles": clock_ghz, "issue_frac_2clk_at_measured_clock": ((2 / clock_ghz) / ns) if clock_ghz else None,
             "ubench_ceiling_ns": ceiling, "issue_frac_ubench": ceiling / ns,
             "quarter_rate_fraction": f_trans, "salu_per_valu": issue["SQ_INSTS_SALU"] / insts,
             # what a v_fmac stream with this much scalar company reaches, plus what the kernel's quarter-rate instructions add to a plain stream

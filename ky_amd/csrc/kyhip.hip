@@ -848,10 +848,10 @@ struct SceneSlot {
 constexpr int KY_STREAM_STATES = 8, KY_SCENE_SLOTS = 8;
 // what kyhip_render / kyhip_render_multi keep between calls (the host-film seam); `m` serialises such calls per device, it is never
 // taken while a context's enqueue mutex is held
-// (measured on configs[1]'s 9.4 MB film, tools/seam_trace.py: what a call costs beyond its kernel is 0.62 ms with one band and one thread,
-// 0.44 ms with eight bands on four threads, 0.57 ms with sixteen on eight -- every band is a copy command and an event; the film's pinned
-// download alone takes 0.18 ms)
-constexpr int KY_SEAM_BANDS = 8, KY_SEAM_THREADS = 4;
+// (measured on configs[1]'s 9.4 MB film, tools/seam_trace.py: what a call costs beyond its kernel -- the film's pinned download alone is 0.18 ms -- is
+// 0.62 ms with one download and one adding thread; 0.44 with eight bands dealt to four threads; with every thread adding its slice of every band
+// 0.39-0.42 (one band), 0.34-0.36 (two), 0.33-0.36 (four), 0.40 (eight): each band is a copy command and an event)
+constexpr int KY_SEAM_BANDS = 2, KY_SEAM_THREADS = 4;
 struct SeamBuffers {
     std::mutex m;
     void* d_gather = nullptr; size_t gather_bytes = 0;   // root: [n_devices][shard 0's tile buffer]
@@ -1779,18 +1779,20 @@ int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene,
         bands_enqueued = b + 1;
     }
 #undef HIP_CHECK_BREAK
-    // 4. host threads add band b as soon as it has arrived: film_t::add_color, 1586-1590.  Bands are dealt round-robin, so with T threads
-    // the first T bands are waited for concurrently and every later band is already there when its thread gets to it.
+    // 4. host threads add the bands as they arrive: film_t::add_color, 1586-1590.  Every thread works on its slice of the rows of EVERY band (a band is
+    // waited for once, by the thread that gets to it first under the band's flag), so the threads are all busy from the first band on.
     hipError_t sync_err = hipSuccess;
     if (rcode == KY_OK && bands_enqueued == n_bands) {
         const int hw = (int)std::thread::hardware_concurrency();
-        const int n_threads = std::max(1, std::min({n_bands, hw > 0 ? hw : 1, (int)KY_SEAM_THREADS}));
+        const int n_threads = std::max(1, std::min({p->height, hw > 0 ? hw : 1, (int)KY_SEAM_THREADS}));
         std::vector<hipError_t> errs(n_threads, hipSuccess);
         auto work = [&](int t) {
-            for (int b = t; b < n_bands; b += n_threads) {
-                const hipError_t e = hipEventSynchronize(sb.band[b]);
+            for (int b = 0; b < n_bands; ++b) {
+                const hipError_t e = hipEventSynchronize(sb.band[b]);   // (returns at once for a band that has arrived)
                 if (e != hipSuccess) { errs[t] = e; return; }
-                host_add_rows(film_rgb, stride_px, sb.h_stage, p->width, band_row(b), band_row(b + 1));
+                const int y0 = band_row(b), y1 = band_row(b + 1);
+                const int r0 = y0 + (int)((long long)(y1 - y0) * t / n_threads), r1 = y0 + (int)((long long)(y1 - y0) * (t + 1) / n_threads);
+                host_add_rows(film_rgb, stride_px, sb.h_stage, p->width, r0, r1);
             }
         };
         host_pool().run(n_threads, work);

@@ -445,14 +445,14 @@ def main():
             model_ops += u * fr.samples / world
             model_frames.append({"frame": fr.label, "useful_lane_instr_per_sample": u, "terms": terms, "counters": wc.get(fr.label)})
         model_achieved = model_ops / (kernel_total_ms * 1e-3) / 1e12 if model_ops is not None else None
-        # profiles/valu.json is only as good as the code it profiled: it carries the sha256 of the library of its rocprofv3 session
-        lib_sha = file_sha256(getattr(lib, "_name", ""))
+        # profiles/valu.json is only as good as the code it profiled: it carries kyhip_kernel_source_hash() of the library of its rocprofv3 session
+        lib_sha = "%016x" % lib.kyhip_kernel_source_hash()
         if valu:
-            valu["lib_sha256_profiled"] = valu.get("lib_sha256")
-            valu["lib_sha256_loaded"] = lib_sha
-            if valu.get("lib_sha256") != lib_sha:
+            valu["kernel_source_hash_profiled"] = valu.get("kernel_source_hash")
+            valu["kernel_source_hash_loaded"] = lib_sha
+            if valu.get("kernel_source_hash") != lib_sha:
                 valu["stale"] = True
-                valu["stale_reason"] = "the loaded libkyhip.so is not the build profiles/valu.json was measured on: utilisation figures withheld"
+                valu["stale_reason"] = "the loaded library's kernels are not compiled from the sources profiles/valu.json was measured on (kyhip_kernel_source_hash): utilisation figures withheld"
                 for k in ("lane_slot_frac", "issue_frac_2clk", "issue_frac_ubench", "issue_frac_mix_model", "lane_occupancy", "wave_instr_per_sample", "ns_per_valu_per_simd"):
                     valu[k] = None
                 traffic = None

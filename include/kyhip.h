@@ -208,6 +208,10 @@ const char* kyhip_jit_status(void);
 /* Host only (no GPU needed): compiles -- or fetches from the cache -- the instantiation named by a C++ expression such as
    "render_kernel<false, 48, false, false, 135, 11, false>" and returns the size of its gfx950 code object, or a negative ky_status. */
 int64_t     kyhip_jit_compile(const char* name_expression);
+/* 64 bits over the text of the device headers the render kernels are compiled from (ky_device.hpp, ky_render.hpp, this file) and their compile flags:
+   what identifies the KERNELS of a build (host-side changes do not move it).  profiles/valu.json carries the hash of the build its counters were
+   measured on, and bench.py withholds those counters when it runs another. */
+uint64_t    kyhip_kernel_source_hash(void);
 int         kyhip_abi_version(void);
 int         kyhip_device_count(void);
 

@@ -1277,6 +1277,7 @@ int64_t kyhip_jit_compile(const char* name_expression) {
     if (!code) return fail(KY_ERR_DEVICE, "%s", kyhip_jit_status());
     return (int64_t)code->object.size();
 }
+uint64_t kyhip_kernel_source_hash(void) { return kyjit::source_hash(); }
 int kyhip_abi_version(void) { return KYHIP_ABI_VERSION; }
 int kyhip_device_count(void) {
     int n = 0;
@@ -1605,6 +1606,26 @@ int kyhip_film_add_gathered_device(int device, const ky_render_params* p, int wo
 // event, and a few host threads add band b into the caller's film (film_t::add_color, 1586-1590) the moment its event has fired, so the
 // host's pass over the film overlaps the rest of the download.  (Round 3 allocated and freed two device buffers per call, downloaded into
 // pageable memory and added with one scalar loop afterwards: 1-2 ms on a 9.4 MB film, a third of a 64-spp frame.)
+// CPUs this process may really use: the affinity mask, cut down to the cgroup's quota where there is one (a container granted 2 CPUs of a 256-thread host
+// reports 256 from std::thread::hardware_concurrency(); four adding threads on two CPUs were slower than two)
+static int cpus_granted() {
+    static const int n = [] {
+        int cpus = (int)std::thread::hardware_concurrency();
+        if (cpus < 1) cpus = 1;
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char quota[32] = {0};
+            long period = 0;
+            if (std::fscanf(f, "%31s %ld", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0) {
+                const long q = (std::atol(quota) + period / 2) / period;
+                if (q >= 1 && q < cpus) cpus = (int)q;
+            }
+            std::fclose(f);
+        }
+        return cpus;
+    }();
+    return n;
+}
+
 static void host_add_rows(float* __restrict__ film, size_t stride_px, const float* __restrict__ src, int width, int y0, int y1) {
     const size_t n = (size_t)width * 3;
     for (int y = y0; y < y1; ++y) {
@@ -1783,8 +1804,7 @@ int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene,
     // waited for once, by the thread that gets to it first under the band's flag), so the threads are all busy from the first band on.
     hipError_t sync_err = hipSuccess;
     if (rcode == KY_OK && bands_enqueued == n_bands) {
-        const int hw = (int)std::thread::hardware_concurrency();
-        const int n_threads = std::max(1, std::min({p->height, hw > 0 ? hw : 1, (int)KY_SEAM_THREADS}));
+        const int n_threads = std::max(1, std::min({p->height, cpus_granted(), (int)KY_SEAM_THREADS}));
         std::vector<hipError_t> errs(n_threads, hipSuccess);
         auto work = [&](int t) {
             for (int b = 0; b < n_bands; ++b) {

@@ -7,7 +7,7 @@
 P=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
-sha256sum ky_amd/lib/libkyhip.so | cut -d' ' -f1 > gpurun_out/final/${P}_lib_sha256.txt
+python3 -c "from ky_amd import _abi as A; print('%016x' % A.load_kyhip().kyhip_kernel_source_hash())" > gpurun_out/final/${P}_kernel_source_hash.txt
 run() {  # tag, bench args...
   T=$1; shift
   rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${P}_$T -o s -- python3 bench.py --no-cpu-baseline --no-extra "$@" > gpurun_out/final/${P}_${T}_stats.log 2>&1

@@ -82,9 +82,10 @@ def main():
     curve = salu_curve(os.path.join(PROF, prefix + "_salu_mix_ubench.txt"))
     plain, trans = ub["v_fmac_f32_e32 (VOP2, 3 vgpr)"], ub["v_rcp_f32"]
     valu, traffic = {}, None
-    # the library the counters were measured on (tools/final_profiles.sh writes its sha256): bench.py withholds these figures when it runs another build
+    # the kernels the counters were measured on (tools/final_profiles.sh writes kyhip_kernel_source_hash(): device headers + compile flags): bench.py
+    # withholds these figures when it runs a build whose kernels come from other sources
     try:
-        lib_sha = open(os.path.join(PROF, prefix + "_lib_sha256.txt")).read().split()[0]
+        lib_sha = open(os.path.join(PROF, prefix + "_kernel_source_hash.txt")).read().split()[0]
     except Exception:
         lib_sha = None
     for wl in ("cornell", "veach", "light_mis", "generic", "recursion"):
@@ -106,7 +107,7 @@ def main():
         ceiling = (1 - f_trans) * plain + f_trans * trans
         fetch_b, write_b = fetch["FETCH_SIZE"] * 1024 * 2, write["WRITE_SIZE"] * 1024   # KiB; FETCH_SIZE x 2 per the guide's gfx950 note
         valu[wl] = {
-            "kernel": LABEL[wl], "samples_per_launch": n, "kernel_ms": ms, "lib_sha256": lib_sha,
+            "kernel": LABEL[wl], "samples_per_launch": n, "kernel_ms": ms, "kernel_source_hash": lib_sha,
             "wave_instr_per_sample": insts / n,
             "lane_occupancy": mix["SQ_THREAD_CYCLES_VALU"] / (64 * issue["SQ_ACTIVE_INST_VALU"]),
             "ns_per_valu_per_simd": ns,

@@ -1643,7 +1643,8 @@ public:
         if (n <= 1) { if (n == 1) fn(0); return; }
         {
             std::lock_guard<std::mutex> lock(m_);
-            while ((int)threads_.size() < n - 1) { const int id = (int)threads_.size() + 1; threads_.emplace_back([this, id] { loop(id); }); }
+            if (pid_ != getpid()) { pid_ = getpid(); n_threads_ = 0; }   // a forked child inherits the object, not the (detached) threads
+            while (n_threads_ < n - 1) { const int id = ++n_threads_; std::thread([this, id] { loop(id); }).detach(); }
             fn_ = &fn; n_ = n; pending_ = n - 1; ++generation_;
         }
         cv_.notify_all();
@@ -1652,11 +1653,6 @@ public:
         done_.wait(lock, [this] { return pending_ == 0; });
         fn_ = nullptr;
     }
-    ~HostPool() {
-        { std::lock_guard<std::mutex> lock(m_); stop_ = true; }
-        cv_.notify_all();
-        for (std::thread& t : threads_) t.join();
-    }
 private:
     void loop(int id) {
         unsigned long long seen = 0;
@@ -1664,8 +1660,7 @@ private:
             const std::function<void(int)>* fn = nullptr;
             {
                 std::unique_lock<std::mutex> lock(m_);
-                cv_.wait(lock, [&] { return stop_ || (generation_ != seen && id < n_); });
-                if (stop_) return;
+                cv_.wait(lock, [&] { return generation_ != seen && id < n_; });
                 seen = generation_;
                 fn = fn_;
             }
@@ -1676,11 +1671,10 @@ private:
     }
     std::mutex job_m_, m_;
     std::condition_variable cv_, done_;
-    std::vector<std::thread> threads_;
     const std::function<void(int)>* fn_ = nullptr;
-    int n_ = 0, pending_ = 0;
+    int n_ = 0, pending_ = 0, n_threads_ = 0;
+    pid_t pid_ = 0;
     unsigned long long generation_ = 0;
-    bool stop_ = false;
 };
 static HostPool& host_pool() { static HostPool* pool = new HostPool; return *pool; }   // never destroyed: no thread joins at process exit
 

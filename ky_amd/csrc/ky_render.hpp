@@ -94,6 +94,12 @@ struct ShardConst {
 #ifndef KY_MAX_RETRACE
 #define KY_MAX_RETRACE 1
 #endif
+#ifndef KY_REFILL_BATCH
+#define KY_REFILL_BATCH 6     // lanes that make a work-item refill pass worth running at once ...
+#endif
+#ifndef KY_REFILL_WAIT
+#define KY_REFILL_WAIT 4      // ... or turns the first of them waits at most
+#endif
 #ifndef KY_RETRACE_THRESHOLD
 #define KY_RETRACE_THRESHOLD 80
 #endif
@@ -183,6 +189,7 @@ KY_DEV void render_kernel_body(const DScene* __restrict__ S_, RenderConst rc, Sh
     }
     bool open = false;        // the chunk has samples left to start (s < s_end)
     bool has_item = false, done = false, alive = false;
+    int waited = 0;           // turns the longest-waiting lane has waited for a refill (wave-uniform)
     PathState ps;
     ps.Lo = mk3(0, 0, 0);
 
@@ -194,7 +201,14 @@ KY_DEV void render_kernel_body(const DScene* __restrict__ S_, RenderConst rc, Sh
         // for each other and the wave drains within one chunk of the end of the queue.
         const bool need = !alive && !done && !open;
         const unsigned long long need_mask = __ballot(need);
-        if (need_mask) {  // wave-uniform branch: every lane runs the bookkeeping below
+        // The pass below costs every lane of the wavefront ~120 VALU instructions whoever needs it, and with 24-sample chunks some lane needs it in 62 % of the
+        // loop's turns.  So it runs when KY_REFILL_BATCH lanes wait for it, or when the first of them has waited KY_REFILL_WAIT turns, or when no lane has
+        // anything else to do (round 4: 6 / 4 is worth +1.3 % on configs[1], +0.7 % on configs[2]; 2 / 1 costs 1 %, 16 / 12 1.3 %: profiles/r04_c_ab_loop_state.txt).
+        // Which lane renders which pixel chunk changes with it; the image does not (a chunk's sum does not depend on its lane).
+        bool refill = need_mask != 0;
+        if (refill && __popcll(need_mask) < KY_REFILL_BATCH && waited < KY_REFILL_WAIT && __any(alive || (open && !done))) { refill = false; ++waited; }
+        if (refill) {  // wave-uniform branch: every lane runs the bookkeeping below
+            waited = 0;
             if (need && has_item) {
                 const float v[3] = {ps.Lo.x * rc.inv_spp, ps.Lo.y * rc.inv_spp, ps.Lo.z * rc.inv_spp};   // 3717, once per chunk
                 ps.Lo = mk3(0, 0, 0);

@@ -107,7 +107,8 @@ struct ShardConst {
 #define KY_WAVES_PER_EU 7           // the hot instantiation <false, both_mis, feat 7>: 72 VGPRs, nothing spilled (six: 80; +3.5 % for the seventh wavefront)
 #endif
 #ifndef KY_WAVES_PER_EU_QUEUE
-#define KY_WAVES_PER_EU_QUEUE 5     // the instantiation with deferred shadow rays: 96 VGPRs (6 spilled) beat 80 (28 spilled) by 3.5 % since round 3
+#define KY_WAVES_PER_EU_QUEUE 6     // the instantiations with deferred shadow rays and no scene facts: round 4 (LDS block 23.0 KB since the chunk sum left it): 80 VGPRs with 20 spilled
+                                    // beat 96 with 6 at five by 3.4 % on the Cornell box with lamp and point light (20.35 against 21.05 ms at 256 spp); seven: 20.43
 #endif
 #ifndef KY_WAVES_PER_EU_QUEUE_FEAT
 #define KY_WAVES_PER_EU_QUEUE_FEAT 7   // ... with scene facts (the sphere-lights kernel): round 4, with its LDS block at 22.9 KB (KY_FEAT_SMALL_TABLES, the pixel key recomputed): 72 VGPRs with 10 spilled beat 80 with 8 at six by 3.4 % (111.7 against 115.5 ms at 1024 spp)

@@ -177,7 +177,9 @@ struct DLight {  // light_t + the shape an area light samples; wave-uniform inde
     int32_t carrier[4];
     int32_t sampled_is_surface;   // the shape this light samples is also the shape of some surface of the scene (so it occludes)
     int32_t occ_ok;               // shadow rays towards samples of this light may use DScene::occ
-    int32_t pad_l[2];
+    int32_t pdf_from_carrier;     // the light samples a planar shape and its ONE carrier surface has that very shape: pdf_direction's re-intersection of the light's
+                                  // shape with isect.spawn_ray(wi) (1057-1061) IS the BSDF-sampling estimator's carrier hit -- same ray, same record, same arithmetic
+    int32_t pad_l;
     DSurf isect;          // traversal record of the sampled shape (pdf_direction re-intersects it, 1057-1061)
 };
 constexpr int KY_MAX_CARRIERS = 4;
@@ -1160,6 +1162,7 @@ KY_DEV void estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f
     bs.f = any3();
     bs.pdf = any_f();
     bool live = false, lit = false;   // live: the sample's value and pdf count; lit: it sees light (Li is set and not black)
+    float t_l = any_f();              // fast path: distance of the nearest carrier hit
     const bool fast = S.is_area(L.kind) && ((S.feat & KY_FEAT_CARRIERS) || (L.n_carriers >= 0 && S->n_gen == 0));  // wave-uniform
     if (fast) {
         // Only the DIRECTION is sampled up front; the BSDF value and pdf (a pow for the Phong lobe) are evaluated for the few
@@ -1171,7 +1174,7 @@ KY_DEV void estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f
             o = offset_ray_origin(v.position, v.normal, bs.wi);  // isect.spawn_ray, 665-668
         }
         // (a) nearest carrier surface along the ray, and what it emits towards the ray (3084, 2957-2960)
-        float t_l = K_INF;
+        t_l = K_INF;
         int c = -1;
         for (int k = 0; k < L.n_carriers; ++k) {
             float t;
@@ -1199,7 +1202,14 @@ KY_DEV void estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f
             if (pending) {
                 f3 Lq = (f_cos * Li) * rcp(bs.pdf);  // 3924
                 if (MIS) {
-                    const float light_pdf = light_pdf_Li(L, S->full, v.position, v.normal, bs.wi, S.general, S.feat);
+                    float light_pdf;
+                    if (L.pdf_from_carrier) {   // (wave-uniform) pdf_direction from the carrier hit itself, see below
+                        const f3 hp = o + t_l * bs.wi;
+                        light_pdf = length_sq(v.position - hp) * rcp(fabsf(dot(ld3(L.n), bs.wi)) * L.area);
+                        if (isinf(light_pdf)) light_pdf = 0.f;
+                    } else {
+                        light_pdf = light_pdf_Li(L, S->full, v.position, v.normal, bs.wi, S.general, S.feat);
+                    }
                     Lq = light_pdf > 0 ? (f_cos * Li) * (2.f * rcp(bs.pdf + light_pdf)) : mk3(0, 0, 0);  // 4028
                 }
                 c = (Lq * beta) * weight;
@@ -1269,7 +1279,14 @@ KY_DEV void estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f
     }
     if (lit) {
         if (MIS) {
-            const float light_pdf = light_pdf_Li(L, S->full, v.position, v.normal, bs.wi, S.general, S.feat);
+            float light_pdf;
+            if (fast && L.pdf_from_carrier) {   // (wave-uniform) shape_t::pdf_direction, 1055-1090, from the hit the carrier test found
+                const f3 hp = o + t_l * bs.wi;
+                light_pdf = length_sq(v.position - hp) * rcp(fabsf(dot(ld3(L.n), bs.wi)) * L.area);
+                if (isinf(light_pdf)) light_pdf = 0.f;
+            } else {
+                light_pdf = light_pdf_Li(L, S->full, v.position, v.normal, bs.wi, S.general, S.feat);
+            }
             if (light_pdf > 0) acc = acc + w * ((f_cos * Li) * (2.f * rcp(bs.pdf + light_pdf)));  // 4028
         } else {
             acc = acc + w * ((f_cos * Li) * rcp(bs.pdf));  // 3924

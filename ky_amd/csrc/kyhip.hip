@@ -757,6 +757,7 @@ static int pack_scene(const ky_scene* in, DScene* out) {
                 if (d.n_carriers >= 0 && d.n_carriers < KY_MAX_CARRIERS) d.carrier[d.n_carriers++] = j2;
                 else d.n_carriers = -1;
             }
+            d.pdf_from_carrier = (d.n_carriers == 1 && d.isect.kind == TK_PARALLELOGRAM && in->surfaces[out->orig[d.carrier[0]]].shape == l.shape) ? 1 : 0;
         }
     }
     if (out->n_gen > 0) out->general = 1;

@@ -180,3 +180,20 @@ def test_recursive_integrators_agree_with_the_iterative_one(A, api, O):
     simple = float(O.render(scene, api.make_params(32, 32, 256, integrator=8)).mean())
     nee = float(O.render(scene, api.make_params(32, 32, 256, integrator=11)).mean())
     assert nee < simple < 1.3 * nee, (simple, nee)
+
+
+def test_work_counters_fixture(A, api, O):
+    """tests/golden/work_counters.json (what bench.py's roofline.valu_model prices, generator beside it) is the oracle's, and the fixture's square
+    Cornell frame and its Veach frame are the reference's own counts to the survey's three digits."""
+    import json
+    fix = json.load(open(os.path.join(HERE, "golden", "work_counters.json")))
+    for label, ref in (("cornell_area", REF_COUNTERS["cornell"]), ("veach", REF_COUNTERS["veach"])):
+        for k, v in ref.items():
+            assert abs(fix[label][k] - v) <= 0.012 * v + 0.006, (label, k, fix[label][k], v)
+    # the 4:3 frame of configs[1] holds less work per sample than the square one (more of its view misses the box): the fixture says so, the oracle agrees
+    assert fix["cornell"]["traversals"] < 0.85 * fix["cornell_area"]["traversals"]
+    row = fix["cornell"]
+    scene = api.cornell_box_scene(A.CB_DEFAULT_SCENE, 128, 96)
+    _, cnt = O.render(scene, api.make_params(128, 96, 32), counters=True)
+    for k in ("traversals", "path_iterations", "light_estimates", "bsdf_path_samples", "primitive_tests"):
+        assert abs(cnt[k] / cnt["camera_samples"] - row[k]) <= 0.015 * row[k] + 0.006, (k, cnt[k] / cnt["camera_samples"], row[k])

@@ -1323,7 +1323,8 @@ struct Variant {
 constexpr int IT = KY_INTEGRATOR_PATH_TRACING_ITERATION;
 static const Variant g_variants[] = {
     // the iterative integrator, both_mis: by scene facts
-    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL, IT),                  // one rectangle area light: configs[1], [4]
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES, IT),   // one rectangle area light, at most 16 surfaces and 8 materials: configs[1], [4]
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL, IT),                  // one rectangle area light
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_DELTA, IT),             // one point / directional light
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_ENV, IT),               // one environment light
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, KY_FEAT_VEACH, IT),                     // several sphere lights, no mirror / glass: configs[2]

@@ -62,7 +62,7 @@ def test_instantiated_kernels_render_what_the_table_renders(A, api, O, tmp_path,
         if len(kinds) >= 2:
             room = cand
             break
-    cases = [(api.cornell_box_scene(A.CB_DEFAULT_SCENE, W, H), api.make_params(W, H, 64), b"135"),                                  # the table has feat 7 for it
+    cases = [(api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | A.CB_LIGHT_POINT, W, H), api.make_params(W, H, 64), b", 142, "),                    # the table has feat 8 for it; all of the scene's facts: 8 + 2 + 4 + 128
              (api.mis_scene(W, H), api.make_params(W, H, 32, direct_sample=A.DIRECT_LIGHT_MIS), None),                             # in the table: nothing to compile
              (room, api.make_params(W, H, 64), b"true, false"),                                                                     # two lights: deferred rays + this room's facts
              (general_shapes_scene(A, api), api.make_params(48, 40, 64, direct_sample=A.DIRECT_LIGHT_MIS), b"32, "),               # the table: strategy at run time

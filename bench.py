@@ -538,9 +538,9 @@ def extra_workloads(args, run_workload, peak_tlaneops, lib, local_rank, kernel_m
                                         "ratio_to_specialised_kernel": kernel_ms_specialised / sum(r["kernel_ms"]), "film_mean": r["film_mean"]}
     finally:
         lib.kyhip_set_specialisation(prev)
-    # Run-time instantiations (kyhip_set_jit, off by default): configs[1] on the kernel compiled for ALL of its scene's facts, and a scene the table
-    # has no row for -- the Cornell box lit by its lamp AND the point light, both_mis: deferred shadow rays without scene facts in the table, with
-    # this scene's facts when instantiated -- each against the table's kernel.  (The first launch of an instantiation compiles it: a warm-up step.)
+    # Run-time instantiations (kyhip_set_jit, off by default): the point-light Cornell box on the kernel compiled for ALL of its scene's facts (the table's
+    # row knows "one delta light"), and a scene the table has no row for -- the Cornell box lit by its lamp AND the point light, both_mis: deferred shadow
+    # rays without scene facts in the table, with this scene's facts when instantiated -- each against the table's kernel.  (The first launch of an instantiation compiles it: a warm-up step.)
     import torch
     dev = torch.device("cuda", local_rank)
 
@@ -555,7 +555,7 @@ def extra_workloads(args, run_workload, peak_tlaneops, lib, local_rank, kernel_m
 
     W, H = 1024, 768
     two = api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | A.CB_LIGHT_AREA | A.CB_LIGHT_POINT, W, H)
-    cases = {"cornell": (api.cornell_box_scene(A.CB_DEFAULT_SCENE, W, H), api.make_params(W, H, 1024)),
+    cases = {"cornell_point_light": (api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | A.CB_LIGHT_POINT, W, H), api.make_params(W, H, 256)),   # the table knows "one delta light"; the scene has more facts
              "cornell_lamp_and_point_light": (two, api.make_params(W, H, 256))}
     jit = {}
     prev = lib.kyhip_set_jit(0)

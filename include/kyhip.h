@@ -195,6 +195,12 @@ int         kyhip_set_engine(int engine);
    compiler contracts a few multiply-adds differently once code around them is gone).  Returns the previous setting.
    A tuning knob, like kyhip_set_engine. */
 int         kyhip_set_specialisation(int on);
+/* Deferred shadow rays (the render kernels' QUEUE instantiations: light samples wait on a per-wavefront stack until 64 of them fill a traversal).
+   mode -1 (default): by the scene -- when its sphere area lights outnumber its point / directional lights by five or more (create_mis_scene's five
+   lamps; measured crossing, tools/queue_policy.py); 0: never; 1: for every scene with lights.  The environment variable KYHIP_SHADOW_QUEUE = 0 / 1 sets the
+   initial mode.  The image does not depend on it beyond float summation order (contributions enter the film in fixed point either way).  Returns the
+   previous mode.  A tuning knob, like kyhip_set_engine. */
+int         kyhip_set_shadow_queue(int mode);
 /* Run-time instantiations.  The render kernel is a template over (sampler, strategy, integrator, deferred shadow rays, general shapes, scene
    facts, table size); the library ships a fixed table of instantiations and picks the nearest one per launch.  mode 1: a launch whose exact
    combination -- with ALL of its scene's facts -- is not in the table gets its own kernel, compiled from the library's embedded source by the

@@ -92,6 +92,7 @@ KYHIP_SYMBOLS = {
     "kyhip_last_error": (C.c_char_p, []),
     "kyhip_set_engine": (C.c_int, [C.c_int]),
     "kyhip_set_specialisation": (C.c_int, [C.c_int]),
+    "kyhip_set_shadow_queue": (C.c_int, [C.c_int]),
     "kyhip_set_jit": (C.c_int, [C.c_int]),
     "kyhip_jit_status": (C.c_char_p, []),
     "kyhip_jit_compile": (C.c_int64, [C.c_char_p]),

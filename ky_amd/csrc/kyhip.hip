@@ -770,18 +770,35 @@ static int pack_scene(const ky_scene* in, DScene* out) {
     return KY_OK;
 }
 
-// Deferred shadow rays (render_kernel<.., QUEUE>) are used for scenes with at least KY_SQ_MIN_LIGHTS lights; the environment
-// variable KYHIP_SHADOW_QUEUE = 0 / 1 switches them off / on for every scene (A/B measurements).
-#ifndef KY_SQ_MIN_LIGHTS
-#define KY_SQ_MIN_LIGHTS 2
+// Deferred shadow rays (render_kernel<.., QUEUE>): which scenes get them.  They pay where most light samples die BEFORE the occlusion traversal and the few
+// survivors of several lights fill one wavefront -- sphere lamps, whose samples hit the sampled sphere itself two times in three (quirk 1) -- and they cost
+// where every sample needs its traversal anyway (rectangle lamps: no gain up to eight of them) or where a light has no BSDF-sampling half to share the
+// vertex with (point / directional lights: 0.35 ms per light and 39 M samples slower than the inline shadow ray).  Measured on the round-4 kernels
+// (tools/queue_policy.py, profiles/r04_h_queue_policy.txt): rooms with N sphere lamps cross over at N = 5; every point light moves the crossing by one; the
+// shipped Veach scene (five sphere lamps) is 19 % faster deferred, the Cornell box with lamp and point light 22 % faster inline.  Rounds 2-3 deferred from two
+// lights on -- right for the kernels of their time, wrong since the inline estimators accumulate in place.
+// kyhip_set_shadow_queue(0 / 1) or the environment variable KYHIP_SHADOW_QUEUE = 0 / 1 switches them off / on for every scene (A/B measurements, tests).
+#ifndef KY_SQ_MIN_SPHERE_MARGIN
+#define KY_SQ_MIN_SPHERE_MARGIN 5   // sphere area lights minus delta lights
 #endif
-static bool shadow_queue_wanted(int light_count) {
-    static int forced = -2;
-    if (forced == -2) {
+static int g_shadow_queue = -2;   // -1 by the scene, 0 never, 1 always
+static int shadow_queue_mode() {
+    if (g_shadow_queue == -2) {
         const char* e = std::getenv("KYHIP_SHADOW_QUEUE");
-        forced = e ? (std::atoi(e) != 0 ? 1 : 0) : -1;
+        g_shadow_queue = e ? (std::atoi(e) != 0 ? 1 : 0) : -1;
     }
-    return forced >= 0 ? forced == 1 : light_count >= KY_SQ_MIN_LIGHTS;
+    return g_shadow_queue;
+}
+static bool shadow_queue_wanted(const ky_scene* scene) {
+    const int mode = shadow_queue_mode();
+    if (mode >= 0) return mode == 1 && scene->light_count > 0;
+    int spheres = 0, deltas = 0;
+    for (int i = 0; i < scene->light_count; ++i) {
+        const ky_light& l = scene->lights[i];
+        if (l.kind == KY_LIGHT_AREA && l.shape >= 0 && l.shape < scene->shape_count && scene->shapes[l.shape].kind == KY_SHAPE_SPHERE) ++spheres;
+        if (l.kind == KY_LIGHT_POINT || l.kind == KY_LIGHT_DIRECTION) ++deltas;
+    }
+    return spheres - deltas >= KY_SQ_MIN_SPHERE_MARGIN;
 }
 
 // KYHIP_BLOCKS_PER_CU=n caps the resident workgroups per CU of the render kernels (shard-drain measurements, tools/shard_scan.py); read once
@@ -1157,6 +1174,11 @@ static bool read_file(const std::string& path, std::vector<char>& out) {
     // a gfx950 code object, bare or as the offload bundle `hipcc --genco` writes (hipModuleLoadData takes both)
     return out.size() > 64 && (std::memcmp(out.data(), "\x7f" "ELF", 4) == 0 || std::memcmp(out.data(), "__CLANG_OFFLOAD_BUNDLE__", 24) == 0);
 }
+// KYHIP_JIT_FLAGS: more compiler flags for the run-time instantiations (tuning: -DKY_WAVES_PER_EU_QUEUE=5 ...); part of the cache key
+static std::string extra_flags() {
+    const char* e = std::getenv("KYHIP_JIT_FLAGS");
+    return e ? e : "";
+}
 static std::string compiler() {
     if (const char* e = std::getenv("KYHIP_HIPCC")) return e;
     for (const char* p : {"/opt/rocm/bin/hipcc", "/usr/bin/hipcc"})
@@ -1173,7 +1195,8 @@ static const Code* get_code(const std::string& args) {
     Code& c = g_code[args];
     const std::string dir = cache_dir();
     char name[64];
-    snprintf(name, sizeof name, "%016llx", (unsigned long long)hash_bytes(source_hash(), args.data(), args.size()));
+    const std::string extra = extra_flags();
+    snprintf(name, sizeof name, "%016llx", (unsigned long long)hash_bytes(hash_bytes(source_hash(), args.data(), args.size()), extra.data(), extra.size()));
     const std::string object = dir + "/" + name + ".hsaco";
     if (read_file(object, c.object)) { g_status = "on (code objects from " + dir + ")"; return &c; }
     c.object.clear();
@@ -1195,7 +1218,7 @@ static const Code* get_code(const std::string& args) {
                              "unsigned* __restrict__ flags, float4* __restrict__ queue_mem) {\n    render_kernel_body<" + args + ">(S, rc, sh, counter, accum, flags, queue_mem);\n}\n";
     ok = ok && write_text(tu, text.c_str());
     if (!ok) { g_status = "cannot write the sources under " + dir; return nullptr; }
-    const std::string cmd = "'" + compiler() + "' " + k_flags + " -o '" + tmp + "' '" + tu + "' > '" + log + "' 2>&1";
+    const std::string cmd = "'" + compiler() + "' " + k_flags + " " + extra + " -o '" + tmp + "' '" + tu + "' > '" + log + "' 2>&1";
     const int rc = std::system(cmd.c_str());
     (void)std::remove(tu.c_str());
     if (rc != 0 || !read_file(tmp, c.object)) {
@@ -1251,6 +1274,11 @@ int kyhip_set_engine(int engine) {
 int kyhip_set_specialisation(int on) {
     const int prev = specialisation_enabled() ? 1 : 0;
     if (on == 0 || on == 1) g_specialise = on;
+    return prev;
+}
+int kyhip_set_shadow_queue(int mode) {
+    const int prev = shadow_queue_mode();
+    if (mode >= -1 && mode <= 1) g_shadow_queue = mode;
     return prev;
 }
 int kyhip_set_jit(int mode) {
@@ -1372,7 +1400,7 @@ static const Variant g_variants[] = {
 constexpr int KY_N_VARIANTS = (int)(sizeof g_variants / sizeof g_variants[0]);
 static_assert(KY_N_VARIANTS <= 48, "DeviceCtx::variant_blocks");
 
-static const Variant* pick_variant(const ky_render_params* p, const DScene* packed, int light_count, int n_pix) {
+static const Variant* pick_variant(const ky_render_params* p, const DScene* packed, bool deferred_rays, int n_pix) {
     const bool dbg = p->sampler == KY_SAMPLER_DEBUG;
     const bool general = packed->general != 0;
     const bool large = packed->n_surfaces > KY_LDS_SURFACES || packed->n_materials > KY_LDS_MATERIALS;
@@ -1384,9 +1412,8 @@ static const Variant* pick_variant(const ky_render_params* p, const DScene* pack
             if (v.strategy != p->direct_sample || v.integrator != p->integrator) continue;
         }
         if ((v.feat & packed->feat) != v.feat) continue;
-        // deferred shadow rays pay when a vertex has several light samples to resolve (ky_device.hpp); KYHIP_SHADOW_QUEUE=0 / 1 forces.
-        // The ray's destination tag holds the pixel in 26 bits.
-        if (v.queue && !(n_pix < (1 << 26) && shadow_queue_wanted(light_count))) continue;
+        // deferred shadow rays for the scenes shadow_queue_wanted() names.  The ray's destination tag holds the pixel in 26 bits.
+        if (v.queue && !(n_pix < (1 << 26) && deferred_rays)) continue;
         return &v;
     }
     return nullptr;   // not reached: the last entries accept everything
@@ -1446,7 +1473,7 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
         else hipLaunchKernelGGL((render_kernel_q<true, -1>), dim3(grid), dim3(QE_THREADS), 0, stream, sc->d, rc, sh, st->d_counter, accum, flags);
         c->last_variant = -2;
     } else {
-        const Variant* v = pick_variant(p, sc->h, scene->light_count, sh.n_pix);
+        const Variant* v = pick_variant(p, sc->h, shadow_queue_wanted(scene), sh.n_pix);
         if (!v) return fail(KY_ERR_DEVICE, "internal: no render kernel for these parameters");
         const int vi = (int)(v - g_variants);
         // run-time instantiation (kyhip_set_jit(1)): this launch's own kernel -- its sampler, strategy and integrator as compile-time constants and ALL
@@ -1457,7 +1484,7 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
             const bool dbg = p->sampler == KY_SAMPLER_DEBUG, general = sc->h->general != 0;
             const int feat = (dbg || general) ? 0 : sc->h->feat;
             const bool want_queue = (p->direct_sample == KY_DIRECT_BOTH_MIS || p->direct_sample == KY_DIRECT_LIGHT_MIS || p->direct_sample == KY_DIRECT_LIGHT) &&
-                                    p->integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION && sh.n_pix < (1 << 26) && shadow_queue_wanted(scene->light_count);
+                                    p->integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION && sh.n_pix < (1 << 26) && !general && shadow_queue_wanted(scene);
             const bool same = v->dbg == dbg && v->strategy == p->direct_sample && v->queue == want_queue && v->general == general && v->feat == feat &&
                               v->integrator == p->integrator && v->large == large_scene;
             if (!same) {

@@ -32,12 +32,22 @@ def _room(A, api, colour, second_light):
 @pytest.mark.parametrize("second_light", [False, True])
 @pytest.mark.parametrize("colour", [(np.nan, np.inf, 1e30), (-np.inf, 4.0, np.nan), (np.inf, -1e30, 0.5)])
 def test_nonfinite_emitter(colour, second_light, A, api, O):
+    lib = A.load_kyhip()
+    prev = lib.kyhip_set_shadow_queue(1 if second_light else -1)   # two lights: through the deferred rays' resolve (the library would trace this room's rays inline)
+    try:
+        _nonfinite_emitter(colour, second_light, A, api, O, lib)
+    finally:
+        lib.kyhip_set_shadow_queue(prev)
+
+
+def _nonfinite_emitter(colour, second_light, A, api, O, lib):
     scene, W, H = _room(A, api, colour, second_light)
     for strategy in (A.DIRECT_BOTH_MIS, A.DIRECT_LIGHT_MIS):
         p = api.make_params(W, H, 64, direct_sample=strategy, tile_w=16, tile_h=8)
         with np.errstate(all="ignore"):
             g, c = api.render(scene, p), O.render(scene, p)
         assert np.isfinite(g).all() and g.min() >= 0 and g.max() <= 1
+        assert (b"deferred shadow rays" in lib.kyhip_last_kernel(0)) == second_light, lib.kyhip_last_kernel(0)
         nan = np.isnan(c)
         assert (nan.any() or not np.isnan(colour).any()) and (g[nan] == 0).all()   # NaN stays NaN in the reference; the writers (and the GPU film) make it 0
         fin = ~nan

@@ -129,6 +129,21 @@ def test_random_room(seed, A, api, O):
     # the multi-device entry and the kernel choice do not show in the image
     p = api.make_params(W, H, 16)
     assert np.array_equal(api.render(scene, p), api.render_multi(scene, p, [0, 0, 0]))
+    # deferred shadow rays (which the library keeps for scenes with many sphere lamps: kyhip_set_shadow_queue) forced on: the same picture up to the
+    # order in which a pixel's contributions are summed
+    lib = A.load_kyhip()
+    for strategy in (A.DIRECT_BOTH_MIS, A.DIRECT_LIGHT_MIS):
+        p = api.make_params(W, H, 64, direct_sample=strategy, tile_w=16, tile_h=8)
+        inline = api.render(scene, p)
+        inline_kernel = lib.kyhip_last_kernel(0)
+        prev = lib.kyhip_set_shadow_queue(1)
+        try:
+            deferred = api.render(scene, p)
+            deferred_kernel = lib.kyhip_last_kernel(0)
+        finally:
+            lib.kyhip_set_shadow_queue(prev)
+        assert b"deferred" not in inline_kernel and (general or len(kinds) < 2 or b"deferred shadow rays" in deferred_kernel), (inline_kernel, deferred_kernel)
+        assert np.abs(inline - deferred).max() <= 2e-6, (seed, strategy, np.abs(inline - deferred).max())   # measured: <= 2.4e-7
     print("room %d (%s%s): mismatching samples both_mis %.2f%% light_mis %.2f%% bsdf %.2f%%; film RMSE both_mis %.2e light_mis %.2e" % (
         seed, "+".join(kinds), ", general shapes" if general else "", 100 * rates[A.DIRECT_BOTH_MIS], 100 * rates[A.DIRECT_LIGHT_MIS], 100 * rates[A.DIRECT_BSDF],
         films[A.DIRECT_BOTH_MIS], films[A.DIRECT_LIGHT_MIS]))

@@ -539,8 +539,8 @@ def extra_workloads(args, run_workload, peak_tlaneops, lib, local_rank, kernel_m
     finally:
         lib.kyhip_set_specialisation(prev)
     # Run-time instantiations (kyhip_set_jit, off by default): the point-light Cornell box on the kernel compiled for ALL of its scene's facts (the table's
-    # row knows "one delta light"), and a scene the table has no row for -- the Cornell box lit by its lamp AND the point light, both_mis: deferred shadow
-    # rays without scene facts in the table, with this scene's facts when instantiated -- each against the table's kernel.  (The first launch of an instantiation compiles it: a warm-up step.)
+    # row knows "one delta light"), and a scene the table has no row for -- the Cornell box lit by its lamp AND the point light, both_mis: the fact-free
+    # kernel in the table, this scene's facts when instantiated (shadow rays inline either way: kyhip.hip, shadow_queue_wanted) -- each against the table's kernel.  (The first launch of an instantiation compiles it: a warm-up step.)
     import torch
     dev = torch.device("cuda", local_rank)
 

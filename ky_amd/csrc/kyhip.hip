@@ -1356,7 +1356,7 @@ static const Variant g_variants[] = {
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_DELTA, IT),             // one point / directional light
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_ENV, IT),               // one environment light
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, KY_FEAT_VEACH, IT),                     // several sphere lights, no mirror / glass: configs[2]
-    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, 0, IT),                                 // several lights: deferred shadow rays
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, 0, IT),                                 // many sphere lamps (shadow_queue_wanted): deferred shadow rays
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, 0, IT),
     // the iterative integrator, the other five strategies (render_direct_sample_enum 4779, render_mis_scene 4878)
     KY_VARIANT(false, KY_DIRECT_BSDF, false, false, KY_FEAT_VEACH, IT),                        // render_mis_scene's other strategies on its sphere lights
@@ -1388,6 +1388,9 @@ static const Variant g_variants[] = {
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, 0, KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION),
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, 0, KY_INTEGRATOR_PATH_TRACING_RECURSION),
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, 0, KY_INTEGRATOR_PATH_TRACING_RECURSION_DEFERED),
+    // scenes with triangles, disks or non-planar quads under the default strategy: the strategy as a compile-time constant is worth 17-23 % over the
+    // run-time-dispatched kernel below (round 4: tools/room_rates.py, the random rooms with general shapes)
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, true, 0, IT),
     // everything else: strategy and integrator at run time; the debug sampler; scenes with general shapes
     KY_VARIANT(false, -1, false, false, 0, IT),
     KY_VARIANT(true, -1, false, false, 0, IT),

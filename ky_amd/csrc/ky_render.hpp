@@ -117,7 +117,10 @@ struct ShardConst {
 #define KY_WAVES_PER_EU_HOT 8          // the iterative integrator's both_mis with a single-light fact (every Cornell configuration): 64 VGPRs with 0-4 spilled, +1 % over
 #endif                                 // seven (+1.0 ... +2.9 % per Cornell light variant); the other strategies lose up to 15 % at eight
 #ifndef KY_WAVES_PER_EU_NO_FACTS
-#define KY_WAVES_PER_EU_NO_FACTS 6     // both_mis without scene facts (any lights, inline shadow rays; every integrator): 19-39 spilled VGPRs at seven
+#define KY_WAVES_PER_EU_NO_FACTS 7     // both_mis without scene facts (any lights, inline shadow rays; every integrator).  Round 3: six (19-39 spilled VGPRs at seven); round 4, with
+#endif                                 // the path state the loop no longer carries: seven is +1 ... +2.4 % with two or more lights (the Cornell box with lamp and point light 17.41 -> 17.00 ms), -2 % with one
+#ifndef KY_WAVES_PER_EU_NO_FACTS_GENERAL
+#define KY_WAVES_PER_EU_NO_FACTS_GENERAL 6   // ... with general shapes (triangle / disk tests inline): -4 ... +2 % at seven, left at six
 #endif
 #ifndef KY_WAVES_PER_EU_GENERIC
 #define KY_WAVES_PER_EU_GENERIC 5   // strategy / integrator read at run time: more code alive at once, 96 VGPRs measured best
@@ -146,7 +149,7 @@ struct ItemSlot {  // one fetched work item, decoded once (wave-uniform) and rea
 template <bool DEBUG_SAMPLER, int STRATEGY, bool QUEUE, bool GENERAL, int FEAT, int INTEGRATOR, bool LARGE>
 constexpr int ky_waves_per_eu() {
     return STRATEGY >= 0 ? (QUEUE ? (FEAT ? KY_WAVES_PER_EU_QUEUE_FEAT : KY_WAVES_PER_EU_QUEUE)
-                                  : ((FEAT == 0 && STRATEGY == KY_DIRECT_BOTH_MIS) ? KY_WAVES_PER_EU_NO_FACTS
+                                  : ((FEAT == 0 && STRATEGY == KY_DIRECT_BOTH_MIS) ? (GENERAL ? KY_WAVES_PER_EU_NO_FACTS_GENERAL : KY_WAVES_PER_EU_NO_FACTS)
                                      : ((FEAT != 0 && STRATEGY == KY_DIRECT_BOTH_MIS && INTEGRATOR == KY_INTEGRATOR_PATH_TRACING_ITERATION) ? KY_WAVES_PER_EU_HOT : KY_WAVES_PER_EU)))
                          : KY_WAVES_PER_EU_GENERIC;
 }

@@ -120,8 +120,8 @@ struct ShardConst {
 #define KY_WAVES_PER_EU_NO_FACTS 7     // both_mis without scene facts (any lights, inline shadow rays; every integrator).  Round 3: six (19-39 spilled VGPRs at seven); round 4, with
 #endif                                 // the path state the loop no longer carries: seven is +1 ... +2.4 % with two or more lights (the Cornell box with lamp and point light 17.41 -> 17.00 ms), -2 % with one
 #ifndef KY_WAVES_PER_EU_NO_FACTS_GENERAL
-#define KY_WAVES_PER_EU_NO_FACTS_GENERAL 6   // ... with general shapes (triangle / disk tests inline): -4 ... +2 % at seven, left at six
-#endif
+#define KY_WAVES_PER_EU_NO_FACTS_GENERAL 6   // ... with general shapes (triangle / disk tests inline): -4 ... +2 % at seven, left at six; and path_tracing_recursion_t, whose
+#endif                                       // recursion keeps a frame per level: 10.8 -> 15.0 ms at seven on the Cornell box with lamp and point light (the other integrators +1.5 ... +3 %)
 #ifndef KY_WAVES_PER_EU_GENERIC
 #define KY_WAVES_PER_EU_GENERIC 5   // strategy / integrator read at run time: more code alive at once, 96 VGPRs measured best
 #endif
@@ -149,7 +149,7 @@ struct ItemSlot {  // one fetched work item, decoded once (wave-uniform) and rea
 template <bool DEBUG_SAMPLER, int STRATEGY, bool QUEUE, bool GENERAL, int FEAT, int INTEGRATOR, bool LARGE>
 constexpr int ky_waves_per_eu() {
     return STRATEGY >= 0 ? (QUEUE ? (FEAT ? KY_WAVES_PER_EU_QUEUE_FEAT : KY_WAVES_PER_EU_QUEUE)
-                                  : ((FEAT == 0 && STRATEGY == KY_DIRECT_BOTH_MIS) ? (GENERAL ? KY_WAVES_PER_EU_NO_FACTS_GENERAL : KY_WAVES_PER_EU_NO_FACTS)
+                                  : ((FEAT == 0 && STRATEGY == KY_DIRECT_BOTH_MIS) ? ((GENERAL || INTEGRATOR == KY_INTEGRATOR_PATH_TRACING_RECURSION) ? KY_WAVES_PER_EU_NO_FACTS_GENERAL : KY_WAVES_PER_EU_NO_FACTS)
                                      : ((FEAT != 0 && STRATEGY == KY_DIRECT_BOTH_MIS && INTEGRATOR == KY_INTEGRATOR_PATH_TRACING_ITERATION) ? KY_WAVES_PER_EU_HOT : KY_WAVES_PER_EU)))
                          : KY_WAVES_PER_EU_GENERIC;
 }

@@ -1483,7 +1483,7 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
         // of the scene's facts -- unless the table's pick is exactly that already
         DeviceCtx::JitKernel* jk = nullptr;
         bool queue = v->queue;
-        if (kyjit::mode() == 1 && p->integrator >= KY_INTEGRATOR_DIRECT_LIGHTING) {
+        if (kyjit::mode() == 1 && specialisation_enabled() && p->integrator >= KY_INTEGRATOR_DIRECT_LIGHTING) {   // (kyhip_set_specialisation(0) asks for the fact-free kernels: nothing to instantiate)
             const bool dbg = p->sampler == KY_SAMPLER_DEBUG, general = sc->h->general != 0;
             const int feat = (dbg || general) ? 0 : sc->h->feat;
             const bool want_queue = (p->direct_sample == KY_DIRECT_BOTH_MIS || p->direct_sample == KY_DIRECT_LIGHT_MIS || p->direct_sample == KY_DIRECT_LIGHT) &&
@@ -1512,7 +1512,10 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
                     }
                     jk = &k;
                     queue = want_queue;
-                    c->last_jit = std::string("render_kernel<") + expr + ">";
+                    char desc[224];   // the table's way of naming a kernel, then the template arguments it was compiled with
+                    snprintf(desc, sizeof desc, "render_kernel<%sstrategy %d%s%s%s, feat %d, integrator %d> = render_kernel<", dbg ? "debug sampler, " : "", p->direct_sample,
+                             want_queue ? ", deferred shadow rays" : "", general ? ", general shapes" : "", large_scene ? ", scene-sized LDS block" : "", feat, p->integrator);
+                    c->last_jit = std::string(desc) + expr + ">";
                 }
             }
         }
@@ -1585,7 +1588,7 @@ const char* kyhip_last_kernel(int device) {
     if (!c) return name.c_str();
     std::lock_guard<std::mutex> lock(c->m);
     if (c->last_variant == -2) name = "render_kernel_q (queue engine)";
-    else if (c->last_variant == -3) name = c->last_jit + " (run-time instantiation: sampler, strategy, deferred shadow rays, general shapes, feat, integrator, scene-sized LDS block)";
+    else if (c->last_variant == -3) name = c->last_jit + " (run-time instantiation; template arguments: DEBUG_SAMPLER, STRATEGY, QUEUE, GENERAL, FEAT, INTEGRATOR, LARGE)";
     else if (c->last_variant >= 0) {
         const Variant& v = g_variants[c->last_variant];
         char buf[160];

@@ -46,3 +46,11 @@ def O():
 @pytest.fixture(scope="session")
 def rng():
     return np.random.default_rng(20251001)
+
+
+@pytest.fixture(scope="session")
+def table_kernels():
+    """False when the suite runs with KYHIP_JIT=1 (every launch on a kernel compiled for it): assertions about WHICH row of the library's table a launch
+    picked are skipped then, every numeric assertion stays."""
+    import os
+    return os.environ.get("KYHIP_JIT", "0") in ("", "0")

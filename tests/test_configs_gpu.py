@@ -283,7 +283,7 @@ def test_c2_headline_frame_through_the_cpp_driver(A, api, O, tmp_path):
     assert got == FW.bmp_bytes(api.render(scene, params))
 
 
-def test_specialised_instantiations_change_nothing(A, api, O):
+def test_specialised_instantiations_change_nothing(A, api, O, table_kernels):
     """A scene lit by one rectangle area light runs a both_mis kernel compiled without the other light kinds, the environment term, the
     lights loop and the other light shapes (SceneRef::feat); the other five strategies of the iterative integrator have kernels of their
     own instead of the run-time-dispatched one.  Same arithmetic, same random streams: the image must be the same either way
@@ -309,7 +309,9 @@ def test_specialised_instantiations_change_nothing(A, api, O):
                 kernel_off = lib.kyhip_last_kernel(0).decode()
                 assert on.mean() > 0.01 or strategy == A.DIRECT_IDLE
                 assert "feat 0" in kernel_off and ("strategy -1" in kernel_off or "strategy 48" in kernel_off), kernel_off
-                if "feat 0" not in kernel_on:
+                if not table_kernels:   # KYHIP_JIT=1: every launch on a kernel compiled with all of its scene's facts -- tests/test_jit.py's bound
+                    assert np.abs(on - off).max() <= 2e-5, (kernel_on, depth, np.abs(on - off).max())
+                elif "feat 0" not in kernel_on:
                     # an instantiation by scene facts (the Cornell lamp): the same expressions, but with code removed around them the
                     # compiler contracts a few multiply-adds differently -- the last bit of some pixels (measured: 6e-8 on 10 % of them)
                     assert scene is not room and np.abs(on - off).max() <= 1.2e-7, (kernel_on, depth, np.abs(on - off).max())
@@ -335,11 +337,11 @@ def test_specialised_instantiations_change_nothing(A, api, O):
                 assert "integrator %d" % integrator in kernel_on and "strategy 48" in kernel_on, kernel_on
                 if integrator != A.INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION:    # (it samples no lights: one kernel for every scene)
                     # (the iterative integrator's lamp kernel also knows the scene's tables for small: 7 + 128)
-                    assert (fact if not (flag == A.CB_LIGHT_AREA and integrator == A.INTEGRATOR_PATH_TRACING_ITERATION) else "feat 135") in kernel_on, (kernel_on, fact)
+                    assert not table_kernels or (fact if not (flag == A.CB_LIGHT_AREA and integrator == A.INTEGRATOR_PATH_TRACING_ITERATION) else "feat 135") in kernel_on, (kernel_on, fact)
                 if integrator != A.INTEGRATOR_PATH_TRACING_ITERATION:
                     assert "strategy -1" in kernel_off, kernel_off
                 fin = np.isfinite(on) & np.isfinite(off)
-                assert fin.mean() > 0.999 and np.abs(on[fin] - off[fin]).max() <= 2.4e-7, (kernel_on, kernel_off, np.abs(on[fin] - off[fin]).max())
+                assert fin.mean() > 0.999 and np.abs(on[fin] - off[fin]).max() <= (2.4e-7 if table_kernels else 2e-5), (kernel_on, kernel_off, np.abs(on[fin] - off[fin]).max())
         lib.kyhip_set_specialisation(1)
         api.render(api.mis_scene(64, 36), api.make_params(64, 36, 8))
         assert "deferred shadow rays" in lib.kyhip_last_kernel(0).decode()
@@ -348,7 +350,7 @@ def test_specialised_instantiations_change_nothing(A, api, O):
 
 
 @pytest.mark.parametrize("seed, fact", [(16, "feat 16"), (20, "feat 8"), (34, "feat 7"), (42, "feat 8"), (78, None)])
-def test_recursion_look_up_rides_along(seed, fact, A, api, O):
+def test_recursion_look_up_rides_along(seed, fact, A, api, O, table_kernels):
     """path_tracing_recursion_t's emitter look-up at specular vertices (ky.cpp:4341-4349) in that integrator's own instantiations: the
     look-up ray is carried by the light loop's first traversal (ky_device.hpp, RideAlong) -- under an environment light by the BSDF-sampling
     estimator's nearest-hit scan, otherwise by the shadow-ray scan -- and a hit on a PLASTIC surface draws its lobe number from the path's
@@ -374,12 +376,12 @@ def test_recursion_look_up_rides_along(seed, fact, A, api, O):
     finally:
         lib.kyhip_set_specialisation(prev)
     assert "integrator 9" in kernel_on and "strategy 48" in kernel_on and "strategy -1" in kernel_off, (kernel_on, kernel_off)
-    if fact:
+    if fact and table_kernels:
         assert fact in kernel_on, kernel_on
     fin = np.isfinite(on) & np.isfinite(off)
     d = np.where(fin, np.abs(on - off), 0).max(axis=2)
     if fact:
-        assert fin.mean() > 0.999 and d.max() <= 2.4e-7, (kernel_on, d.max())
+        assert fin.mean() > 0.999 and d.max() <= (2.4e-7 if table_kernels else 2e-5), (kernel_on, d.max())
     else:
         # the sphere light (radius 0.1): uniform-cone sampling cancels (ky.cpp:798, 1510-1512), so the sampled point moves by 1e-4 of the radius with
         # the compiler's choice of fused multiply-adds -- which differs between the two instantiations' copies of the estimator -- and a sample

@@ -62,7 +62,7 @@ def test_debug_pixel_and_debug_area_replay_the_render(A, api):
     assert api.debug_area_host_api(scene, 7, 5, 48, A.SAMPLER_RANDOM, 1, W, H, (1, 1), (2, 2)) is None    # create_integrator -> nullptr (4638)
 
 
-def test_shadow_ray_stacks_grow_with_the_launch(A, api, O):
+def test_shadow_ray_stacks_grow_with_the_launch(A, api, O, table_kernels):
     """Round-3 advice (high): the per-stream block of shadow-ray stacks was sized by the FIRST deferred-rays launch on the stream.  The
     fact-free variants run five workgroups per CU, the sphere-lights one six: a full grid of the second after the first wrote past the
     block.  Both at sizes that fill the chip, in that order, on one stream; the second image must equal its two-shard sum (bit for bit
@@ -80,7 +80,7 @@ def test_shadow_ray_stacks_grow_with_the_launch(A, api, O):
     prev = lib.kyhip_set_shadow_queue(1)   # (left to itself the library traces this room's shadow rays inline: too few sphere lamps)
     try:
         room = api.render(sc, p)
-        assert b"deferred shadow rays" in lib.kyhip_last_kernel(0) and b"feat 0" in lib.kyhip_last_kernel(0), lib.kyhip_last_kernel(0)
+        assert b"deferred shadow rays" in lib.kyhip_last_kernel(0) and (b"feat 0" in lib.kyhip_last_kernel(0) or not table_kernels), lib.kyhip_last_kernel(0)
         _stacks_grow(A, api, O, lib, sc, p, room, W, H, spp)
     finally:
         lib.kyhip_set_shadow_queue(prev)

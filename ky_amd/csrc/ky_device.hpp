@@ -156,8 +156,10 @@ struct DHit {  // what is needed once the nearest surface is known; gathered per
     int32_t kind;
     int32_t material;
     int32_t area_light;
-    int32_t pad_h[2];   // 32 B: a per-lane index becomes an LDS address by a shift (24 B cost a v_mul_lo_u32 at each of three look-ups per loop turn)
+    float fs[3], ft[3];   // planar shapes: frame_t(stored normal)'s s and t (537-541), made once by the host instead of at every vertex (surface_frame below)
+    int32_t pad_h[4];     // 64 B: a per-lane index becomes an LDS address by a shift (24 B cost a v_mul_lo_u32 at each of three look-ups per loop turn)
 };
+static_assert(sizeof(DHit) == 64, "DHit");
 
 struct DMat {  // ky_material, gathered per lane from LDS
     float c0[3];        // lambert albedo | mirror R | glass R; plastic: Kd / P_diff, the Lambert lobe's albedo (2667)
@@ -773,9 +775,22 @@ KY_DEV f3 vertex_basis_c(const Vertex& v) {
     return mk3(g_vertex_lds.c[0][i], g_vertex_lds.c[1][i], g_vertex_lds.c[2][i]);
 }
 
+// frame_t(isect.normal) (2100) of a vertex on the surface `H` describes.  A planar shape reports its stored normal or, a rectangle seen from behind, the
+// opposite one (1289): frame_t(n) = (s, t, n) and frame_t(-n) = (s, -t, -n) exactly (t = normalize(n x axis) changes sign, s = t x n does not), so the host
+// builds (s, t) once per surface and a vertex reads them -- no frame build, no rsq, at the planar hits that are all of a Cornell box's non-specular
+// vertices.  Spheres (a normal per hit) and callers without a surface record (the BSDF KATs: any normal) build the frame here.
+KY_DEV Frame surface_frame(const DHit* H, f3 n) {
+    if (H != nullptr && H->kind != KY_SHAPE_SPHERE) {
+        const bool turned = (n.x != H->n[0]) | (n.y != H->n[1]) | (n.z != H->n[2]);   // n is the stored normal or its negative, bit for bit
+        const float sg = turned ? -1.f : 1.f;
+        return Frame{ld3(H->fs), ld3(H->ft) * sg, n};
+    }
+    return make_frame(n);
+}
+
 // The basis of a non-delta vertex (see the section comment).  wo = -ray.direction (3125), unit.
-KY_DEV LobeBasis make_lobe_basis(const Bsdf& B, f3 n, f3 wo) {
-    const Frame fr = make_frame(n);   // frame_t(isect.normal), 2100
+KY_DEV LobeBasis make_lobe_basis(const Bsdf& B, f3 n, f3 wo, const DHit* H = nullptr) {
+    const Frame fr = surface_frame(H, n);   // frame_t(isect.normal), 2100
     LobeBasis L{fr.s, fr.t, n};
     if (B.lobe == LOBE_PHONG) {       // 2533-2536: wr = reflect(wo, z) in the shading frame, frame_t(wr) there
         const f3 wo_l = to_local(fr, wo);
@@ -796,8 +811,8 @@ KY_DEV LobeBasis make_lobe_basis(const Bsdf& B, f3 n, f3 wo) {
     return L;
 }
 // scattering + the vertex's basis: what an (active) lane does once per vertex after v.bsdf is known
-KY_DEV void vertex_prepare(Vertex& v, f3 wo) {
-    if (!bsdf_is_delta(v.bsdf)) vertex_set_basis(v, make_lobe_basis(v.bsdf, v.normal, wo));
+KY_DEV void vertex_prepare(Vertex& v, f3 wo, const DHit* H = nullptr) {
+    if (!bsdf_is_delta(v.bsdf)) vertex_set_basis(v, make_lobe_basis(v.bsdf, v.normal, wo, H));
 }
 
 // eval_ and pdf_ of the two non-delta lobes at one (wo, wi) pair, world space (2227-2240, 2489-2508, 2545-2550); the delta
@@ -1710,7 +1725,7 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, SceneRef S, const LdsScene& Lds
         } else {
             v.bsdf = make_bsdf_for_lobe(M, lobe);
         }
-        vertex_prepare(v, -ps.d);   // ps.d still holds the direction of the ray that found this vertex
+        vertex_prepare(v, -ps.d, &Lds.hit[v.surface]);   // ps.d still holds the direction of the ray that found this vertex
     }
     const f3 wo = -ps.d;   // isect.wo, 3125
 

@@ -280,7 +280,7 @@ KY_DEV void qe_vertex(Vertex& v, const LdsScene& Lds, f3 position, f3 d, int sur
     v.surface = surface;
     v.normal = hit_normal(Lds.hit[surface], position, d);
     v.bsdf = make_bsdf_for_lobe(Lds.mat[Lds.hit[surface].material], lobe);
-    vertex_prepare(v, -d);   // the lobe's basis in registers (in_lds is false here)
+    vertex_prepare(v, -d, &Lds.hit[surface]);   // the lobe's basis in registers (in_lds is false here)
 }
 
 #ifndef KY_QE_WAVES

@@ -325,6 +325,19 @@ __global__ void kat_li_trace_kernel(const DScene* __restrict__ S, RenderConst rc
 // host side
 // ------------------------------------------------------------------------------------------------
 static void cp3(float* d, const float* s) { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; }
+// frame_t(n) for a unit n (ky.cpp:537-541, 566-571; ky_device.hpp make_frame): t = normalize(n x (|n.x| > 0.99 ? Y : X)), s = t x n
+static void host_frame(const float* n, float* fs, float* ft) {
+    if (std::fabs(n[0]) > 0.99f) {
+        const float k = 1.0f / std::sqrt(n[2] * n[2] + n[0] * n[0]);
+        ft[0] = -n[2] * k; ft[1] = 0.f; ft[2] = n[0] * k;
+    } else {
+        const float k = 1.0f / std::sqrt(n[2] * n[2] + n[1] * n[1]);
+        ft[0] = 0.f; ft[1] = n[2] * k; ft[2] = -n[1] * k;
+    }
+    fs[0] = ft[1] * n[2] - ft[2] * n[1];
+    fs[1] = ft[2] * n[0] - ft[0] * n[2];
+    fs[2] = ft[0] * n[1] - ft[1] * n[0];
+}
 
 static float host_shape_area(const ky_shape& s) {  // shape_t::area x4 (1141, 1222, 1304, 1401), fp32
     auto sub = [](const float* a, const float* b, float* r) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; };
@@ -667,6 +680,7 @@ static int pack_scene(const ky_scene* in, DScene* out) {
             DHit& h = out->hit[j];
             cp3(h.n, sh.kind == KY_SHAPE_SPHERE ? sh.p[0] : sh.normal);
             h.kind = sh.kind; h.material = sf.material; h.area_light = sf.area_light;
+            if (sh.kind != KY_SHAPE_SPHERE) host_frame(sh.normal, h.fs, h.ft);   // frame_t(normal), read by every vertex on this surface (ky_device.hpp, surface_frame)
             out->orig[j] = i;
             ++j;
         }

@@ -1431,13 +1431,6 @@ KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, f3 wo, int
         // work of a dead sample would need ALL lanes of the wave dead; the nested version paid for its structure with defaults and
         // exec-mask bookkeeping at every level instead.)
         const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1, S.feat);
-        f3 f;
-        float bsdf_pdf, abs_cos_i;
-        bsdf_eval_pdf(v, wo, ls.wi, f, bsdf_pdf, abs_cos_i);
-        const f3 f_cos = f * abs_cos_i;
-        const bool delta_light = S.is_delta(L.kind);
-        const f3 Ld = (!MIS || delta_light) ? (f_cos * ls.Li) * rcp(ls.pdf) : (f_cos * ls.Li) * (2.f * rcp(ls.pdf + bsdf_pdf));   // 3956 / 4057 / 4070
-        r.c = (Ld * beta) * weight;   // the product beta x weight is not kept in registers across the lights loop: three multiplies per light instead
         // scene_t::occluded(isect, ls.position), 3187-3201: the ray
         const f3 to = ls.position - v.position;
         const float d2 = length_sq(to);
@@ -1445,6 +1438,14 @@ KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, f3 wo, int
         r.d = to * inv_d;
         r.tmax = d2 * inv_d - 2e-3f;
         r.o = offset_ray_origin(v.position, v.normal, r.d);
+        f3 f;
+        float bsdf_pdf, abs_cos_i;
+        // an area light's ls.wi IS r.d for a sample that counts (the same expression of the same operands, 1075-1078): its cosine is the one the origin was offset by
+        bsdf_eval_pdf(v, wo, S.is_area(L.kind) ? r.d : ls.wi, f, bsdf_pdf, abs_cos_i);
+        const f3 f_cos = f * abs_cos_i;
+        const bool delta_light = S.is_delta(L.kind);
+        const f3 Ld = (!MIS || delta_light) ? (f_cos * ls.Li) * rcp(ls.pdf) : (f_cos * ls.Li) * (2.f * rcp(ls.pdf + bsdf_pdf));   // 3956 / 4057 / 4070
+        r.c = (Ld * beta) * weight;   // the product beta x weight is not kept in registers across the lights loop: three multiplies per light instead
         push = !(is_black(ls.Li) || (MIS ? ls.pdf <= 0 : ls.pdf == 0)) && !is_black(f_cos) && !(r.c.x == 0.f && r.c.y == 0.f && r.c.z == 0.f);
         // the sampled shape itself is the likeliest occluder (quirk 1): one test here saves the ray a full traversal
         if (S.is_area(L.kind) && L.sampled_is_surface) {   // wave-uniform
@@ -1495,7 +1496,8 @@ KY_DEV void estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v
             KY_PROBE(5);
             f3 f;
             float bsdf_pdf, abs_cos_i;
-            bsdf_eval_pdf(v, wo, ls.wi, f, bsdf_pdf, abs_cos_i);
+            // an area light's ls.wi IS dir for a live sample (the same expression of the same operands, 1075-1078): its cosine is the one the ray's origin was offset by
+            bsdf_eval_pdf(v, wo, S.is_area(L.kind) ? dir : ls.wi, f, bsdf_pdf, abs_cos_i);
             const f3 f_cos = f * abs_cos_i;
             if (!is_black(f_cos)) {
                 const bool delta_light = S.is_delta(L.kind);
@@ -1543,7 +1545,7 @@ KY_DEV void estimate_by_emitter_ride(SceneRef S, const LdsScene& Lds, const Vert
     if (!dead && !occ) {
         f3 f;
         float bsdf_pdf, abs_cos_i;
-        bsdf_eval_pdf(v, wo, ls.wi, f, bsdf_pdf, abs_cos_i);
+        bsdf_eval_pdf(v, wo, S.is_area(L.kind) ? dir : ls.wi, f, bsdf_pdf, abs_cos_i);   // (an area light's ls.wi IS dir for a live sample; no lane is both live and riding)
         const f3 f_cos = f * abs_cos_i;
         if (!is_black(f_cos)) {
             const bool delta_light = S.is_delta(L.kind);

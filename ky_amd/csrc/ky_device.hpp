@@ -386,15 +386,15 @@ KY_DEV void sampler_start(Sampler& s, uint32_t h, uint32_t sample_index) {
     s.s1 = mix32((h ^ 0x6A09E667u) + sample_index * 0x85EBCA6Bu) | 1u;
 }
 KY_DEV uint32_t rotl32(uint32_t x, int k) { return __builtin_amdgcn_alignbit(x, x, 32 - k); }   // v_alignbit_b32
-// xoroshiro64+ (Blackman / Vigna; a = 26, b = 9, c = 13): nine full-rate VALU instructions per number with the conversion -- three xor, two
-// v_alignbit, a shift, an add; v_alignbit, subtract -- against eleven for rounds 1-3's PCG-RXS-M-XS-32 with its two slow integer multiplies
+// xoroshiro64+ (Blackman / Vigna; a = 26, b = 9, c = 13): eight full-rate VALU instructions per number with the conversion -- a xor, a three-way xor
+// (v_bitop3_b32), two v_alignbit, a shift, an add; v_alignbit, subtract -- against eleven for rounds 1-3's PCG-RXS-M-XS-32 with its two slow integer multiplies
 // (v_mul_lo_u32, v_mad_u64_u32).  The sum's weak low bits are among the nine the conversion drops.
 template <bool DEBUG_SAMPLER>
 KY_DEV float sampler_next(Sampler& s) {
     if (DEBUG_SAMPLER) return 0.5f;  // debug_sampler_t, 933-941
     const uint32_t r = s.s0 + s.s1;
     s.s1 ^= s.s0;
-    s.s0 = rotl32(s.s0, 26) ^ s.s1 ^ (s.s1 << 9);
+    s.s0 = __builtin_amdgcn_bitop3_b32(rotl32(s.s0, 26), s.s1, s.s1 << 9, 0x96);   // a ^ b ^ c in one v_bitop3_b32 (gfx950; the compiler writes two v_xor for the C expression)
     s.s1 = rotl32(s.s1, 13);
     // the sum's upper 23 bits as the mantissa of a float in [1, 2), minus one: v_alignbit_b32 (0x7f : r) >> 9, v_sub -- two instructions where
     // shift, convert, scale were three; the value is (r >> 9) 2^-23 exactly, which is how the oracle writes it

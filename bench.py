@@ -86,7 +86,7 @@ LANE_OP = {
     "bsdf_dir": 29,        # concentric disk 16, z 4, basis combination 9 (the Phong lobe's mapping costs about the same)
     "ray_spawn": 7,        # offset_ray_origin (614-620)
     "continuation": 46,    # bsdf_dir + weight 6 + ray_spawn + roulette 4
-    "rng_draw": 9,         # xoroshiro64+ incl. the two-instruction conversion to [0, 1)
+    "rng_draw": 8,         # xoroshiro64+ (add, xor, 2 rotates, shift, three-way xor) incl. the two-instruction conversion to [0, 1)
     "film": 4,             # Lo / spp into the pixel's sum
 }
 SCENE_SHAPES = {   # planar rectangles in an axis plane, other parallelograms, spheres; the light kind of each light estimate

@@ -39,6 +39,20 @@ import time
 os.environ.setdefault("OMP_PROC_BIND", "close")
 os.environ.setdefault("OMP_PLACES", "cores")
 
+
+def _quota_cpus():   # (cpus_granted() below, needed here before the imports: OpenMP sizes its teams by the affinity mask, not by the cgroup's quota)
+    granted = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            granted = min(granted, max(1, int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return granted
+
+
+os.environ.setdefault("OMP_NUM_THREADS", str(_quota_cpus()))
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

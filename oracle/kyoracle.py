@@ -59,8 +59,30 @@ def _f(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def cpus_granted():
+    """CPUs this process may really use: the affinity mask cut down to the cgroup's CPU quota.  OpenMP sizes its team by the mask alone; on a box that shows
+    256 CPUs and grants two, a 256-thread team spins against the quota and a one-second render takes minutes."""
+    import os
+    granted = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            fields = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = fields[0], fields[1]
+            else:
+                quota, period = fields[0], open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0]
+            if quota not in ("max", "-1"):
+                granted = min(granted, max(1, int(round(int(quota) / int(period)))))
+            break
+        except Exception:
+            continue
+    return granted
+
+
 def render(scene, params, film=None, threads=0, counters=False):
     lib = load()
+    if threads <= 0:
+        threads = cpus_granted()
     if film is None:
         film = np.zeros((params.height, params.width, 3), np.float32)
     cnt = np.zeros(len(COUNTER_NAMES), np.uint64) if counters else None

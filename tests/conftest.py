@@ -1,8 +1,23 @@
 import os
 import sys
 
-import numpy as np
-import pytest
+# OpenMP sizes its teams by the affinity mask; a box that shows 256 CPUs and grants two through its cgroup turns every oracle call into minutes of
+# spinning against the quota (the two-rank bench test took 500 s there).  Set before numpy / torch bring an OpenMP runtime in.
+def _cpus_granted():
+    granted = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            granted = min(granted, max(1, int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return granted
+
+
+os.environ.setdefault("OMP_NUM_THREADS", str(_cpus_granted()))
+
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

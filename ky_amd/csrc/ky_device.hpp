@@ -849,6 +849,32 @@ KY_DEV void bsdf_eval_pdf(const Vertex& v, f3 wo, f3 wi, f3& f, float& pdf, floa
     pdf = nondelta ? p : 0.f;
 }
 
+// The same as two factors, f = col x scale, for callers that multiply the value by a chain of scalars (the light-sampling estimators: |cos|, the MIS
+// factor, the strategy weight): the scalars are multiplied first and the three colour channels once.  col: the material's colour as stored.
+KY_DEV void bsdf_eval_parts(const Vertex& v, f3 wo, f3 wi, f3& col, float& scale, float& pdf, float& abs_cos_i) {
+    const Bsdf& B = v.bsdf;
+    const float cos_o = dot(v.normal, wo), cos_i = dot(v.normal, wi);
+    abs_cos_i = fabsf(cos_i);
+    const bool same = cos_o * cos_i > 0;
+    float p;
+    if (B.lobe == LOBE_PHONG) {
+        const float cos_alpha = dot(vertex_basis_c(v), wi);
+        const float exponent = B.m->exponent;
+        const float pe = phong_pow(cos_alpha, exponent, B.m->exp_flags);
+        const float p0 = exponent == 0.f ? 1.f : (exponent > 0.f ? 0.f : K_INF);
+        col = ld3(B.m->cs);
+        scale = same ? pe * B.m->inv_eta : 0.f;
+        p = (cos_alpha > 0.f ? pe : p0) * B.m->phong_pdf_norm;
+    } else {
+        col = ld3(B.m->c0);
+        scale = same ? K_INV_PI : 0.f;
+        p = same ? abs_cos_i * K_INV_PI : 0.f;
+    }
+    const bool nondelta = !bsdf_is_delta(B);
+    scale = nondelta ? scale : 0.f;
+    pdf = nondelta ? p : 0.f;
+}
+
 // The direction half of sample_ for the two non-delta lobes, world space (their value and pdf are eval_ / pdf_ of that
 // direction: 2253-2254, 2526-2527), so that a caller that rarely needs the value can defer it (estimate_by_bsdf).
 // Both lobes place a point (rad cos, rad sin) on a circle and lift it: the cosine lobe by the concentric disk mapping (710-743), the
@@ -990,6 +1016,7 @@ KY_DEV BsdfContinue bsdf_continue(const Vertex& v, f3 wo, float u0, float u1) {
 struct LightSample {
     f3 position, wi, Li;
     float pdf;
+    bool lit;   // area lights: the sample sees the light's emitting side, i.e. Li is the light's colour (a wave-uniform value) and not black by position
 };
 
 KY_DEV f3 uniform_sphere_sample(float u0, float u1) {  // 761-769
@@ -1096,6 +1123,7 @@ KY_DEV float env_pdf(float wz) {
 // light_t::sample_Li x4 (2825, 2891, 2964, 3026)
 KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0, float u1, int feat = 0) {
     LightSample s;   // every kind (wave-uniform) assigns every field
+    s.lit = true;
     const SceneRef K{nullptr, false, feat};   // the kind predicates only
     if (K.is_area(L.kind)) {
         f3 lposition, lnormal;
@@ -1108,6 +1136,7 @@ KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0,
         s.wi = mk3(ok ? wi.x : 0.f, ok ? wi.y : 0.f, ok ? wi.z : 0.f);
         // areal_radiance(light_isect, -wi) with the SAMPLED (stored) normal: one-sided (quirk 5), 2957-2960
         const bool lit = ok && dot(lnormal, wi) < 0;
+        s.lit = lit;
         s.Li = mk3(lit ? L.color[0] : 0.f, lit ? L.color[1] : 0.f, lit ? L.color[2] : 0.f);
     } else if (K.is_delta(L.kind) && L.kind == KY_LIGHT_POINT) {
         const f3 lp = ld3(L.position);
@@ -1440,15 +1469,21 @@ KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, f3 wo, int
         r.d = to * inv_d;
         r.tmax = d2 * inv_d - 2e-3f;
         r.o = offset_ray_origin(v.position, v.normal, r.d);
-        f3 f;
-        float bsdf_pdf, abs_cos_i;
+        f3 col;
+        float scale, bsdf_pdf, abs_cos_i;
         // an area light's ls.wi IS r.d for a sample that counts (the same expression of the same operands, 1075-1078): its cosine is the one the origin was offset by
-        bsdf_eval_pdf(v, wo, S.is_area(L.kind) ? r.d : ls.wi, f, bsdf_pdf, abs_cos_i);
-        const f3 f_cos = f * abs_cos_i;
+        bsdf_eval_parts(v, wo, S.is_area(L.kind) ? r.d : ls.wi, col, scale, bsdf_pdf, abs_cos_i);
         const bool delta_light = S.is_delta(L.kind);
-        const f3 Ld = (!MIS || delta_light) ? (f_cos * ls.Li) * rcp(ls.pdf) : (f_cos * ls.Li) * (2.f * rcp(ls.pdf + bsdf_pdf));   // 3956 / 4057 / 4070
-        r.c = (Ld * beta) * weight;   // the product beta x weight is not kept in registers across the lights loop: three multiplies per light instead
-        push = !(is_black(ls.Li) || (MIS ? ls.pdf <= 0 : ls.pdf == 0)) && !is_black(f_cos) && !(r.c.x == 0.f && r.c.y == 0.f && r.c.z == 0.f);
+        // f |cos| Li / pdf (3956) or 2 f |cos| Li / (p_l + p_b) (4057 / 4070), times throughput and strategy weight: the scalar factors first, the three channels once;
+        // an area light's Li is its colour where the sample is lit (a wave-uniform value: scalar operands) and the predicate below says whether it is
+        const float fc = scale * abs_cos_i;   // f |cos| = col x fc
+        const float k = fc * ((!MIS || delta_light) ? rcp(ls.pdf) : 2.f * rcp(ls.pdf + bsdf_pdf)) * weight;
+        const bool area = S.is_area(L.kind);
+        const f3 Li = area ? ld3(L.color) : ls.Li;
+        r.c = ((col * Li) * beta) * k;
+        // !is_black(f |cos|) (3952 / 4052) without the product: a positive factor (a Phong lobe's odd power of a negative cosine is negative: black) and a material that is
+        // not black; a NaN factor counts.  (A light whose colour is not finite must not meet a zero here: 0 x inf.)
+        push = (area ? ls.lit : !is_black(ls.Li)) && !(MIS ? ls.pdf <= 0 : ls.pdf == 0) && !(fc <= 0.f) && !is_black(col);
         // the sampled shape itself is the likeliest occluder (quirk 1): one test here saves the ray a full traversal
         if (S.is_area(L.kind) && L.sampled_is_surface) {   // wave-uniform
             float t;
@@ -1481,7 +1516,8 @@ KY_DEV void estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v
     const DLight& L = scene_light(S, li);
     KY_PROBE(3);
     const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1, S.feat);
-    const bool dead = is_black(ls.Li) || (MIS ? (ls.pdf <= 0) : (ls.pdf == 0));
+    const bool area = S.is_area(L.kind);   // (wave-uniform)
+    const bool dead = (area ? !ls.lit : is_black(ls.Li)) || (MIS ? (ls.pdf <= 0) : (ls.pdf == 0));
     KY_CLK(5);
     if (!dead) {
         // scene_t::occluded(isect, ls.position), 3187-3201
@@ -1496,15 +1532,16 @@ KY_DEV void estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v
         KY_CLK(6);
         if (!occ) {
             KY_PROBE(5);
-            f3 f;
-            float bsdf_pdf, abs_cos_i;
+            f3 col;
+            float scale, bsdf_pdf, abs_cos_i;
             // an area light's ls.wi IS dir for a live sample (the same expression of the same operands, 1075-1078): its cosine is the one the ray's origin was offset by
-            bsdf_eval_pdf(v, wo, S.is_area(L.kind) ? dir : ls.wi, f, bsdf_pdf, abs_cos_i);
-            const f3 f_cos = f * abs_cos_i;
-            if (!is_black(f_cos)) {
+            bsdf_eval_parts(v, wo, area ? dir : ls.wi, col, scale, bsdf_pdf, abs_cos_i);
+            const float fc = scale * abs_cos_i;   // f |cos| = col x fc
+            if (!(fc <= 0.f) && !is_black(col)) {    // !is_black(f |cos|), 3952 / 4052: some channel positive (colours are not negative; a NaN factor counts)
                 const bool delta_light = S.is_delta(L.kind);
-                const float k = (!MIS || delta_light) ? rcp(ls.pdf) : 2.f * rcp(ls.pdf + bsdf_pdf);   // 3956 / 4057 / 4070
-                acc = acc + w * ((f_cos * ls.Li) * k);
+                // 3956 / 4057 / 4070, the scalar factors first; an area light's Li is its colour where the sample is lit (wave-uniform: scalar operands)
+                const float k = fc * ((!MIS || delta_light) ? rcp(ls.pdf) : 2.f * rcp(ls.pdf + bsdf_pdf));
+                acc = acc + ((col * (area ? ld3(L.color) : ls.Li)) * w) * k;
             }
             KY_CLK(7);
         }
@@ -1517,11 +1554,12 @@ KY_DEV void estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v
 template <bool MIS>
 KY_DEV void estimate_by_emitter_ride(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, int li, float u0, float u1, bool active, RideAlong& ra, f3& acc, f3 w) {
     const DLight& L = scene_light(S, li);
-    LightSample ls{any3(), any3(), any3(), any_f()};
+    LightSample ls{any3(), any3(), any3(), any_f(), false};
+    const bool area = S.is_area(L.kind);   // (wave-uniform)
     bool dead = true;
     if (active) {
         ls = light_sample_Li(L, v.position, v.normal, u0, u1, S.feat);
-        dead = is_black(ls.Li) || (MIS ? (ls.pdf <= 0) : (ls.pdf == 0));
+        dead = (area ? !ls.lit : is_black(ls.Li)) || (MIS ? (ls.pdf <= 0) : (ls.pdf == 0));
     }
     f3 o = any3(), dir = any3();
     float tmax = any_f();
@@ -1545,14 +1583,14 @@ KY_DEV void estimate_by_emitter_ride(SceneRef S, const LdsScene& Lds, const Vert
         occ = light_sample_occluded(S, li, o, dir, tmax);
     }
     if (!dead && !occ) {
-        f3 f;
-        float bsdf_pdf, abs_cos_i;
-        bsdf_eval_pdf(v, wo, S.is_area(L.kind) ? dir : ls.wi, f, bsdf_pdf, abs_cos_i);   // (an area light's ls.wi IS dir for a live sample; no lane is both live and riding)
-        const f3 f_cos = f * abs_cos_i;
-        if (!is_black(f_cos)) {
+        f3 col;
+        float scale, bsdf_pdf, abs_cos_i;
+        bsdf_eval_parts(v, wo, area ? dir : ls.wi, col, scale, bsdf_pdf, abs_cos_i);   // (an area light's ls.wi IS dir for a live sample; no lane is both live and riding)
+        const float fc = scale * abs_cos_i;
+        if (!(fc <= 0.f) && !is_black(col)) {    // !is_black(f |cos|), 3952 / 4052: some channel positive (colours are not negative; a NaN factor counts)
             const bool delta_light = S.is_delta(L.kind);
-            const float k = (!MIS || delta_light) ? rcp(ls.pdf) : 2.f * rcp(ls.pdf + bsdf_pdf);   // 3956 / 4057 / 4070
-            acc = acc + w * ((f_cos * ls.Li) * k);
+            const float k = fc * ((!MIS || delta_light) ? rcp(ls.pdf) : 2.f * rcp(ls.pdf + bsdf_pdf));   // 3956 / 4057 / 4070: scalar factors first (estimate_by_emitter)
+            acc = acc + ((col * (area ? ld3(L.color) : ls.Li)) * w) * k;
         }
     }
 }

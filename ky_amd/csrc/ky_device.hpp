@@ -523,22 +523,31 @@ KY_DEV void aar_scan(SceneRef S, unsigned aar_off, int first, int n, f3 o, f3 d,
 }
 
 // sphere_t::intersect, 1336-1393.  sqrt of a negative discriminant is NaN, which fails both range tests.
-KY_DEV bool sph_hit(const float4 c, f3 o, f3 d, float tmax, float& t_out) {
+// The second half -- root, two distances, four range tests -- runs only when some lane's LINE meets the sphere (a wave-uniform branch on the discriminants' signs):
+// for a lamp that subtends a thousandth of the sphere of directions that is one wavefront in fifty, and a Veach vertex tests five such lamps three times over.
+// `sparse` (a compile-time constant at every call): the scene's spheres are small lamps (KY_FEAT_SPHERE_LIGHTS).  With the two big spheres of a Cornell box some lane's
+// line nearly always meets the sphere and the branch only costs (configs[1] -1.3 %); with Veach's lamps it pays (configs[2] +1.9 %).
+KY_DEV bool sph_hit(const float4 c, f3 o, f3 d, float tmax, float& t_out, bool sparse = false) {
     const f3 oc = mk3(c.x, c.y, c.z) - o;
     const float neg_b = dot(oc, d);
     const float discr = neg_b * neg_b - dot(oc, oc) + c.w;
-    const float sq = fsqrt(discr);
-    const float t0 = neg_b - sq, t1 = neg_b + sq;
-    const bool h0 = (t0 > K_SHAPE_EPS) & (t0 < tmax);
-    const bool h1 = (t1 > K_SHAPE_EPS) & (t1 < tmax);
-    t_out = h0 ? t0 : t1;
-    return h0 | h1;
+    bool hit = false;
+    t_out = neg_b;   // (read by no caller without a hit)
+    if (!sparse || __any(discr >= 0.f)) {
+        const float sq = fsqrt(discr);
+        const float t0 = neg_b - sq, t1 = neg_b + sq;
+        const bool h0 = (t0 > K_SHAPE_EPS) & (t0 < tmax);
+        const bool h1 = (t1 > K_SHAPE_EPS) & (t1 < tmax);
+        t_out = h0 ? t0 : t1;
+        hit = h0 | h1;
+    }
+    return hit;
 }
 
 // one shape given as a generic record (KAT entry point, light shapes re-intersected by pdf_direction)
 // `general` false: the caller knows the record is a parallelogram or a sphere (SceneRef::general)
 KY_DEV bool surf_hit(const DSurf& S, const DShapeFull* __restrict__ full, f3 o, f3 d, float tmax, float& t_out, bool general = true, bool sphere_only = false) {
-    if (sphere_only) return sph_hit(make_float4(S.f[0], S.f[1], S.f[2], S.f[3]), o, d, tmax, t_out);   // the caller knows (KY_FEAT_SPHERE_LIGHTS)
+    if (sphere_only) return sph_hit(make_float4(S.f[0], S.f[1], S.f[2], S.f[3]), o, d, tmax, t_out, true);   // the caller knows (KY_FEAT_SPHERE_LIGHTS): small lamps
     if (S.kind == TK_PARALLELOGRAM)
         return par_hit(make_float4(S.f[0], S.f[1], S.f[2], S.f[3]), make_float4(S.f[4], S.f[5], S.f[6], S.f[7]), make_float4(S.f[8], S.f[9], S.f[10], S.f[11]), o, d, tmax, t_out);
     if (!general || S.kind == TK_SPHERE) return sph_hit(make_float4(S.f[0], S.f[1], S.f[2], S.f[3]), o, d, tmax, t_out);
@@ -577,7 +586,7 @@ KY_DEV int trace_nearest(SceneRef S, f3 o, f3 d, float& tmax) {
         for (int i = 0; i < n_sph; ++i) {
             asm volatile("" : "+s"(off));
             float t;
-            const bool ok = sph_hit(scene_at<DSph>(S, off).c, o, d, tmax, t);
+            const bool ok = sph_hit(scene_at<DSph>(S, off).c, o, d, tmax, t, S.sphere_lights());
             tmax = ok ? t : tmax;
             best = ok ? n_aar + n_par + i : best;
             off += (unsigned)sizeof(DSph);
@@ -629,7 +638,7 @@ KY_DEV bool trace_any(SceneRef S, const DTrav& T, f3 o, f3 d, float tmax) {
         unsigned off = scene_off(S, &S->sph[0]);
         for (int i = 0; i < n_sph; ++i) {
             asm volatile("" : "+s"(off));
-            occ = occ | sph_hit(scene_at<DSph>(S, off).c, o, d, tmax, t);
+            occ = occ | sph_hit(scene_at<DSph>(S, off).c, o, d, tmax, t, S.sphere_lights());
             off += (unsigned)sizeof(DSph);
         }
     }

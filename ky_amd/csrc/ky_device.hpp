@@ -546,8 +546,8 @@ KY_DEV bool sph_hit(const float4 c, f3 o, f3 d, float tmax, float& t_out, bool s
 
 // one shape given as a generic record (KAT entry point, light shapes re-intersected by pdf_direction)
 // `general` false: the caller knows the record is a parallelogram or a sphere (SceneRef::general)
-KY_DEV bool surf_hit(const DSurf& S, const DShapeFull* __restrict__ full, f3 o, f3 d, float tmax, float& t_out, bool general = true, bool sphere_only = false) {
-    if (sphere_only) return sph_hit(make_float4(S.f[0], S.f[1], S.f[2], S.f[3]), o, d, tmax, t_out, true);   // the caller knows (KY_FEAT_SPHERE_LIGHTS): small lamps
+KY_DEV bool surf_hit(const DSurf& S, const DShapeFull* __restrict__ full, f3 o, f3 d, float tmax, float& t_out, bool general = true, bool sphere_only = false, bool sparse = true) {
+    if (sphere_only) return sph_hit(make_float4(S.f[0], S.f[1], S.f[2], S.f[3]), o, d, tmax, t_out, sparse);   // the caller knows (KY_FEAT_SPHERE_LIGHTS): small lamps, rarely met (sparse)
     if (S.kind == TK_PARALLELOGRAM)
         return par_hit(make_float4(S.f[0], S.f[1], S.f[2], S.f[3]), make_float4(S.f[4], S.f[5], S.f[6], S.f[7]), make_float4(S.f[8], S.f[9], S.f[10], S.f[11]), o, d, tmax, t_out);
     if (!general || S.kind == TK_SPHERE) return sph_hit(make_float4(S.f[0], S.f[1], S.f[2], S.f[3]), o, d, tmax, t_out);
@@ -1496,7 +1496,7 @@ KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, f3 wo, int
         // the sampled shape itself is the likeliest occluder (quirk 1): one test here saves the ray a full traversal
         if (S.is_area(L.kind) && L.sampled_is_surface) {   // wave-uniform
             float t;
-            if (surf_hit(L.isect, S->full, r.o, r.d, r.tmax, t, S.general, S.sphere_lights())) push = false;
+            if (surf_hit(L.isect, S->full, r.o, r.d, r.tmax, t, S.general, S.sphere_lights(), false)) push = false;   // (every one of these rays is aimed at the sphere: not sparse)
         }
     }
     sq_push(S, q, push, r);

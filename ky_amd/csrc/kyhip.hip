@@ -33,6 +33,7 @@
 #include <map>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <cctype>
 #include <cstring>
 #include <functional>
 #include <limits>
@@ -1191,7 +1192,10 @@ static bool read_file(const std::string& path, std::vector<char>& out) {
 // KYHIP_JIT_FLAGS: more compiler flags for the run-time instantiations (tuning: -DKY_WAVES_PER_EU_QUEUE=5 ...); part of the cache key
 static std::string extra_flags() {
     const char* e = std::getenv("KYHIP_JIT_FLAGS");
-    return e ? e : "";
+    if (!e) return "";
+    for (const char* c = e; *c; ++c)   // the string goes into a shell command: compiler options only (-DNAME=1 -mllvm ...), no quoting, no metacharacters
+        if (!(std::isalnum((unsigned char)*c) || std::strchr("_=-+.,/ ", *c))) return "";
+    return e;
 }
 static std::string compiler() {
     if (const char* e = std::getenv("KYHIP_HIPCC")) return e;

@@ -1,5 +1,5 @@
 # Builds every native piece in-tree:
-#   ky_amd/lib/libkyhip.so   the product: gfx950 kernels + C ABI (include/kyhip.h)
+#   ky_amd/lib/libkyhip.so   the product: gfx950 kernels + C ABI (include/kyhip.h), five translation units under ky_amd/csrc
 #   ky_amd/lib/libkyhost.so  host-side C++ API (ky_amd/host/ky.hpp) behind a small C API for Python
 #   oracle/libkyoracle.so    the CPU checker (test infrastructure only)
 HIPCC    ?= hipcc
@@ -12,14 +12,32 @@ LIBDIR   := ky_amd/lib
 
 all: $(LIBDIR)/libkyhip.so $(LIBDIR)/libkyhost.so oracle examples
 
-# the device headers as text inside the library: what its run-time instantiations compile (kyhip.hip, kyjit)
-RTC_INC := ky_amd/csrc/ky_rtc_sources.inc
-$(RTC_INC): ky_amd/csrc/ky_device.hpp ky_amd/csrc/ky_render.hpp include/kyhip.h tools/embed_sources.py
-	python3 tools/embed_sources.py $@ ky_device.hpp=ky_amd/csrc/ky_device.hpp ky_render.hpp=ky_amd/csrc/ky_render.hpp ../../include/kyhip.h=include/kyhip.h
+# the device headers as text inside the library: what its run-time instantiations compile (ky_jit.cpp)
+CSRC    := ky_amd/csrc
+RTC_INC := $(CSRC)/ky_rtc_sources.inc
+DEVICE_HDRS := $(CSRC)/ky_scene.hpp $(CSRC)/ky_shard.hpp $(CSRC)/ky_device.hpp $(CSRC)/ky_render.hpp
+$(RTC_INC): $(DEVICE_HDRS) include/kyhip.h tools/embed_sources.py
+	python3 tools/embed_sources.py $@ ky_scene.hpp=$(CSRC)/ky_scene.hpp ky_shard.hpp=$(CSRC)/ky_shard.hpp ky_device.hpp=$(CSRC)/ky_device.hpp ky_render.hpp=$(CSRC)/ky_render.hpp ../../include/kyhip.h=include/kyhip.h
 
-$(LIBDIR)/libkyhip.so: ky_amd/csrc/kyhip.hip ky_amd/csrc/ky_device.hpp ky_amd/csrc/ky_queue.hpp ky_amd/csrc/ky_smallpt.hpp ky_amd/csrc/ky_measure.hpp ky_amd/csrc/ky_render.hpp include/kyhip.h $(RTC_INC)
+# libkyhip.so = five translation units (round 5; one 2100-line kyhip.hip before):
+#   ky_launch.hip  the render kernels' table + launch path, film kernels, fp64 smallpt      ky_kat.hip   KAT kernels + entries
+#   ky_pack.cpp    host: params, scene packing, occluder proof, policies, HostPool           ky_jit.cpp   run-time instantiations' code cache
+#   ky_seam.cpp    host-film calls (kyhip_render / kyhip_render_multi)
+# (ky_pack.cpp and ky_jit.cpp make no HIP call: `make sanitize` builds the same files with g++ -fsanitize=...)
+HOST_HDRS := $(CSRC)/ky_host.hpp $(CSRC)/ky_ctx.hpp $(CSRC)/ky_scene.hpp $(CSRC)/ky_shard.hpp include/kyhip.h
+OBJDIR  := build/obj
+KYHIP_OBJS := $(OBJDIR)/ky_launch.o $(OBJDIR)/ky_kat.o $(OBJDIR)/ky_pack.o $(OBJDIR)/ky_jit.o $(OBJDIR)/ky_seam.o
+$(OBJDIR)/ky_launch.o: $(CSRC)/ky_launch.hip $(DEVICE_HDRS) $(CSRC)/ky_queue.hpp $(CSRC)/ky_smallpt.hpp $(CSRC)/ky_measure.hpp $(HOST_HDRS)
+$(OBJDIR)/ky_kat.o: $(CSRC)/ky_kat.hip $(DEVICE_HDRS) $(CSRC)/ky_measure.hpp $(HOST_HDRS)
+$(OBJDIR)/ky_pack.o: $(CSRC)/ky_pack.cpp $(HOST_HDRS)
+$(OBJDIR)/ky_jit.o: $(CSRC)/ky_jit.cpp $(HOST_HDRS) $(RTC_INC)
+$(OBJDIR)/ky_seam.o: $(CSRC)/ky_seam.cpp $(HOST_HDRS)
+$(OBJDIR)/%.o:
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(KYFLAGS) -c -o $@ $<
+$(LIBDIR)/libkyhip.so: $(KYHIP_OBJS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ ky_amd/csrc/kyhip.hip
+	$(HIPCC) --offload-arch=gfx950 -fPIC -no-hip-rt -shared -o $@ $(KYHIP_OBJS)
 
 $(LIBDIR)/libkyhost.so: ky_amd/host/ky_capi.cpp ky_amd/host/ky.hpp include/kyhip.h $(LIBDIR)/libkyhip.so
 	$(CXX) -O2 -std=c++17 -fPIC -Wall -shared -o $@ ky_amd/host/ky_capi.cpp -L$(LIBDIR) -lkyhip -Wl,-rpath,'$$ORIGIN'
@@ -41,6 +59,6 @@ build_variants/%: tools/ubench/%.hip
 	$(HIPCC) --offload-arch=gfx950 -O2 -Wno-unused-value -o $@ $<
 
 clean:
-	rm -rf $(LIBDIR) examples/bin $(RTC_INC)
+	rm -rf $(LIBDIR) examples/bin $(RTC_INC) $(OBJDIR)
 	$(MAKE) -C oracle clean
 .PHONY: all oracle examples ubench clean

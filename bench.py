@@ -78,18 +78,26 @@ def bytes_per_sample(iterations):
 ITER = {"cornell": 4.168, "veach": 2.711, "cornell_d16": 4.266, "cornell_other_lights": 4.215, "veach_square": 2.803, "aov": 1.0}
 
 
-# ---- roofline.valu_model: USEFUL lane-instructions per camera sample, independent of how the kernel is built ------------------------
+# ---- roofline.valu_model: USEFUL lane-instructions per camera sample -- a floor, never more than what ran ------------------------------
 # The path is bound by VALU issue, so its roofline is lane-slots: CUs x 4 SIMDs x 32 fp32 lanes per clock at the maximum
 # engine clock (the guide's 157.3 TFLOP/s of vector fp32 FMAs is the same figure x 2).  What fills a slot usefully is one fp32 / int32 VALU
-# operation of ONE path that the ALGORITHM needs: the reference's own event counts per camera sample (tests/golden/work_counters.json: the
-# oracle's counters of each frame; tests/test_oracle_pins.py holds them to SURVEY section 6's gprof counts of the reference within 1.2 %)
-# priced with the cheapest instruction sequence each event admits on this ISA (DESIGN.md 7 has the table with the sequences).  A kernel that
-# wastes instructions, idles lanes or waits scores lower; one that skips work the reference does (the occluder tables, the MIS rays' carrier
-# test) scores higher -- the fraction prices the algorithm's work, not the kernel's.
+# operation of ONE path that the CHEAPEST ALGORITHM for the reference's result needs: the reference's event counts per camera sample
+# (tests/golden/work_counters.json: the oracle's counters of each frame; tests/test_oracle_pins.py holds them to SURVEY section 6's gprof
+# counts of the reference within 1.2 %), each priced with the least work that decides it (round 5; rounds 3-4 priced every ray as the
+# reference traces it -- every surface of the scene -- and so credited work the kernel legitimately skips: 0.82 on configs[2] for a
+# kernel whose counters say 0.50):
+#   nearest-hit ray      every surface once (no scan of a dozen surfaces beats the branch-free linear one: DESIGN.md 10)
+#   MIS BSDF ray         "is the nearest hit a carrier of this light" (3989-3995): the carrier's own test -- one parallelogram (a Cornell lamp)
+#                        or the discriminant half of a sphere test (a Veach lamp: a line that misses the sphere needs no root)
+#   shadow ray           occluded: ONE surface test (the first surface tried is the blocker at best); unoccluded: the light's occluder table
+#                        once (DScene::occ_front / occ / trav: the surfaces no proof removes)
+# so that useful <= executed by construction: main() checks it against the kernel's own counters whenever profiles/valu.json describes the
+# loaded kernels (`valu_model_exceeds_executed`), and reports the executed fraction (`lane_slot_frac`) beside `frac`.
 LANE_OP = {
-    "aar_test": 12,        # rectangle in an axis plane, incl. the nearest / any update: sub, mul, 2 x (fma, sub), 4 compares, 2 selects
-    "par_test": 26,        # planar parallelogram: 2 dots (6), rcp, mul, hit point (3), 2 dual-basis dots + offsets (8), 4 compares, 2 selects
+    "aar_test": 12,        # rectangle in an axis plane, incl. the nearest / any update: sub, mul, 2 x (fma, sub), 4 compares, 2 moves
+    "par_test": 26,        # planar parallelogram: 2 dots (6), rcp, mul, hit point (3), 2 dual-basis dots + offsets (8), 4 compares, 2 moves
     "sphere_test": 21,     # oc (3), b (3), |oc|^2 (3), discriminant (2), sqrt, 2 roots, 4 compares, select, 2 selects
+    "sphere_reject": 11,   # the same up to the discriminant's sign (a lamp that subtends a thousandth of the directions: sph_hit's `sparse` form)
     "traversal_setup": 7,  # 3 reciprocals of the direction, tmax / best initialisation
     "vertex": 32,          # hit point 3, normal fetch + flip / normalise 8, emission test 5, termination tests 3, material + lobe 6, ray spawn 7
     "frame": 12,           # frame_t(n) for a non-delta vertex (566-571): rsq, 2 mul, cross
@@ -103,10 +111,16 @@ LANE_OP = {
     "rng_draw": 8,         # xoroshiro64+ (add, xor, 2 rotates, shift, three-way xor) incl. the two-instruction conversion to [0, 1)
     "film": 4,             # Lo / spp into the pixel's sum
 }
-SCENE_SHAPES = {   # planar rectangles in an axis plane, other parallelograms, spheres; the light kind of each light estimate
-    "cornell": (10, 0, 2, "rect"), "cornell_area": (10, 0, 2, "rect"), "cornell_d16": (10, 0, 2, "rect"),
-    "cornell_point": (5, 0, 2, "point"), "cornell_direction": (5, 0, 2, "direction"), "cornell_environment": (5, 0, 2, "environment"),
-    "veach": (2, 4, 5, "sphere"), "veach_square": (2, 4, 5, "sphere"),
+# per frame: the whole scene (rectangles in an axis plane, other parallelograms, spheres), the light kind of each light estimate, what an MIS BSDF ray must
+# test (LANE_OP key; None: the light has no BSDF-sampling half or no carrier surface), and the occluder table an UNOCCLUDED shadow ray scans (same triple;
+# spheres of a sphere-lights scene at the reject price).  The Cornell lamp's table is DScene::occ_front (the lamp's rectangle + the two balls); the delta
+# lights' is DScene::occ (the room's five walls proved away: two balls); the environment light's rays leave the room: every surface; Veach: no wall
+# qualifies (its floor reaches under the back wall), every surface.
+SCENE_SHAPES = {
+    "cornell": ((10, 0, 2), "rect", "par_test", (1, 0, 2)), "cornell_area": ((10, 0, 2), "rect", "par_test", (1, 0, 2)), "cornell_d16": ((10, 0, 2), "rect", "par_test", (1, 0, 2)),
+    "cornell_point": ((5, 0, 2), "point", None, (0, 0, 2)), "cornell_direction": ((5, 0, 2), "direction", None, (5, 0, 2)),
+    "cornell_environment": ((5, 0, 2), "environment", None, (5, 0, 2)),
+    "veach": ((2, 4, 5), "sphere", "sphere_reject", (2, 4, 5)), "veach_square": ((2, 4, 5), "sphere", "sphere_reject", (2, 4, 5)),
 }
 
 
@@ -123,13 +137,22 @@ def useful_lane_ops(label, counters):
     c = counters.get(label)
     if not c or label not in SCENE_SHAPES:
         return None, None
-    n_aar, n_par, n_sph, light = SCENE_SHAPES[label]
-    per_traversal = n_aar * LANE_OP["aar_test"] + n_par * LANE_OP["par_test"] + n_sph * LANE_OP["sphere_test"] + LANE_OP["traversal_setup"]
+    (n_aar, n_par, n_sph), light, mis_test, (o_aar, o_par, o_sph) = SCENE_SHAPES[label]
+    sphere_lamps = light == "sphere"
+    per_nearest = n_aar * LANE_OP["aar_test"] + n_par * LANE_OP["par_test"] + n_sph * LANE_OP["sphere_test"] + LANE_OP["traversal_setup"]
+    per_unoccluded = (o_aar * LANE_OP["aar_test"] + o_par * LANE_OP["par_test"] + o_sph * LANE_OP["sphere_reject" if sphere_lamps else "sphere_test"]
+                      + LANE_OP["traversal_setup"])
+    per_occluded = LANE_OP["sphere_test"] if sphere_lamps else LANE_OP["aar_test"]   # the blocker itself: a lamp's own sphere (quirk 1) / the Cornell lamp's rectangle
+    nearest = c["traversals"] - c["shadow_rays"] - c["mis_bsdf_rays"]
+    # an environment light's BSDF-sampled ray asks for the NEAREST hit of the whole scene (a miss counts): no carrier to test instead
+    per_mis = LANE_OP[mis_test] if mis_test else (per_nearest if light == "environment" else 0)
     area = light in ("rect", "sphere", "environment")   # lights whose estimate has a BSDF-sampling half (a delta light's returns black, 3977)
     per_estimate = LANE_OP["light_" + light] + LANE_OP["shadow_setup"] + LANE_OP["bsdf_eval"] + LANE_OP["mis"] + ((LANE_OP["bsdf_dir"] + LANE_OP["ray_spawn"]) if area else 0)
     draws = 2 + 4 * c["light_estimates"] + 2 * c["bsdf_path_samples"] + c["rr_draws"]
     terms = {
-        "traversals": c["traversals"] * per_traversal,
+        "nearest_hit_rays": nearest * per_nearest,
+        "mis_bsdf_rays": c["mis_bsdf_rays"] * per_mis,
+        "shadow_rays": (c["shadow_rays"] - c["shadow_occluded"]) * per_unoccluded + c["shadow_occluded"] * per_occluded,
         "path_vertices": c["path_iterations"] * LANE_OP["vertex"] + c["nee_vertices"] * LANE_OP["frame"],
         "light_estimates": c["light_estimates"] * per_estimate,
         "continuation": c["bsdf_path_samples"] * LANE_OP["continuation"],
@@ -137,6 +160,13 @@ def useful_lane_ops(label, counters):
         "film": LANE_OP["film"],
     }
     return sum(terms.values()), terms
+
+
+def frame_iterations(label, fallback):
+    """mean path iterations per camera sample of the frame `label`: its own counter (tests/golden/work_counters.json) where there is one --
+    configs[1]'s 4:3 frame holds 3.489, not the square frame's 4.168 SURVEY section 6 quotes."""
+    c = work_counters().get(label)
+    return float(c["path_iterations"]) if c and "path_iterations" in c else fallback
 
 
 def parse():
@@ -153,8 +183,8 @@ def parse():
                     help="direct_sample_enum_t of the path integrator frames (profiling the run-time-dispatched kernel; the metric's configs use 48)")
     ap.add_argument("--integrator", type=int, default=A.INTEGRATOR_PATH_TRACING_ITERATION, choices=[6, 8, 9, 10, 11],
                     help="integrator_enum_t of the path frames (profiling direct_lighting_t = 6 and the recursive integrators 8 / 9 / 10; the metric's configs use 11)")
-    ap.add_argument("--no-pipeline", action="store_true", help="render the timed steps on one stream even with N > 1 (no overlap of a frame's start with the previous frame's tail)")
-    ap.add_argument("--pipeline", action="store_true", help="overlap consecutive frames on two streams at N = 1 too (default: only with N > 1)")
+    ap.add_argument("--no-pipeline", action="store_true", help="render the timed steps on one stream (no overlap of a frame's start with the previous frame's tail): `value` is then the single-frame rate")
+    ap.add_argument("--pipeline", action="store_true", help="(the default since round 5, at every N: consecutive frames on two streams; kept so that old command lines still parse)")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_workloads and projected_scaling (they run for the default N = 1 cornell line only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
@@ -164,7 +194,8 @@ def parse():
 class Frame:
     def __init__(self, label, scene, params, iterations, origin=(0, 0)):
         self.label, self.scene, self.params, self.origin = label, scene, params, origin
-        self.bytes_per_sample = bytes_per_sample(iterations)
+        self.iterations = frame_iterations(label, iterations)   # the frame's own count where the oracle's counters hold one, SURVEY's otherwise
+        self.bytes_per_sample = bytes_per_sample(self.iterations)
         self.samples = params.width * params.height * params.samples_per_pixel
 
 
@@ -324,6 +355,15 @@ def load_json(name):
         return None
 
 
+def executed_lane_ops(key, lib_sha):
+    """Active lane-instructions per camera sample the kernels of workload `key` really executed: SQ_INSTS_VALU x 64 x lane occupancy from the
+    counter set of profiles/valu.json -- None when there is no set for the workload or it was measured on other kernel sources."""
+    v = (load_json("valu.json") or {}).get(key)
+    if not v or v.get("kernel_source_hash") != lib_sha or not v.get("wave_instr_per_sample") or not v.get("lane_occupancy"):
+        return None
+    return v["wave_instr_per_sample"] * 64.0 * v["lane_occupancy"]
+
+
 def contract_frac(frames, kernel_ms_per_frame, world=1):
     """algorithmic bytes of the launch set over the measured kernel time, against the HBM peak."""
     launch_bytes = sum(fr.bytes_per_sample * fr.samples / world for fr in frames)
@@ -346,10 +386,15 @@ def main():
     # KY_BENCH_ONE_GPU=1 (testing only): every rank uses cuda:0 and the gather runs over gloo, so that the N > 1 code
     # path can be exercised on a single-GPU box; the numbers of such a run are meaningless.
     one_gpu_test = os.environ.get("KY_BENCH_ONE_GPU") == "1"
-    if one_gpu_test:
-        local_rank = 0
+    # The device of this rank: LOCAL_RANK among the devices THIS PROCESS sees.  A launcher that masks devices per rank (HIP_VISIBLE_DEVICES /
+    # ROCR_VISIBLE_DEVICES = one GPU each, the commonest way to start eight ranks) leaves every rank with device 0 only; one that does not leaves
+    # every rank with all of them.  `local_rank % device_count` is right in both cases (and in the one-GPU test, where every rank shares cuda:0).
+    n_visible = torch.cuda.device_count()
+    rank_on_node = local_rank
+    local_rank = local_rank % max(n_visible, 1) if (n_visible == 1 or not one_gpu_test) else 0   # from here on: the HIP ordinal inside this process (torch's and libkyhip's alike)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm = {"backend": None, "world": 1}
     if world > 1:
         import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -357,19 +402,32 @@ def main():
             tdist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI; never executed on hardware so far
+        comm = {"backend": tdist.get_backend(), "world": tdist.get_world_size()}   # what the communicator itself reports
+    # which physical device each rank renders on (rank 0 prints the list: two ranks on one GPU would show here, not in the rate)
+    props0 = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "local_rank": rank_on_node, "hip_ordinal": local_rank, "visible_devices": n_visible,
+          "mask": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES"),
+          "name": props0.name, "pci_bus_id": getattr(props0, "pci_bus_id", None), "pci_device_id": getattr(props0, "pci_device_id", None),
+          "uuid": str(getattr(props0, "uuid", "")) or None}
+    ranks = [me]
+    if world > 1:
+        ranks = [None] * world
+        tdist.all_gather_object(ranks, me)
 
     def barrier():
         if world > 1:
             tdist.barrier()
         torch.cuda.synchronize(dev)
 
-    # Launch overlap: with N > 1 every rank renders 1/N of the frame and the per-launch start-up and tail of the persistent kernel
-    # (0.3 ms against 7 ms at N = 8) are what limit scaling, so consecutive frames go to two alternating streams and the next frame's
-    # kernel fills them (ky_amd/dist.py).  At N = 1 the gain is 0.4 % and the overlap would blur rocprofv3's per-kernel durations of
-    # this very command, so the single-GPU line renders on one stream; --pipeline forces it on (projected_scaling measures its effect).
-    pipeline = (world > 1 or args.pipeline) and not args.no_pipeline
+    # Launch overlap: consecutive frames go to two alternating streams, so that the next frame's kernel fills the start-up and the tail of the
+    # current frame's persistent kernel (ky_amd/dist.py): 0.3 ms per launch, which is 0.4 % of a frame at N = 1 and 5 % of a 1/8 shard.  Round 5: the
+    # SAME mode at every N (rounds 3-4 pipelined only N > 1, which would have credited a scaling curve with overlap N = 1 was denied: VERDICT round 4),
+    # and the line carries both rates -- `value` (pipelined, the default) and `single_frame` (every frame on one stream, nothing overlapped).
+    # --no-pipeline makes `value` itself the single-frame rate: what the profiling commands use (tools/final_profiles.sh), so that rocprofv3's
+    # per-kernel durations are those of kernels that have the chip to themselves.
+    pipeline = not args.no_pipeline
 
-    def run_workload(wargs, steps, warmup, record_in_timed=False):
+    def run_workload(wargs, steps, warmup, record_in_timed=False, pipeline=pipeline):
         """-> dict(frames, name, elapsed, kernel_ms per frame, film_mean): `warmup` untimed and `steps` timed steps of the workload, then an
         untimed pass that reads every frame's kernel duration (HIP events recorded by the library around render_kernel only).
         record_in_timed (the 25-second stress frame): the timed steps themselves read the kernel durations, nothing is rendered twice."""
@@ -413,6 +471,10 @@ def main():
 
     R = run_workload(args, args.steps, args.warmup)
     frames, name, elapsed, frame_kernel_ms = R["frames"], R["name"], R["elapsed"], R["kernel_ms"]
+    # the same K steps with nothing overlapped (skipped for the 20-second stress frame, where a launch's start-up and tail are 1e-5 of it)
+    R1 = None
+    if pipeline and frames[0].samples <= 2e10:
+        R1 = run_workload(args, args.steps, 1, pipeline=False)
 
     if rank == 0:
         samples_per_step = sum(fr.samples for fr in frames)
@@ -470,23 +532,45 @@ def main():
                 for k in ("lane_slot_frac", "issue_frac_2clk", "issue_frac_ubench", "issue_frac_mix_model", "lane_occupancy", "wave_instr_per_sample", "ns_per_valu_per_simd"):
                     valu[k] = None
                 traffic = None
+        # What ran: executed active lane-instructions per camera sample from the kernel's own counters (SQ_INSTS_VALU x 64 x lane occupancy), available when
+        # profiles/valu.json describes the loaded kernels on this very workload.  `lane_slot_frac` prices them against the same peak over the LIVE kernel time; the
+        # model's useful work must not exceed them (it is a floor: VERDICT round 4) -- if it ever does, the line says so and `frac` falls back to what ran.
+        executed_per_sample = lane_slot_frac = None
+        exceeds = None
+        if valu and not valu.get("stale") and key == args.workload and valu.get("wave_instr_per_sample") and valu.get("lane_occupancy"):
+            executed_per_sample = valu["wave_instr_per_sample"] * 64.0 * valu["lane_occupancy"]
+            lane_slot_frac = executed_per_sample * (samples_per_step / world) / (kernel_total_ms * 1e-3) / 1e12 / peak_tlaneops
+            if model_ops is not None:
+                exceeds = bool(model_ops / (samples_per_step / world) > executed_per_sample)
+        frac = (model_achieved / peak_tlaneops) if model_achieved is not None else None
+        if exceeds:
+            frac, model_achieved = lane_slot_frac, lane_slot_frac * peak_tlaneops
         line = {
             "metric": "Msamples/s (paths*spp)", "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "launch_mode": "pipelined (consecutive frames on two streams)" if pipeline else "single frame (one stream, nothing overlapped)",
+            "single_frame": ({"value": samples_per_step * args.steps / R1["elapsed"] / 1e6, "unit": "Msamples/s", "ms_per_step": R1["elapsed"] / args.steps * 1e3,
+                              "steps": args.steps, "note": "the same steps with every frame on one stream: no overlap of a frame's start with the previous frame's tail"}
+                             if R1 else ({"value": value, "unit": "Msamples/s", "ms_per_step": ms_per_step, "steps": args.steps} if not pipeline else None)),
+            "ranks": ranks, "communicator": comm,
             "config": {"workload": name, "frames": [fr.label for fr in frames], "width": p0.width, "height": p0.height, "spp": p0.samples_per_pixel,
                        "max_path_depth": p0.max_path_depth, "direct_sample": {0: "idle", 4: "bsdf", 8: "light", 16: "bsdf_mis", 32: "light_mis", 48: "both_mis"}[p0.direct_sample],
                        "integrator": {6: "direct_lighting", 8: "simple_path_tracing_recursion", 9: "path_tracing_recursion", 10: "path_tracing_recursion_defered", 11: "path_tracing_iteration"}[args.integrator],
                        "seed": p0.seed, "tile": [p0.tile_w, p0.tile_h],
                        "parallelism": "image tiles interleaved over %d GPU(s), one film-tile gather per frame; launches %s" % (world, "pipelined on two streams" if pipeline else "on one stream")},
             # The kernel keeps all path state in registers and LDS and is bound by VALU issue, so the roofline that bounds it is lane-slots:
-            # `achieved` = USEFUL lane-instructions (the algorithm's event counts x the cheapest instruction sequences, `valu_model`) over the kernel
-            # time measured live with HIP events; `peak` = CUs x 4 SIMDs x 32 lanes per clock x the maximum engine clock; `frac` <= 1 unless the
-            # kernel does less work than the reference's algorithm counts.  `contract` keeps SURVEY 8(d)'s figure -- ALGORITHMIC bytes of an HBM
+            # `achieved` = USEFUL lane-instructions (the reference's event counts x the least work that decides each, `valu_model`: a floor under what any
+            # kernel must execute) over the kernel time measured live with HIP events; `peak` = CUs x 4 SIMDs x 32 lanes per clock x the maximum engine
+            # clock; `lane_slot_frac` = the active lane-instructions the kernel really executed (its counters, profiles/valu.json) over the same peak and
+            # time: frac <= lane_slot_frac <= 1, the gap between the two is instructions that do no path arithmetic.  `contract` keeps SURVEY 8(d)'s figure -- ALGORITHMIC bytes of an HBM
             # ray-pool tracer over the same kernel time against 8 TB/s -- which stopped bounding anything at 14.7 Gsamples/s because those bytes
             # never move here; `traffic` is what the memory side really saw (profiled build only); `valu` are the kernel's own utilisation counters.
             "roofline": {"bound": "valu", "achieved": model_achieved, "peak": peak_tlaneops, "unit": "Tlaneop/s (useful fp32 / int32 VALU lane-instructions per second)",
-                         "frac": (model_achieved / peak_tlaneops) if model_achieved is not None else None,
+                         "frac": frac,
+                         "lane_slot_frac": lane_slot_frac, "executed_lane_instr_per_sample": executed_per_sample,
+                         "useful_lane_instr_per_sample": (model_ops / (samples_per_step / world)) if model_ops is not None else None,
+                         "valu_model_exceeds_executed": exceeds,
                          "traffic": traffic, "traffic_source": (valu or {}).get("source") if traffic is not None else None,
                          "kernel": "render_kernel", "kernel_ms": kernel_total_ms, "kernel_ms_per_frame": frame_kernel_ms,
                          "samples_per_launch_set": samples_per_step // world,
@@ -535,9 +619,15 @@ def extra_workloads(args, run_workload, peak_tlaneops, lib, local_rank, kernel_m
         for fr in r["frames"]:
             u = (2 + 11 * 20 + LANE_OP["traversal_setup"] + LANE_OP["vertex"]) if fr.label == "veach_normal_aov" else useful_lane_ops(fr.label, wc)[0]
             ops = None if (ops is None or u is None) else ops + u * fr.samples
+        # what ran (the workload's own counter set of profiles/valu.json, when it describes the loaded kernels) beside the model's floor; a model above it is reported, and capped
+        ex = executed_lane_ops(wl, "%016x" % lib.kyhip_kernel_source_hash())
+        k_s = sum(r["kernel_ms"]) * 1e-3
+        lane_slot = (ex * samples / k_s / 1e12 / peak_tlaneops) if ex is not None else None
+        model_frac = (ops / k_s / 1e12 / peak_tlaneops) if ops is not None else None
+        exceeds = bool(model_frac > lane_slot) if (model_frac is not None and lane_slot is not None) else None
         out[wl] = {"workload": r["name"], "value": samples / r["elapsed"] / 1e6, "unit": "Msamples/s", "steps": 1, "warmup": warm, "ms_per_step": r["elapsed"] * 1e3,
                    "frames": [fr.label for fr in r["frames"]], "kernel_ms_per_frame": r["kernel_ms"], "kernel_ms": sum(r["kernel_ms"]),
-                   "roofline_frac": (ops / (sum(r["kernel_ms"]) * 1e-3) / 1e12 / peak_tlaneops) if ops is not None else None,
+                   "roofline_frac": lane_slot if exceeds else model_frac, "lane_slot_frac": lane_slot, "valu_model_exceeds_executed": exceeds,
                    "contract_frac": achieved / HBM_PEAK_GBS, "film_mean": r["film_mean"]}
     # configs[1] without the scene-fact instantiations (kyhip_set_specialisation(0): what a scene outside the table of facts gets -- the
     # both_mis kernel that assumes nothing about lights or materials), next to its specialised twin of the headline
@@ -554,7 +644,7 @@ def extra_workloads(args, run_workload, peak_tlaneops, lib, local_rank, kernel_m
         lib.kyhip_set_specialisation(prev)
     # Run-time instantiations (kyhip_set_jit, off by default): the point-light Cornell box on the kernel compiled for ALL of its scene's facts (the table's
     # row knows "one delta light"), and a scene the table has no row for -- the Cornell box lit by its lamp AND the point light, both_mis: the fact-free
-    # kernel in the table, this scene's facts when instantiated (shadow rays inline either way: kyhip.hip, shadow_queue_wanted) -- each against the table's kernel.  (The first launch of an instantiation compiles it: a warm-up step.)
+    # kernel in the table, this scene's facts when instantiated (shadow rays inline either way: ky_pack.cpp, shadow_queue_wanted) -- each against the table's kernel.  (The first launch of an instantiation compiles it: a warm-up step.)
     import torch
     dev = torch.device("cuda", local_rank)
 

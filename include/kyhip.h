@@ -206,11 +206,19 @@ int         kyhip_set_shadow_queue(int mode);
    combination -- with ALL of its scene's facts -- is not in the table gets its own kernel, compiled from the library's embedded source by the
    ROCm compiler (a child process: $KYHIP_HIPCC, default /opt/rocm/bin/hipcc) on first use (a few seconds, blocking that launch; afterwards a
    code object in memory and under $KYHIP_CACHE_DIR, default ~/.cache/kyhip).
-   mode 0 (default; environment variable KYHIP_JIT=1 turns it on): the table only.  The image does not depend on it beyond the last bit of a pixel
-   (like kyhip_set_specialisation).  If no compiler is found or a compile fails, the table's kernel runs and kyhip_jit_status() says why.
+   mode 2 (round 5): the same without the wait -- a missing instantiation is compiled by a background thread while the table's kernel renders, and
+   launches switch to it once it is there; all shards of one kyhip_render_multi call use one kernel.  WHEN a process switches is a matter of timing,
+   and table and own kernel differ in the last bit of a pixel: use mode 1 where frames must be reproducible bit for bit (the ranks of a multi-process
+   job: ky_amd/dist.py refuses mode 2 there).
+   mode 0 (default; environment variable KYHIP_JIT=1 / 2 sets the initial mode): the table only.  The image does not depend on the mode beyond the last
+   bit of a pixel (like kyhip_set_specialisation).  If no compiler is found or a compile fails, the table's kernel runs and kyhip_jit_status() says why
+   (kyhip_jit_failures() counts such compiles: a multi-rank job checks it, because a rank that fell back renders its shards on another kernel).
+   The compiler is started with posix_spawn (argv array, no shell) and an environment without LD_PRELOAD / profiler variables; in a process that
+   is itself being profiled nothing is compiled ("stands down under a profiler").  Processes share the cache directory safely (flock, write-once).
    Returns the previous mode.  A tuning knob, not part of the reference's interface. */
 int         kyhip_set_jit(int mode);
 const char* kyhip_jit_status(void);
+int         kyhip_jit_failures(void);
 /* Host only (no GPU needed): compiles -- or fetches from the cache -- the instantiation named by a C++ expression such as
    "render_kernel<false, 48, false, false, 135, 11, false>" and returns the size of its gfx950 code object, or a negative ky_status. */
 int64_t     kyhip_jit_compile(const char* name_expression);
@@ -293,7 +301,7 @@ int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene,
  */
 float kyhip_kernel_ms(int device);
 /* Which render-kernel instantiation that call launched, e.g. "render_kernel<strategy 48, feat 7, integrator 11>" (the library holds one
-   per direct-lighting strategy, integrator and set of scene facts; kyhip.hip, g_variants).  The string stays valid until the next call
+   per direct-lighting strategy, integrator and set of scene facts; ky_launch.hip, g_variants).  The string stays valid until the next call
    of this function from the same thread.  "" if nothing was launched. */
 const char* kyhip_last_kernel(int device);
 

@@ -95,6 +95,7 @@ KYHIP_SYMBOLS = {
     "kyhip_set_shadow_queue": (C.c_int, [C.c_int]),
     "kyhip_set_jit": (C.c_int, [C.c_int]),
     "kyhip_jit_status": (C.c_char_p, []),
+    "kyhip_jit_failures": (C.c_int, []),
     "kyhip_jit_compile": (C.c_int64, [C.c_char_p]),
     "kyhip_kernel_source_hash": (C.c_uint64, []),
     "kyhip_abi_version": (C.c_int, []),

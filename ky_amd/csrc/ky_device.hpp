@@ -27,7 +27,7 @@
 #include <stdint.h>
 #endif
 
-#include "../../include/kyhip.h"
+#include "ky_scene.hpp"   // DScene and its records, KY_FEAT_*, RenderConst: plain data shared with the host's packing code
 
 #define KY_DEV __device__ __forceinline__
 
@@ -118,172 +118,8 @@ constexpr float K_SHAPE_EPS = 1e-3f;   // shape_t::epsilon, 1093
 constexpr float K_RAY_OFFSET = 1e-2f;  // offset_ray_origin, 616
 constexpr float K_INF = __builtin_huge_valf();
 
-// ---------------------------------------------------------------------------------------------
-// device scene layout (HBM, read-only)
-// ---------------------------------------------------------------------------------------------
-enum : int {  // traversal kinds
-    TK_DISK = KY_SHAPE_DISK,
-    TK_TRIANGLE = KY_SHAPE_TRIANGLE,
-    TK_QUAD = KY_SHAPE_RECTANGLE,  // general (non-parallelogram / non-planar) quad: the reference's edge tests
-    TK_SPHERE = KY_SHAPE_SPHERE,
-    TK_PARALLELOGRAM = 4           // planar parallelogram: plane hit + dual-basis coordinates
-};
-
-// 64-byte traversal record, read with a wave-uniform index (scalar loads):
-//   TK_PARALLELOGRAM  f[0..2] = n, f[3] = n.p0, f[4..6] = a*, f[7] = a*.p1 + 0.5, f[8..10] = b*, f[11] = b*.p1 + 0.5
-//                     where a = p0 - p1, b = p2 - p1 and (a*, b*) is the dual basis in the plane, so that for a point
-//                     h of the plane  h.a* - f[7] = u - 0.5,  h.b* - f[11] = v - 0.5  with h = p1 + u a + v b
-//   TK_SPHERE         f[0..2] = centre, f[3] = radius^2
-//   other kinds       full = index of the DShapeFull record
-struct DSurf {
-    float f[12];
-    int32_t kind;
-    int32_t full;
-    int32_t pad[2];
-};
-
-struct DShapeFull {  // the reference's own shape data (ky_shape)
-    float p[4][3];
-    float n[3];
-    float radius;
-    float radius_sq;
-    int32_t kind;
-    int32_t pad[2];
-};  // 80 B
-
-struct DHit {  // what is needed once the nearest surface is known; gathered per lane from LDS
-    float n[3];  // stored normal, or the sphere centre
-    int32_t kind;
-    int32_t material;
-    int32_t area_light;
-    float fs[3], ft[3];   // planar shapes: frame_t(stored normal)'s s and t (537-541), made once by the host instead of at every vertex (surface_frame below)
-    int32_t pad_h[4];     // 64 B: a per-lane index becomes an LDS address by a shift (24 B cost a v_mul_lo_u32 at each of three look-ups per loop turn)
-};
-static_assert(sizeof(DHit) == 64, "DHit");
-
-struct DMat {  // ky_material, gathered per lane from LDS
-    float c0[3];        // lambert albedo | mirror R | glass R; plastic: Kd / P_diff, the Lambert lobe's albedo (2667)
-    int32_t kind;
-    float c1[3];        // glass T; plastic: cs (n + 2) / (n + 1), the Phong lobe's value / pdf per unit |cos| (bsdf_continue)
-    float eta;          // glass: eta; plastic: 1 / (exponent + 1), the power of the Phong lobe's cos(theta) = u^(1/(n+1)) (2515)
-    float exponent, phong_pdf_norm, p_specular;   // phong_pdf_norm = (exponent + 1) / 2 pi (2549)
-    int32_t exp_flags;  // bit 0: exponent is integral, bit 1: it is odd (sign of pow(negative, n))
-    float cs[3];        // plastic: Ks / P_spec, the Phong lobe's colour (2665)
-    float inv_eta;      // glass: 1 / eta (`eta_i / eta_t` entering, 1977 / 2388: the same float division, done once on the host);
-                        // plastic: (exponent + 2) / 2 pi, the Phong lobe's normalisation (2505)
-};  // 64 B
-
-struct DLight {  // light_t + the shape an area light samples; wave-uniform index
-    float color[3];
-    int32_t kind;
-    float position[3];
-    float world_radius;
-    float direction[3];
-    int32_t shape_kind;   // ky_shape_kind of the sampled shape
-    float p1[3];          // rectangle: p1, e0 = p0 - p1, e1 = p2 - p1 (1310); triangle: p0, p1, p2; sphere / disk: centre
-    float radius;
-    float e0[3];
-    float area;
-    float e1[3];
-    float inv_area;
-    float n[3];           // stored normal
-    int32_t n_carriers;   // surfaces whose surface_t::area_light is this light (sorted indices); -1: more than KY_MAX_CARRIERS
-    int32_t carrier[4];
-    int32_t sampled_is_surface;   // the shape this light samples is also the shape of some surface of the scene (so it occludes)
-    int32_t occ_ok;               // shadow rays towards samples of this light may use DScene::occ
-    int32_t pdf_from_carrier;     // the light samples a planar shape and its ONE carrier surface has that very shape: pdf_direction's re-intersection of the light's
-                                  // shape with isect.spawn_ray(wi) (1057-1061) IS the BSDF-sampling estimator's carrier hit -- same ray, same record, same arithmetic
-    int32_t pad_l;
-    DSurf isect;          // traversal record of the sampled shape (pdf_direction re-intersects it, 1057-1061)
-};
-constexpr int KY_MAX_CARRIERS = 4;
-
-struct DPar {  // planar parallelogram, 48 B: q0 = (n, n.p0), q1 = (a*, a*.p1 + 0.5), q2 = (b*, b*.p1 + 0.5)
-    float4 q0, q1, q2;
-};
-struct DSph {  // sphere, 16 B: centre, radius^2
-    float4 c;
-};
-// axis-aligned rectangle in the plane x_axis = c, 32 B.  With (u, v) = the other two axes in cyclic order and [lo, hi] the
-// rectangle's extent along them: q0 = (c, mu, ru, mv), q1.x = rv with m = (lo + hi) / 2, r = (hi - lo) / 2: a point h of
-// the plane is inside iff |h_u - mu| <= ru and |h_v - mv| <= rv (borders inclusive, like the parallelogram test; each
-// test is one subtract and one compare with a single scalar operand).
-struct DAar {
-    float4 q0, q1;
-};
-
-// The surfaces are stored SORTED BY TRAVERSAL KIND -- axis-aligned rectangles (x, y, z planes), other parallelograms, then
-// spheres, then everything else -- keeping the
-// reference's surface order inside each group, so that each traversal loop is branch-free.  `hit[]` and every surface
-// index used on the device are in this sorted order; orig[] maps back to the caller's surface index.  (Ties: the
-// reference's "first surface in list order wins an exactly equal distance" (3177-3180) is preserved inside a group;
-// an exact tie between shapes of different kinds has measure zero.)
-struct DTrav {   // the planar part of a traversal table: axis-aligned rectangles grouped by axis (x, y, z planes), then other parallelograms
-    int32_t n_aar, n_par, pad_t0, pad_t1;   // n_aar = n_aar_axis[0] + [1] + [2]
-    int32_t n_aar_axis[3], pad_t2;
-    DAar aar[KYHIP_MAX_SURFACES + 1];   // one readable record past the end: the traversal reads i + 1
-    DPar par[KYHIP_MAX_SURFACES + 1];
-};
-struct DScene {
-    int32_t n_surfaces, n_lights, n_materials, env_light;
-    int32_t n_sph, n_gen, general, occ_deferred_ok;   // general: SceneRef::general; occ_deferred_ok: shadow rays towards every light may use `occ`
-    float cam_position[3], cam_inv_w;
-    float cam_front[3], cam_inv_h;
-    float cam_right[3], pad0;
-    float cam_up[3], pad1;
-    DTrav trav;                         // every planar surface; its order is the sorted surface order
-    // Occluder tables (host: find_non_occluders, which states the conditions): `trav` without surfaces that provably hold no point of a
-    // shadow ray.
-    //  occ            without the walls of a room: planar surfaces that have the whole scene in one closed half-space of their plane.
-    //                 For rays that end at a scene point (the MIS rays' "is anything in front of the carrier" query) and, when
-    //                 occ_deferred_ok, for the deferred shadow rays of all lights.
-    //                 Shadow rays towards a SAMPLE of light li (by_emitter) use it when DLight::occ_ok: the light keeps clear of every
-    //                 wall's plane by more than the ray origin's offset (never for directional / environment lights).
-    //  Spheres are in none of these tables: they are always tested.
-    DTrav occ;
-    // Two-stage scan for shadow rays towards ONE planar area light (ts_light; -1: none): `occ` split by the plane n.x = k of the light's
-    // sampled shape into occ_front (everything not entirely in n.x <= k, plus the light's own surfaces) and occ_behind (the planar
-    // surfaces entirely in n.x <= k: what is mounted behind a lamp).  A segment has a point in that half-space only if one of its ends
-    // has; such rays overshoot the lamp (quirk 1) and the lamp itself stops nearly all of them, so occ_behind is scanned only for the
-    // few that are left, under a wave-uniform branch.
-    int32_t ts_light, feat, ts_pad[2];   // feat: the KY_FEAT_* facts that hold for this scene (host: pack_scene)
-    float ts_plane[4];
-    DTrav occ_front, occ_behind;
-    DSph sph[KYHIP_MAX_SURFACES + 1];
-    DSurf gen[KYHIP_MAX_SURFACES];
-    DSurf all[KYHIP_MAX_SURFACES];      // every surface as a generic record, sorted order (carrier tests, surface-parallel queries)
-    DShapeFull full[KYHIP_MAX_SURFACES + KYHIP_MAX_LIGHTS];
-    DHit hit[KYHIP_MAX_SURFACES];
-    int32_t orig[KYHIP_MAX_SURFACES];
-    DMat mat[KYHIP_MAX_MATERIALS];
-    DLight light[KYHIP_MAX_LIGHTS];
-};
-
-// How device functions see the scene: the pointer plus one compile-time fact.  `general` = the scene may hold shapes that
-// need the reference's own formulations (quads that are not parallelograms, triangles, disks: full_shape_hit, ~150 VALU and
-// the register peak of the whole kernel).  The hot instantiation of the render kernel is launched only for scenes without
-// them (every scene ky ships) and passes `false`, which removes that code; everything else converts from the bare pointer.
-// Compile-time facts about a scene (SceneRef::feat, a mask): what a render-kernel instantiation may assume, and so what code it does
-// not carry.  Code a scene never executes still costs it registers and instruction-cache space; each of these was measured
-// (DESIGN.md 3).  The host computes the scene's facts (pack_scene -> DScene::feat) and launches an instantiation whose assumptions
-// are a subset of them; 0 assumes nothing.
-enum : int {
-    KY_FEAT_SINGLE_AREA = 1,     // the lights are exactly ONE area light, no environment light: no other light kind's code, no environment term, no lights loop
-    KY_FEAT_RECT_LIGHTS = 2,     // every area light samples a rectangle (the Cornell lamp): no sphere / triangle / disk light sampling
-    KY_FEAT_CARRIERS = 4,        // every area light is carried by at most KY_MAX_CARRIERS surfaces and the scene has no general shapes: the
-                                 // BSDF-sampling estimators always take the carrier test, never the full traversal (estimate_by_bsdf)
-    KY_FEAT_SINGLE_DELTA = 8,    // the lights are exactly ONE point or directional light, no environment light: the BSDF-sampling estimators
-                                 // are gone (they return black for a delta light, 3894 / 3977), and with them every area / environment path
-    KY_FEAT_SINGLE_ENV = 16,     // the lights are exactly ONE environment light (which is the scene's environment): no area / delta light code
-    KY_FEAT_SPHERE_LIGHTS = 32,  // every light is an area light that samples a SPHERE and is carried by sphere surfaces only, no environment light (the
-                                 // Veach scene's five): no other light kind's or light shape's code, no dispatch on either per light and vertex
-    KY_FEAT_NO_DELTA = 64,       // no material is a mirror or glass: no delta lobe's code, prev_specular is never set
-    KY_FEAT_SMALL_TABLES = 128   // at most KY_LDS_SURFACES_SMALL surfaces and KY_LDS_MATERIALS_SMALL materials: the per-lane tables' LDS block is 1.1 KB instead of
-                                 // 3.8 (what lets the sphere-lights kernel with its deferred rays' sums fit a seventh workgroup per CU)
-};
-constexpr int KY_FEAT_SINGLE_LIGHT = KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_DELTA | KY_FEAT_SINGLE_ENV;   // any of them: no lights loop
-// (Measured and not kept: "every area light samples a sphere" + "no mirror or glass material" for the Veach scene: 11 fewer spilled
-// registers in the instantiation with deferred shadow rays, no change in time.)
+// How device functions see the scene: the pointer plus the compile-time facts of the instantiation (ky_scene.hpp, KY_FEAT_*; `general`: the scene may
+// hold shapes that need the reference's own formulations, `large`: more than KY_LDS_SURFACES surfaces).
 struct SceneRef {
     const DScene* p;
     bool general;
@@ -308,14 +144,6 @@ struct SceneRef {
     __device__ __forceinline__ bool sphere_lights() const { return (feat & KY_FEAT_SPHERE_LIGHTS) != 0; }
 };
 
-// The per-workgroup LDS copy of the tables that are indexed per lane: hit[n_surfaces], mat[n_materials], light_color[n_lights][4].
-// Two homes.  The standard kernels keep a STATIC block for scenes of up to KY_LDS_SURFACES surfaces and KY_LDS_MATERIALS materials
-// (every scene ky ships has 11-13 and 4-8): its addresses are compile-time constants that fold into the ds_read offsets.  Larger
-// scenes (up to the ABI's KYHIP_MAX_*) run on the LARGE instantiations, which size the block by the scene in dynamic shared memory
-// (lds_scene_bytes() at launch) and pay an add per table access for it -- measured on the kernels that do not need it: Veach -2.2 %,
-// Cornell -0.5 %, which is why they keep the static block.
-constexpr int KY_LDS_SURFACES = 64, KY_LDS_MATERIALS = 32;
-constexpr int KY_LDS_SURFACES_SMALL = 16, KY_LDS_MATERIALS_SMALL = 8;
 struct LdsScene {
     const DHit* hit;
     const DMat* mat;
@@ -329,9 +157,6 @@ struct LdsSceneStaticT {
 };
 using LdsSceneStatic = LdsSceneStaticT<KY_LDS_SURFACES, KY_LDS_MATERIALS>;
 extern __shared__ __attribute__((aligned(16))) unsigned char g_lds_scene[];
-__host__ __device__ inline int lds_scene_mat_offset(int n_surfaces) { return (n_surfaces * (int)sizeof(DHit) + 15) & ~15; }
-__host__ __device__ inline int lds_scene_light_offset(int n_surfaces, int n_materials) { return lds_scene_mat_offset(n_surfaces) + n_materials * (int)sizeof(DMat); }
-__host__ __device__ inline int lds_scene_bytes(int n_surfaces, int n_materials, int n_lights) { return lds_scene_light_offset(n_surfaces, n_materials) + n_lights * 16; }
 
 KY_DEV f3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
 
@@ -383,7 +208,11 @@ struct Sampler {
 KY_DEV uint32_t sampler_pixel_key(uint32_t seed, uint32_t pixel_index) { return mix32(pixel_index ^ mix32(seed)); }  // constant per pixel
 KY_DEV void sampler_start(Sampler& s, uint32_t h, uint32_t sample_index) {
     s.s0 = mix32(h + sample_index * 0x9E3779B9u);
+#ifdef KY_ONE_HASH   // experiment: the second state word from the first and the pixel key, no second hash
+    s.s1 = (__builtin_amdgcn_alignbit(s.s0, s.s0, 16) ^ h) | 1u;
+#else
     s.s1 = mix32((h ^ 0x6A09E667u) + sample_index * 0x85EBCA6Bu) | 1u;
+#endif
 }
 KY_DEV uint32_t rotl32(uint32_t x, int k) { return __builtin_amdgcn_alignbit(x, x, 32 - k); }   // v_alignbit_b32
 // xoroshiro64+ (Blackman / Vigna; a = 26, b = 9, c = 13): eight full-rate VALU instructions per number with the conversion -- a xor, a three-way xor
@@ -471,6 +300,16 @@ KY_DEV bool par_hit(const float4 q0, const float4 q1, const float4 q2, f3 o, f3 
     return (fabsf(u) <= 0.5f) & (fabsf(v) <= 0.5f) & (t > K_SHAPE_EPS) & (t < tmax);
 }
 
+// the same up to the range tests: distance and the hit point's dual-basis coordinates minus one half (hit_update_nearest / hit_update_any test them)
+KY_DEV void par_coords(const float4 q0, const float4 q1, const float4 q2, f3 o, f3 d, float& t, float& u, float& v) {
+    const float den = q0.x * d.x + q0.y * d.y + q0.z * d.z;
+    const float num = q0.w - (q0.x * o.x + q0.y * o.y + q0.z * o.z);   // n.(p0 - o)
+    t = num * rcp(den);
+    const f3 h = o + t * d;
+    u = (h.x * q1.x + h.y * q1.y + h.z * q1.z) - q1.w;
+    v = (h.x * q2.x + h.y * q2.y + h.z * q2.z) - q2.w;
+}
+
 // rectangle_t::intersect (1261-1297) for a rectangle in an axis plane: the plane hit is one subtraction and one multiply
 // by the ray's reciprocal direction, the inside test needs only the two in-plane coordinates (12 VALU instead of 26).
 // A zero direction component gives inf / NaN, which compare false.
@@ -500,11 +339,64 @@ KY_DEV unsigned opaque_off(unsigned off) { asm volatile("" : "+s"(off)); return 
 KY_DEV const DLight& scene_light(SceneRef S, int li) { return scene_at<DLight>(S, opaque_off((unsigned)__builtin_offsetof(DScene, light) + (unsigned)li * (unsigned)sizeof(DLight))); }
 KY_DEV const DSurf& scene_surf(SceneRef S, int i) { return scene_at<DSurf>(S, opaque_off((unsigned)__builtin_offsetof(DScene, all) + (unsigned)i * (unsigned)sizeof(DSurf))); }
 
+// The four range tests of a hit and the update they guard, as a chain of v_cmpx: each compare NARROWS the exec mask to the lanes that passed, the
+// update is two plain moves under what is left (the surface index straight from its SGPR), one s_mov restores the mask.  As C++ (`ok = a & b & c & d;
+// tmax = ok ? t : tmax; best = ok ? i : best`) the compiler writes four v_cmp into SGPR pairs, three s_and_b64, a v_mov for the index and two
+// v_cndmask: one VALU and three SALU instructions more per surface, in loops that run at 0.85 SALU per VALU instruction (the scalar unit retires
+// an instruction per 1.84 ns against 1.1 for the vector unit: ky_amd DESIGN 3, "what bounds the kernel").  `ex` is the mask on entry (wave-uniform control
+// flow inside the scan loops: the same for every surface of a scan).
+#ifndef KY_CMPX
+#define KY_CMPX 1
+#endif
+KY_DEV void hit_update_nearest(unsigned long long ex, float u, float ru, float v, float rv, float t, float& tmax, int& best, int i) {
+    unsigned long long tmp;
+    asm volatile(
+        "v_cmpx_le_f32_e64 %[tmp], |%[u]|, %[ru]\n\t"
+        "v_cmpx_le_f32_e64 %[tmp], |%[v]|, %[rv]\n\t"
+        "v_cmpx_lt_f32_e64 %[tmp], %[eps], %[t]\n\t"
+        "v_cmpx_lt_f32_e64 %[tmp], %[t], %[tmax]\n\t"
+        "v_mov_b32_e32 %[tmax], %[t]\n\t"
+        "v_mov_b32_e32 %[best], %[i]\n\t"
+        "s_mov_b64 exec, %[ex]"
+        : [tmax] "+v"(tmax), [best] "+v"(best), [tmp] "=&s"(tmp)
+        : [u] "v"(u), [ru] "s"(ru), [v] "v"(v), [rv] "s"(rv), [t] "v"(t), [eps] "s"(K_SHAPE_EPS), [i] "s"(i), [ex] "s"(ex));
+}
+KY_DEV void hit_update_any(unsigned long long ex, float u, float ru, float v, float rv, float t, float tmax, unsigned& occ) {
+    unsigned long long tmp;
+    asm volatile(
+        "v_cmpx_le_f32_e64 %[tmp], |%[u]|, %[ru]\n\t"
+        "v_cmpx_le_f32_e64 %[tmp], |%[v]|, %[rv]\n\t"
+        "v_cmpx_lt_f32_e64 %[tmp], %[eps], %[t]\n\t"
+        "v_cmpx_lt_f32_e64 %[tmp], %[t], %[tmax]\n\t"
+        "v_mov_b32_e32 %[occ], 1\n\t"
+        "s_mov_b64 exec, %[ex]"
+        : [occ] "+v"(occ), [tmp] "=&s"(tmp)
+        : [u] "v"(u), [ru] "s"(ru), [v] "v"(v), [rv] "s"(rv), [t] "v"(t), [tmax] "v"(tmax), [eps] "s"(K_SHAPE_EPS), [ex] "s"(ex));
+}
+
 // the axis-aligned rectangles of one axis: records [first, first + n) of the table at byte offset `aar_off`, whose sorted surface indices are the same
 template <int AXIS, bool NEAREST>
-KY_DEV void aar_scan(SceneRef S, unsigned aar_off, int first, int n, f3 o, f3 d, f3 inv_d, float& tmax, int& best, bool& occ) {
+KY_DEV void aar_scan(SceneRef S, unsigned aar_off, int first, int n, f3 o, f3 d, f3 inv_d, float& tmax, int& best, unsigned& occ_v) {
     if (n <= 0) return;
     unsigned off = aar_off + (unsigned)first * (unsigned)sizeof(DAar);
+#if KY_CMPX
+    const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);   // the exec mask here
+    const float oa = AXIS == 0 ? o.x : (AXIS == 1 ? o.y : o.z), ia = AXIS == 0 ? inv_d.x : (AXIS == 1 ? inv_d.y : inv_d.z);
+    const float ou_ = AXIS == 0 ? o.y : (AXIS == 1 ? o.z : o.x), du_ = AXIS == 0 ? d.y : (AXIS == 1 ? d.z : d.x);
+    const float ov_ = AXIS == 0 ? o.z : (AXIS == 1 ? o.x : o.y), dv_ = AXIS == 0 ? d.z : (AXIS == 1 ? d.x : d.y);
+    for (int i = first; i < first + n; ++i) {
+        asm volatile("" : "+s"(off));
+        const DAar& r = scene_at<DAar>(S, off);
+        const float4 q0 = r.q0;
+        const float rv = r.q1.x;
+        const float t = (q0.x - oa) * ia;                 // aar_hit
+        const float u = (ou_ + t * du_) - q0.y;
+        const float v = (ov_ + t * dv_) - q0.w;
+        if (NEAREST) hit_update_nearest(ex, u, q0.z, v, rv, t, tmax, best, i);
+        else hit_update_any(ex, u, q0.z, v, rv, t, tmax, occ_v);
+        off += (unsigned)sizeof(DAar);
+    }
+#else
     for (int i = first; i < first + n; ++i) {
         asm volatile("" : "+s"(off));
         const DAar& r = scene_at<DAar>(S, off);
@@ -516,10 +408,11 @@ KY_DEV void aar_scan(SceneRef S, unsigned aar_off, int first, int n, f3 o, f3 d,
             tmax = ok ? t : tmax;
             best = ok ? i : best;
         } else {
-            occ = occ | ok;
+            occ_v |= ok ? 1u : 0u;
         }
         off += (unsigned)sizeof(DAar);
     }
+#endif
 }
 
 // sphere_t::intersect, 1336-1393.  sqrt of a negative discriminant is NaN, which fails both range tests.
@@ -562,7 +455,7 @@ KY_DEV int trace_nearest(SceneRef S, f3 o, f3 d, float& tmax) {
     const int n_aar = head.x, n_par = head.y, n_sph = S->n_sph, n_gen = S->n_gen;
     if (n_aar > 0) {
         const f3 inv_d = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
-        bool unused = false;
+        unsigned unused = 0;
         const int n0 = axis.x, n1 = axis.y, n2 = axis.z;
         const unsigned aar_off = t_off + (unsigned)__builtin_offsetof(DTrav, aar);
         aar_scan<0, true>(S, aar_off, 0, n0, o, d, inv_d, tmax, best, unused);
@@ -571,13 +464,22 @@ KY_DEV int trace_nearest(SceneRef S, f3 o, f3 d, float& tmax) {
     }
     if (n_par > 0) {
         unsigned off = t_off + (unsigned)__builtin_offsetof(DTrav, par);
+#if KY_CMPX
+        const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
+#endif
         for (int i = 0; i < n_par; ++i) {
             asm volatile("" : "+s"(off));
             const DPar& r = scene_at<DPar>(S, off);
+#if KY_CMPX
+            float t, u, v;
+            par_coords(r.q0, r.q1, r.q2, o, d, t, u, v);
+            hit_update_nearest(ex, u, 0.5f, v, 0.5f, t, tmax, best, n_aar + i);
+#else
             float t;
             const bool ok = par_hit(r.q0, r.q1, r.q2, o, d, tmax, t);
             tmax = ok ? t : tmax;
             best = ok ? n_aar + i : best;
+#endif
             off += (unsigned)sizeof(DPar);
         }
     }
@@ -605,7 +507,7 @@ KY_DEV int trace_nearest(SceneRef S, f3 o, f3 d, float& tmax) {
 // scene_t::occluded's traversal (3193-3195): any hit inside (eps, tmax) occludes.  `T` (wave-uniform): the table of planar surfaces
 // to test -- S->trav (all), or the occluder table when the ray qualifies for it (DScene::occ).
 KY_DEV bool trace_any_planar(SceneRef S, const DTrav& T, f3 o, f3 d, float tmax) {
-    bool occ = false;
+    unsigned occ = 0;   // a lane flag in a VGPR: the scans OR into it (hit_update_any)
     const unsigned t_off = opaque_off(scene_off(S, &T));
     const int4 head = scene_at<int4>(S, t_off), axis = scene_at<int4>(S, t_off + 16u);   // n_aar, n_par; n_aar_axis[3]
     const int n_aar = head.x, n_par = head.y;
@@ -620,15 +522,24 @@ KY_DEV bool trace_any_planar(SceneRef S, const DTrav& T, f3 o, f3 d, float tmax)
     }
     if (n_par > 0) {
         unsigned off = t_off + (unsigned)__builtin_offsetof(DTrav, par);
+#if KY_CMPX
+        const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
+#endif
         for (int i = 0; i < n_par; ++i) {
             asm volatile("" : "+s"(off));
             const DPar& r = scene_at<DPar>(S, off);
+#if KY_CMPX
+            float t, u, v;
+            par_coords(r.q0, r.q1, r.q2, o, d, t, u, v);
+            hit_update_any(ex, u, 0.5f, v, 0.5f, t, tmax, occ);
+#else
             float t;
-            occ = occ | par_hit(r.q0, r.q1, r.q2, o, d, tmax, t);
+            occ |= par_hit(r.q0, r.q1, r.q2, o, d, tmax, t) ? 1u : 0u;
+#endif
             off += (unsigned)sizeof(DPar);
         }
     }
-    return occ;
+    return occ != 0;
 }
 KY_DEV bool trace_any(SceneRef S, const DTrav& T, f3 o, f3 d, float tmax) {
     bool occ = trace_any_planar(S, T, o, d, tmax);
@@ -1144,7 +1055,9 @@ KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0,
         const f3 wi = dv * rsq(d2);
         s.wi = mk3(ok ? wi.x : 0.f, ok ? wi.y : 0.f, ok ? wi.z : 0.f);
         // areal_radiance(light_isect, -wi) with the SAMPLED (stored) normal: one-sided (quirk 5), 2957-2960
-        const bool lit = ok && dot(lnormal, wi) < 0;
+        // (a light whose colour is black -- or not positive -- emits nothing: is_black(Li) ends the estimate in the reference, 3940 / 4045.  The test is on a
+        // wave-uniform value, a scalar compare; without it such a sample would trace its shadow ray and add colour x 0 x k, NaN when k overflows.)
+        const bool lit = ok && dot(lnormal, wi) < 0 && !is_black(ld3(L.color));
         s.lit = lit;
         s.Li = mk3(lit ? L.color[0] : 0.f, lit ? L.color[1] : 0.f, lit ? L.color[2] : 0.f);
     } else if (K.is_delta(L.kind) && L.kind == KY_LIGHT_POINT) {
@@ -1362,7 +1275,7 @@ KY_DEV void estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f
 }
 
 // ---------------------------------------------------------------------------------------------
-// deferred shadow rays (the lane engine's QUEUE instantiation, kyhip.hip)
+// deferred shadow rays (the lane engine's QUEUE instantiation, ky_launch.hip)
 //
 // scene_t::occluded (3187-3201) is the most expensive step of the light-sampling estimators and the one with the fewest
 // lanes that need it: many light samples are dead before it (back side of the light, zero BSDF value -- a Phong lobe away
@@ -1680,12 +1593,6 @@ KY_DEV void path_state_dead(PathState& ps) {
     ps.smp.s0 = any_reg_u(); ps.smp.s1 = any_reg_u(); ps.bounces = (int)any_reg_u(); ps.prev_specular = any_reg_u() != 0;
 }
 
-struct RenderConst {  // wave-uniform launch constants
-    int integrator, max_path_depth, strategy;
-    uint32_t seed;
-    int width, height, spp;
-    float inv_spp;
-};
 
 // KEEP_LO (render_kernel): ps.Lo is not the sample's radiance but the running sum of the lane's pixel chunk -- every contribution of every
 // path of the chunk is added to it, the kernel scales and flushes it once per chunk -- so a new path leaves it alone.

@@ -1,7 +1,7 @@
 /*
  * ky_queue.hpp -- the "queue" engine for path_tracing_iteration_t::Li (ky.cpp:4529-4617).
  *
- * The lane engine (render_kernel in kyhip.hip) walks one path per lane; lanes whose path has ended, whose vertex is a
+ * The lane engine (render_kernel: ky_render.hpp, launched by ky_launch.hip) walks one path per lane; lanes whose path has ended, whose vertex is a
  * delta lobe or whose light sample is dead idle through the phases they do not need (measured lane occupancy 0.60).
  * Here a workgroup keeps the state of QE_SLOTS paths in LDS (SoA) and every path is a small state machine:
  *

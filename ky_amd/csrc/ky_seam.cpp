@@ -1,0 +1,178 @@
+/*
+ * ky_seam.cpp -- the drop-in boundary's host-film calls: kyhip_render / kyhip_render_multi (include/kyhip.h), what stands behind
+ * integrator_t::render(&scene, sampler, &film) (ky.cpp:3689; ky_amd/host/ky.hpp).  Shards of the frame go to the listed devices' own streams
+ * (kyhip_render_tiles_device), the tile buffers are gathered on the first device, one kernel adds them into a device film, and the film comes
+ * home in row bands that a few parked host threads add into the caller's buffer (film_t::add_color, 1586-1590).  HIP runtime calls only: no kernel
+ * is defined here.
+ */
+#include <algorithm>
+#include <vector>
+
+#include "ky_ctx.hpp"
+
+using namespace kyh;
+
+// integrator_t::render on a LIST of devices (the reference spreads the pixel loop over all cores inside render(),
+// ky.cpp:3696-3699).  Shard i of the frame goes to devices[i] on that device's own stream; the tile buffers are gathered on
+// devices[0] (peer copies over xGMI), de-interleaved by one kernel and added into the caller's film.
+//
+// What the call owns besides the kernels is kept per device and reused (SeamBuffers): the gather block and the device film on the root, a
+// PINNED host staging film, the tile buffers of remote shards.  The film comes back in row bands: band b's download is followed by an
+// event, and a few host threads add band b into the caller's film (film_t::add_color, 1586-1590) the moment its event has fired, so the
+// host's pass over the film overlaps the rest of the download.  (Round 3 allocated and freed two device buffers per call, downloaded into
+// pageable memory and added with one scalar loop afterwards: 1-2 ms on a 9.4 MB film, a third of a 64-spp frame.)
+static int seam_reserve(void** p, size_t* have, size_t need, bool pinned) {
+    if (*have >= need) return KY_OK;
+    if (*p) { HIP_TRY(pinned ? hipHostFree(*p) : hipFree(*p)); *p = nullptr; *have = 0; }
+    const size_t bytes = need + need / 4;   // some slack: a caller that alternates frame sizes does not reallocate on every call
+    HIP_TRY(pinned ? hipHostMalloc(p, bytes) : hipMalloc(p, bytes < 16 ? 16 : bytes));
+    *have = bytes;
+    return KY_OK;
+}
+
+extern "C" {
+
+int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene, const ky_render_params* p, float* film_rgb, size_t stride_px) {
+    if (!valid_params(p)) return fail(KY_ERR_INVALID_VALUE, "invalid render params (integrator %d, direct_sample %d)", p ? p->integrator : -1, p ? p->direct_sample : -1);
+    if (!shard_in_range(p)) return fail(KY_ERR_LIMIT, "frame too large for the device's 32-bit work-item and pixel indices (%d x %d, %d spp)", p->width, p->height, p->samples_per_pixel);
+    if (!devices || n_devices < 1 || n_devices > 64) return fail(KY_ERR_INVALID_VALUE, "bad device list");
+    if ((long long)p->tile_step * n_devices > 0x7fffffffLL) return fail(KY_ERR_INVALID_VALUE, "tile_step x devices overflows");
+    if (!film_rgb || stride_px < (size_t)p->width) return fail(KY_ERR_INVALID_VALUE, "bad film arguments");
+    const int root = devices[0];
+    std::vector<ky_render_params> shard(n_devices, *p);
+    std::vector<DeviceCtx*> ctx(n_devices, nullptr);
+    for (int i = 0; i < n_devices; ++i) {
+        shard[i].tile_first = p->tile_first + i * p->tile_step;
+        shard[i].tile_step = p->tile_step * n_devices;
+        const int rc = get_ctx(devices[i], &ctx[i]);
+        if (rc != KY_OK) return rc;
+    }
+    const size_t rank_stride = (size_t)make_shard(&shard[0]).n_pix * 3;   // shard 0 owns the most tiles
+    const size_t film_floats = (size_t)p->width * p->height * 3;
+
+    // The cached buffers of every device of the list belong to this call until it returns: their seam mutexes are taken in ascending
+    // device order (two calls with overlapping lists cannot deadlock), never while a context's enqueue mutex is held.
+    std::vector<int> order(devices, devices + n_devices);
+    std::sort(order.begin(), order.end());
+    order.erase(std::unique(order.begin(), order.end()), order.end());
+    std::vector<std::unique_lock<std::mutex>> seam_locks;
+    for (int d : order) seam_locks.emplace_back(find_ctx(d)->seam.m);
+
+    // buffers: one gather block and the film on the root, the pinned staging film; a tile buffer per remote shard on its device
+    HIP_TRY(hipSetDevice(root));
+    SeamBuffers& sb = ctx[0]->seam;
+    int rcode = seam_reserve(&sb.d_gather, &sb.gather_bytes, rank_stride * n_devices * sizeof(float), false);
+    if (rcode == KY_OK) rcode = seam_reserve(&sb.d_film, &sb.film_bytes, film_floats * sizeof(float), false);
+    if (rcode == KY_OK) rcode = seam_reserve((void**)&sb.h_stage, &sb.stage_bytes, film_floats * sizeof(float), true);
+    if (rcode != KY_OK) return rcode;
+    for (hipEvent_t& e : sb.band)
+        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    float* const d_gather = (float*)sb.d_gather;
+    float* const d_film = (float*)sb.d_film;
+    hipStream_t root_stream = ctx[0]->stream;
+    HIP_TRY(hipMemsetAsync(d_film, 0, film_floats * sizeof(float), root_stream));
+    std::vector<float*> remote(n_devices, nullptr);
+    std::vector<int> remote_slot(n_devices, 0);   // a device listed k times needs k tile buffers
+    std::vector<hipEvent_t> done(n_devices, nullptr);
+    struct EventGuard {
+        std::vector<hipEvent_t>& ev;
+        ~EventGuard() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); }
+    } event_guard{done};
+
+    // 1. every shard is enqueued before anything is waited for: the devices render concurrently.  From here on a failure must not
+    // return before the streams are drained (step 3): shards already launched write into buffers this function uses.
+#define HIP_CHECK_BREAK(expr)                                                                                         \
+    {                                                                                                               \
+        const hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) { rcode = fail(KY_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); break; } \
+    }
+    kyjit::frame_begin();   // asynchronous run-time instantiations (kyhip_set_jit(2)): every shard of this frame renders on the same kernel
+    struct FrameEnd { ~FrameEnd() { kyjit::frame_end(); } } frame_end_guard;
+    for (int i = 0; i < n_devices && rcode == KY_OK; ++i) {
+        float* dst = d_gather + rank_stride * i;
+        if (devices[i] != root) {
+            HIP_CHECK_BREAK(hipSetDevice(devices[i]));
+            SeamBuffers& rb = ctx[i]->seam;
+            int slot = 0;
+            for (int j = 0; j < i; ++j) slot += devices[j] == devices[i];
+            if ((int)rb.d_remote.size() <= slot) { rb.d_remote.resize(slot + 1, nullptr); rb.remote_bytes.resize(slot + 1, 0); }
+            rcode = seam_reserve(&rb.d_remote[slot], &rb.remote_bytes[slot], rank_stride * sizeof(float), false);
+            if (rcode != KY_OK) break;
+            remote[i] = dst = (float*)rb.d_remote[slot];
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, root, devices[i]) == hipSuccess && can) {   // direct xGMI copies; staged otherwise
+                HIP_CHECK_BREAK(hipSetDevice(root));
+                (void)hipDeviceEnablePeerAccess(devices[i], 0);
+                (void)hipGetLastError();   // "already enabled" is not an error here
+            }
+        }
+        rcode = kyhip_render_tiles_device(devices[i], scene, &shard[i], dst, nullptr, 0, ctx[i]->stream);
+        if (rcode != KY_OK) break;
+        if (devices[i] != root) {
+            HIP_CHECK_BREAK(hipSetDevice(devices[i]));
+            HIP_CHECK_BREAK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+            HIP_CHECK_BREAK(hipEventRecord(done[i], ctx[i]->stream));
+        }
+    }
+    // 2. the gather: one peer copy per remote shard, ordered behind that shard's kernels; then one add into the device film
+    for (int once = 0; once < 1 && rcode == KY_OK; ++once) {
+        HIP_CHECK_BREAK(hipSetDevice(root));
+        bool failed = false;
+        for (int i = 0; i < n_devices && !failed; ++i) {
+            if (devices[i] == root) continue;
+            hipError_t e = hipStreamWaitEvent(root_stream, done[i], 0);
+            const size_t bytes = (size_t)make_shard(&shard[i]).n_pix * 3 * sizeof(float);
+            if (e == hipSuccess && bytes) e = hipMemcpyPeerAsync(d_gather + rank_stride * i, root, remote[i], devices[i], bytes, root_stream);
+            if (e != hipSuccess) { rcode = fail(KY_ERR_DEVICE, "gathering shard %d failed: %s", i, hipGetErrorString(e)); failed = true; }
+        }
+        if (failed) break;
+        rcode = kyhip_film_add_gathered_device(root, p, n_devices, d_gather, rank_stride, d_film, (size_t)p->width, root_stream);
+    }
+    // 3. the film comes home in row bands, each followed by an event
+    const size_t row_bytes = (size_t)p->width * 3 * sizeof(float);
+    int n_bands = (int)std::min<size_t>(KY_SEAM_BANDS, std::max<size_t>(1, film_floats * sizeof(float) / (512u << 10)));   // bands of at least 512 KB
+    n_bands = std::min(n_bands, p->height);
+    auto band_row = [&](int b) { return (int)((long long)p->height * b / n_bands); };
+    int bands_enqueued = 0;
+    for (int b = 0; b < n_bands && rcode == KY_OK; ++b) {
+        const int y0 = band_row(b), y1 = band_row(b + 1);
+        HIP_CHECK_BREAK(hipMemcpyAsync(sb.h_stage + (size_t)y0 * p->width * 3, d_film + (size_t)y0 * p->width * 3, (size_t)(y1 - y0) * row_bytes, hipMemcpyDeviceToHost, root_stream));
+        HIP_CHECK_BREAK(hipEventRecord(sb.band[b], root_stream));
+        bands_enqueued = b + 1;
+    }
+#undef HIP_CHECK_BREAK
+    // 4. host threads add the bands as they arrive: film_t::add_color, 1586-1590.  Every thread works on its slice of the rows of EVERY band (a band is
+    // waited for once, by the thread that gets to it first under the band's flag), so the threads are all busy from the first band on.
+    hipError_t sync_err = hipSuccess;
+    if (rcode == KY_OK && bands_enqueued == n_bands) {
+        const int n_threads = std::max(1, std::min({p->height, cpus_granted(), (int)KY_SEAM_THREADS}));
+        std::vector<hipError_t> errs(n_threads, hipSuccess);
+        auto work = [&](int t) {
+            for (int b = 0; b < n_bands; ++b) {
+                const hipError_t e = hipEventSynchronize(sb.band[b]);   // (returns at once for a band that has arrived)
+                if (e != hipSuccess) { errs[t] = e; return; }
+                const int y0 = band_row(b), y1 = band_row(b + 1);
+                const int r0 = y0 + (int)((long long)(y1 - y0) * t / n_threads), r1 = y0 + (int)((long long)(y1 - y0) * (t + 1) / n_threads);
+                host_add_rows(film_rgb, stride_px, sb.h_stage, p->width, r0, r1);
+            }
+        };
+        host_pool().run(n_threads, work);
+        for (hipError_t e : errs) if (e != hipSuccess) sync_err = e;
+    }
+    // 5. every stream that may still use a buffer of this call is drained before the call returns (also on errors)
+    for (int i = 0; i < n_devices; ++i) {
+        if (hipSetDevice(devices[i]) != hipSuccess) continue;
+        const hipError_t e = hipStreamSynchronize(ctx[i]->stream);
+        if (e != hipSuccess) sync_err = e;
+    }
+    (void)hipSetDevice(root);
+    if (rcode != KY_OK) return rcode;
+    if (sync_err != hipSuccess) return fail(KY_ERR_DEVICE, "render failed: %s (the caller's film may hold a part of the frame)", hipGetErrorString(sync_err));
+    return KY_OK;
+}
+
+int kyhip_render(int device, const ky_scene* scene, const ky_render_params* p, float* film_rgb, size_t stride_px) {
+    return kyhip_render_multi(&device, 1, scene, p, film_rgb, stride_px);
+}
+
+}  // extern "C"

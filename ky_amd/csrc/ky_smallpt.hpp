@@ -17,7 +17,7 @@
  * plain loop over path vertices with a running throughput.
  *
  * All arithmetic is fp64 with contraction off (the CPU builds have no FMA), IEEE sqrt and division.
- * Included by kyhip.hip only.
+ * Included by ky_launch.hip only.
  */
 #pragma once
 #include <hip/hip_runtime.h>

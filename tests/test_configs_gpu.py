@@ -237,34 +237,62 @@ def test_gpu_film_to_bmp_with_odd_width(A, api, tmp_path):
     assert len(b) == 54 + 50 * 34 * 3 and int.from_bytes(b[2:6], "little") == 54 + 152 * 34
 
 
+def _bench_line(cmd, env, cwd):
+    import json
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=cwd)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
 def test_bench_two_ranks_on_one_gpu(tmp_path):
     """bench.py's N > 1 path end to end (torch.distributed.run, two ranks, shards -> ONE gather -> one add kernel) on a single
     GPU: KY_BENCH_ONE_GPU=1 puts both ranks on cuda:0 and runs the collective over gloo.  The film must be the one a single rank
-    renders (the JSON line carries its mean), and the line must keep the contract's fields."""
-    import json
+    renders (the JSON line carries its mean), and the line must keep the contract's fields.  Round 5: the launch mode is the SAME at every N
+    (pipelined by default, --no-pipeline for the single-frame rate), both rates are in the line, and so is which device each rank used."""
     import sys
     env = dict(os.environ, KY_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
     args = ["--steps", "2", "--warmup", "1", "--workload", "batch", "--spp", "16", "--width", "256", "--no-cpu-baseline"]
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, cwd=tmp_path, check=True)
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(29700 + os.getpid() % 200), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args,
-                         capture_output=True, text=True, env=env, cwd=tmp_path, check=True)
-    piped = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pipeline"] + args, capture_output=True, text=True, env=env, cwd=tmp_path, check=True)
-    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
-    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
-    j3 = json.loads([l for l in piped.stdout.splitlines() if l.startswith("{")][-1])
+    bench = os.path.join(ROOT, "bench.py")
+    torchrun = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(29700 + os.getpid() % 200), bench, "--gpus", "2"]
+    j1 = _bench_line([sys.executable, bench] + args, env, tmp_path)
+    j2 = _bench_line(torchrun + args, env, tmp_path)
+    j3 = _bench_line([sys.executable, bench, "--no-pipeline"] + args, env, tmp_path)
     assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["scaling"] == "strong"
     assert j1["film_mean"] == j2["film_mean"] and j1["film_mean"] > 0.01
-    # launches pipelined on two streams (the default with N > 1, forced here at N = 1 as well): the same film
-    assert "pipelined" in j2["config"]["parallelism"] and "pipelined" in j3["config"]["parallelism"] and "one stream" in j1["config"]["parallelism"]
+    # one launch mode for every N: pipelined on two streams unless --no-pipeline; the same film either way
+    assert "pipelined" in j2["config"]["parallelism"] and "pipelined" in j1["config"]["parallelism"] and "one stream" in j3["config"]["parallelism"]
+    assert j1["launch_mode"].startswith("pipelined") and j2["launch_mode"].startswith("pipelined") and j3["launch_mode"].startswith("single frame")
     assert j3["film_mean"] == j1["film_mean"]
-    for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config", "roofline"):
+    for j in (j1, j2, j3):   # both rates in every line
+        assert j["single_frame"]["value"] > 0 and j["single_frame"]["ms_per_step"] > 0
+    assert j3["single_frame"]["value"] == j3["value"]
+    for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config", "roofline", "ranks", "communicator"):
         assert key in j2
     assert j2["roofline"]["bound"] == "valu" and j2["roofline"]["contract"]["bound"] == "hbm" and len(j2["config"]["frames"]) == 6
+    # who rendered where: one entry per rank, the device each used, what the communicator says about itself
+    assert [r["rank"] for r in j2["ranks"]] == [0, 1] and all(r["hip_ordinal"] == 0 and r["name"] for r in j2["ranks"])
+    assert j2["communicator"] == {"backend": "gloo", "world": 2} and j1["communicator"]["world"] == 1
     # the roofline that bounds: useful lane-instructions over lane-slots, a fraction by construction
     for j in (j1, j2):
         assert 0 < j["roofline"]["frac"] < 1 and abs(j["roofline"]["frac"] - j["roofline"]["achieved"] / j["roofline"]["peak"]) < 1e-12
         assert len(j["roofline"]["valu_model"]["frames"]) == 6
+        assert j["roofline"]["valu_model_exceeds_executed"] in (None, False)
+
+
+def test_bench_two_ranks_with_masked_devices(tmp_path):
+    """The commonest way an 8-GPU launcher starts its ranks: every rank sees ONE device (HIP_VISIBLE_DEVICES), so LOCAL_RANK 1 must not ask for
+    cuda:1.  Here both ranks are masked to the box's only GPU and the collective runs over gloo (KY_BENCH_ONE_GPU keeps RCCL, which wants a device
+    per rank, out of it; the device pick is the code under test: local_rank % device_count)."""
+    import sys
+    env = dict(os.environ, KY_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1", HIP_VISIBLE_DEVICES="0")
+    args = ["--steps", "1", "--warmup", "1", "--workload", "cornell", "--spp", "16", "--width", "256", "--height", "192", "--no-cpu-baseline"]
+    bench = os.path.join(ROOT, "bench.py")
+    j1 = _bench_line([sys.executable, bench] + args, env, tmp_path)
+    j2 = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                      "--master-port", str(29950 + os.getpid() % 40), bench, "--gpus", "2"] + args, env, tmp_path)
+    assert j2["n_gpus"] == 2 and j2["film_mean"] == j1["film_mean"] > 0.01
+    assert [(r["local_rank"], r["hip_ordinal"], r["visible_devices"], r["mask"]) for r in j2["ranks"]] == [(0, 0, 1, "0"), (1, 0, 1, "0")]
 
 
 def test_c2_headline_frame_through_the_cpp_driver(A, api, O, tmp_path):

@@ -10,7 +10,7 @@ for m in re.finditer(r'\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', txt):
 # function line ranges of our sources
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ky_amd", "csrc")
 ranges = {}
-for fn in ("ky_device.hpp", "kyhip.hip", "ky_queue.hpp"):
+for fn in ("ky_device.hpp", "ky_render.hpp", "ky_launch.hip", "ky_queue.hpp"):
     src = open(os.path.join(os.environ.get("KY_SRC_DIR", root), fn)).read().split("\n")
     cur = []
     for i, l in enumerate(src, 1):

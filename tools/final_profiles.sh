@@ -10,15 +10,15 @@ mkdir -p gpurun_out/final
 python3 -c "from ky_amd import _abi as A; print('%016x' % A.load_kyhip().kyhip_kernel_source_hash())" > gpurun_out/final/${P}_kernel_source_hash.txt
 run() {  # tag, bench args...
   T=$1; shift
-  rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${P}_$T -o s -- python3 bench.py --no-cpu-baseline --no-extra "$@" > gpurun_out/final/${P}_${T}_stats.log 2>&1
+  rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${P}_$T -o s -- python3 bench.py --no-cpu-baseline --no-extra --no-pipeline "$@" > gpurun_out/final/${P}_${T}_stats.log 2>&1
   python3 tools/rocprof_summary.py gpurun_out/prof_${P}_$T/s_results.db > gpurun_out/final/${P}_${T}_kernel_stats.txt
   for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $C -d gpurun_out/prof_${P}_${T}_$C -o c -- python3 bench.py --no-cpu-baseline --no-extra "$@" > gpurun_out/final/${P}_${T}_$C.log 2>&1
+    rocprofv3 --kernel-trace --pmc $C -d gpurun_out/prof_${P}_${T}_$C -o c -- python3 bench.py --no-cpu-baseline --no-extra --no-pipeline "$@" > gpurun_out/final/${P}_${T}_$C.log 2>&1
     python3 tools/rocprof_summary.py gpurun_out/prof_${P}_${T}_$C/c_results.db --pmc > gpurun_out/final/${P}_${T}_hbm_$(echo $C | tr A-Z a-z).txt
   done
-  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES -d gpurun_out/prof_${P}_${T}_issue -o i -- python3 bench.py --no-cpu-baseline --no-extra --steps 2 "$@" > gpurun_out/final/${P}_${T}_issue.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES -d gpurun_out/prof_${P}_${T}_issue -o i -- python3 bench.py --no-cpu-baseline --no-extra --no-pipeline --steps 2 "$@" > gpurun_out/final/${P}_${T}_issue.log 2>&1
   python3 tools/rocprof_summary.py gpurun_out/prof_${P}_${T}_issue/i_results.db --pmc > gpurun_out/final/${P}_${T}_pmc_sq_issue.txt
-  rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS -d gpurun_out/prof_${P}_${T}_mix -o m -- python3 bench.py --no-cpu-baseline --no-extra --steps 2 "$@" > gpurun_out/final/${P}_${T}_mix.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS -d gpurun_out/prof_${P}_${T}_mix -o m -- python3 bench.py --no-cpu-baseline --no-extra --no-pipeline --steps 2 "$@" > gpurun_out/final/${P}_${T}_mix.log 2>&1
   python3 tools/rocprof_summary.py gpurun_out/prof_${P}_${T}_mix/m_results.db --pmc > gpurun_out/final/${P}_${T}_pmc_sq_mix.txt
 }
 run cornell --workload cornell

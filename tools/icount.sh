@@ -6,7 +6,7 @@ CNT="SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WA
 for v in "$@"; do
   for wl in "cornell" "veach --spp 512"; do
     T=${v}_$(echo $wl | cut -d' ' -f1)
-    KYHIP_LIB=$PWD/build_variants/$v.so rocprofv3 --kernel-trace --pmc $CNT -d gpurun_out/ic_$T -o c -- python3 bench.py --no-cpu-baseline --no-extra --steps 2 --warmup 1 --workload $wl > gpurun_out/ic_$T.log 2>&1
+    KYHIP_LIB=$PWD/build_variants/$v.so rocprofv3 --kernel-trace --pmc $CNT -d gpurun_out/ic_$T -o c -- python3 bench.py --no-cpu-baseline --no-extra --no-pipeline --steps 2 --warmup 1 --workload $wl > gpurun_out/ic_$T.log 2>&1
     python3 - "$T" gpurun_out/ic_$T/c_results.db "$wl" <<'PY'
 import sqlite3, sys
 tag, path, wl = sys.argv[1:4]

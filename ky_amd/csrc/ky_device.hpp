@@ -57,6 +57,8 @@ KY_DEV float clamp01f(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 1.f); }
 KY_DEV float any_f() { float x; asm volatile("" : "=v"(x)); return x; }
 KY_DEV float any_reg() { return any_f(); }
 KY_DEV unsigned any_reg_u() { unsigned x; asm volatile("" : "=v"(x)); return x; }
+// (The compiler puts an `s_nop 0` next to every such statement -- its hazard recogniser cannot see inside an inline asm -- 44 per loop turn of the hot kernel.  They are
+// free: round 5 measured one statement with thirteen outputs against thirteen statements at 42.92 against 42.95-42.99 ms on configs[1]; s_nop does not take a scalar-ALU slot.)
 // x^n for x >= 0 (pow(0, n > 0) = 0, pow(x, 0) = 1)
 KY_DEV float pow_nonneg(float x, float n) { return n == 0.f ? 1.f : __builtin_amdgcn_exp2f(n * __builtin_amdgcn_logf(x)); }
 
@@ -80,6 +82,12 @@ KY_DEV float length_sq(f3 a) { return dot(a, a); }
 KY_DEV f3 normalize(f3 a) { return a * rsq(dot(a, a)); }  // vec3_t::normalize, 314
 KY_DEV float max3(f3 a) { return fmaxf(a.x, fmaxf(a.y, a.z)); }
 KY_DEV bool is_black(f3 c) { return (c.x <= 0) && (c.y <= 0) && (c.z <= 0); }  // color_t::is_black, 258
+// the same for a WAVE-UNIFORM colour in memory (a light's), decided on the scalar unit: x <= 0 for a float that is not a NaN is "sign bit set or zero", i.e. its
+// bits as a signed integer are <= 0 (s_cmp_le_i32; there is no scalar float compare on this chip, and as floats the three tests are VALU compares of SGPRs)
+KY_DEV bool is_black_bits(const float* c) {
+    const int* b = (const int*)c;
+    return (b[0] <= 0) & (b[1] <= 0) & (b[2] <= 0);
+}
 
 // One channel of a film sum -> what goes into the 32.32 fixed-point accumulator and into the pixel's flag word, without a branch:
 // NaN, +inf and -inf (or beyond the accumulator's range) set flag bits 1 << ch, 8 << ch, 64 << ch and add nothing.
@@ -204,15 +212,14 @@ KY_DEV uint32_t mix32(uint32_t x) {
 struct Sampler {
     uint32_t s0, s1;
 };
-// the 64-bit key hashed from (seed, pixel, sample) is the state of a xoroshiro64+ stream (s1 is made odd: the all-zero state is excluded)
+// the state of a sample's xoroshiro64+ stream from (seed, pixel, sample) (s1 is made odd: the all-zero state is excluded)
 KY_DEV uint32_t sampler_pixel_key(uint32_t seed, uint32_t pixel_index) { return mix32(pixel_index ^ mix32(seed)); }  // constant per pixel
+// One hash per sample (round 5; two before): the second state word is the first one rotated by half a word, xor the pixel's key, made odd -- three full-rate
+// instructions where the second lowbias32 was nine, two of them slow integer multiplies (configs[1] +0.9 %).  Samples of one pixel differ in s0 by a hash, pixels in the
+// key; two samples share a stream only if both s0 and the pixel key collide, as before.  The oracle defines the stream the same way (oracle/ky_oracle.cpp, start_sample).
 KY_DEV void sampler_start(Sampler& s, uint32_t h, uint32_t sample_index) {
     s.s0 = mix32(h + sample_index * 0x9E3779B9u);
-#ifdef KY_ONE_HASH   // experiment: the second state word from the first and the pixel key, no second hash
     s.s1 = (__builtin_amdgcn_alignbit(s.s0, s.s0, 16) ^ h) | 1u;
-#else
-    s.s1 = mix32((h ^ 0x6A09E667u) + sample_index * 0x85EBCA6Bu) | 1u;
-#endif
 }
 KY_DEV uint32_t rotl32(uint32_t x, int k) { return __builtin_amdgcn_alignbit(x, x, 32 - k); }   // v_alignbit_b32
 // xoroshiro64+ (Blackman / Vigna; a = 26, b = 9, c = 13): eight full-rate VALU instructions per number with the conversion -- a xor, a three-way xor
@@ -384,7 +391,8 @@ KY_DEV void aar_scan(SceneRef S, unsigned aar_off, int first, int n, f3 o, f3 d,
     const float oa = AXIS == 0 ? o.x : (AXIS == 1 ? o.y : o.z), ia = AXIS == 0 ? inv_d.x : (AXIS == 1 ? inv_d.y : inv_d.z);
     const float ou_ = AXIS == 0 ? o.y : (AXIS == 1 ? o.z : o.x), du_ = AXIS == 0 ? d.y : (AXIS == 1 ? d.z : d.x);
     const float ov_ = AXIS == 0 ? o.z : (AXIS == 1 ? o.x : o.y), dv_ = AXIS == 0 ? d.z : (AXIS == 1 ? d.x : d.y);
-    for (int i = first; i < first + n; ++i) {
+    int i = first;
+    for (; i < first + n; ++i) {
         asm volatile("" : "+s"(off));
         const DAar& r = scene_at<DAar>(S, off);
         const float4 q0 = r.q0;
@@ -1156,19 +1164,31 @@ KY_DEV void estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f
         // (a) nearest carrier surface along the ray, and what it emits towards the ray (3084, 2957-2960)
         t_l = K_INF;
         int c = -1;
+        bool pending;
+        // every carrier carries THIS light (surface_t::area_light == &light, 3994): what it emits is the light's radiance, on the side its
+        // normal faces (areal_radiance, 2957-2960) -- a wave-uniform colour, no per-lane look-up
+        Li = ld3(L.color);
+        if (S.feat & KY_FEAT_OWN_CARRIER) {
+            // the one carrier IS the sampled parallelogram: its traversal record sits in the light's own record.  A rectangle reports the normal that faces the ray
+            // (1289), so it emits towards every ray that hits it (dot(n, wi) = 0 is no hit: the plane test divides by it).
+            const DSurf& R = L.isect;
+            float t;
+            const bool ok = act & par_hit(make_float4(R.f[0], R.f[1], R.f[2], R.f[3]), make_float4(R.f[4], R.f[5], R.f[6], R.f[7]), make_float4(R.f[8], R.f[9], R.f[10], R.f[11]), o, bs.wi, K_INF, t);
+            t_l = ok ? t : t_l;
+            c = ok ? L.carrier[0] : c;
+            pending = ok && !is_black_bits(L.color);
+        } else {
         for (int k = 0; k < L.n_carriers; ++k) {
             float t;
             const bool ok = act & surf_hit(scene_surf(S, L.carrier[k]), S->full, o, bs.wi, t_l, t, S.general, S.sphere_lights());
             t_l = ok ? t : t_l;
             c = ok ? L.carrier[k] : c;
         }
-        // every carrier carries THIS light (surface_t::area_light == &light, 3994): what it emits is the light's radiance, on the side its
-        // normal faces (areal_radiance, 2957-2960) -- a wave-uniform colour, no per-lane look-up
-        Li = ld3(L.color);
-        bool pending = c >= 0 && !is_black(Li);
+        pending = c >= 0 && !is_black(Li);
         if (pending) {
             const f3 hp = o + t_l * bs.wi;
             pending = dot(hit_normal(Lds.hit[c], hp, bs.wi), bs.wi) < 0;
+        }
         }
         if (pending) {  // rare: now the sample's value and pdf (3979-3987)
             float abs_cos_i;

@@ -270,9 +270,7 @@ static const Variant g_variants[] = {
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES, IT),
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, KY_FEAT_VEACH, IT),
     KY_VARIANT(false, -1, false, false, 0, IT),
-};
-static const Variant g_variants_all_unused[] = {
-#endif
+#else
     // the iterative integrator, both_mis: by scene facts
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES, IT),   // one rectangle area light, at most 16 surfaces and 8 materials: configs[1], [4]
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL, IT),                  // one rectangle area light
@@ -322,6 +320,7 @@ static const Variant g_variants_all_unused[] = {
     // scenes beyond the static LDS block (more than 64 surfaces or 32 materials): the run-time-dispatched kernels with a scene-sized block
     KY_VARIANT_LARGE(false, -1, false, true, 0, IT),
     KY_VARIANT_LARGE(true, -1, false, true, 0, IT),
+#endif
 };
 constexpr int KY_N_VARIANTS = (int)(sizeof g_variants / sizeof g_variants[0]);
 static_assert(KY_N_VARIANTS <= 48, "DeviceCtx::variant_blocks");

@@ -549,6 +549,10 @@ int pack_scene(const ky_scene* in, DScene* out) {
         for (int i = 0; i < in->light_count; ++i)
             if (in->lights[i].kind == KY_LIGHT_AREA && out->light[i].n_carriers < 0) carriers = false;
         if (carriers) out->feat |= KY_FEAT_CARRIERS;
+        bool own = true, any_area = false;   // KY_FEAT_OWN_CARRIER: there are area lights, and each is its own (planar) carrier
+        for (int i = 0; i < in->light_count; ++i)
+            if (in->lights[i].kind == KY_LIGHT_AREA) { any_area = true; own = own && out->light[i].pdf_from_carrier != 0; }
+        if (carriers && any_area && own) out->feat |= KY_FEAT_OWN_CARRIER;
     }
     return KY_OK;
 }

@@ -49,7 +49,7 @@ using namespace kyd;
 #define KY_WAVES_PER_EU_GENERIC 5   // strategy / integrator read at run time: more code alive at once, 96 VGPRs measured best
 #endif
 
-constexpr int KY_FEAT_CORNELL = KY_FEAT_SINGLE_AREA | KY_FEAT_RECT_LIGHTS | KY_FEAT_CARRIERS;   // what the Cornell-lamp instantiation assumes
+constexpr int KY_FEAT_CORNELL = KY_FEAT_SINGLE_AREA | KY_FEAT_RECT_LIGHTS | KY_FEAT_CARRIERS | KY_FEAT_OWN_CARRIER;   // what the Cornell-lamp instantiations assume (263; with the small tables 391)
 constexpr int KY_FEAT_VEACH = KY_FEAT_SPHERE_LIGHTS | KY_FEAT_CARRIERS | KY_FEAT_NO_DELTA | KY_FEAT_SMALL_TABLES;   // what the sphere-lights instantiations assume (create_mis_scene)
 
 struct ItemSlot {  // one fetched work item, decoded once (wave-uniform) and read per lane

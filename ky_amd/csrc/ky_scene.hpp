@@ -181,6 +181,9 @@ enum : int {
     KY_FEAT_SPHERE_LIGHTS = 32,  // every light is an area light that samples a SPHERE and is carried by sphere surfaces only, no environment light (the
                                  // Veach scene's five): no other light kind's or light shape's code, no dispatch on either per light and vertex
     KY_FEAT_NO_DELTA = 64,       // no material is a mirror or glass: no delta lobe's code, prev_specular is never set
+    KY_FEAT_OWN_CARRIER = 256,   // every area light samples a planar parallelogram and is carried by exactly ONE surface, which has that very shape (a lamp that is its own
+                                 // emitting rectangle: DLight::pdf_from_carrier for every light): the BSDF-sampling estimators test DLight::isect directly -- no carrier
+                                 // list, no dispatch on the carrier's kind, no look-up of its normal (a rectangle seen by a ray emits on both sides, 1289 / 2957)
     KY_FEAT_SMALL_TABLES = 128   // at most KY_LDS_SURFACES_SMALL surfaces and KY_LDS_MATERIALS_SMALL materials: the per-lane tables' LDS block is 1.1 KB instead of
                                  // 3.8 (what lets the sphere-lights kernel with its deferred rays' sums fit a seventh workgroup per CU)
 };

@@ -228,16 +228,16 @@ struct sampler_t {
     const float* tape = nullptr;   // function-level KATs: the next numbers to hand out, instead of the generator's
     int tape_pos = 0;
     // one camera sample = one stream; sampler_t::start_pixel / next_sample (900-908) select it.
-    // The 64-bit key (k0, k1) hashed from (seed, pixel, sample) is the state of a xoroshiro64+ generator (Blackman / Vigna,
-    // a = 26, b = 9, c = 13; k1 is made odd, which excludes the all-zero state), so two samples share a stream only if both
-    // 32-bit halves collide.  (Rounds 1-3: PCG-RXS-M-XS-32.  The reference's own mt19937_64 stream, re-seeded per image row and
+    // (s0, s1) made from (seed, pixel, sample) is the state of a xoroshiro64+ generator (Blackman / Vigna, a = 26, b = 9, c = 13;
+    // s1 is made odd, which excludes the all-zero state): s0 a hash of the pixel's key and the sample index, s1 = rotl(s0, 16) ^ key,
+    // so two samples share a stream only if s0 and the pixel's key both collide.  (Rounds 1-3: PCG-RXS-M-XS-32.  The reference's own mt19937_64 stream, re-seeded per image row and
     // raced on by its plastic material, is reproduced by neither: DESIGN.md "Random numbers".  No committed fixture holds values
     // of this stream: tests/golden/ is reference-produced data and explicit-input KATs.)
     static uint32_t rotl(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
     void start_sample(uint32_t seed, uint32_t pixel_index, uint32_t sample_index) {
         uint32_t h = mix32(pixel_index ^ mix32(seed));
         s0 = mix32(h + sample_index * 0x9E3779B9u);
-        s1 = mix32((h ^ 0x6A09E667u) + sample_index * 0x85EBCA6Bu) | 1u;
+        s1 = (rotl(s0, 16) ^ h) | 1u;   // round 5: one hash per sample (the device's sampler_start, ky_amd/csrc/ky_device.hpp); two before
     }
     float get_float() {                                                                   // 960
         if (tape) return tape[tape_pos++];

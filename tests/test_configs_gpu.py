@@ -351,7 +351,7 @@ def test_specialised_instantiations_change_nothing(A, api, O, table_kernels):
                     assert np.array_equal(on, off), (strategy, depth)
         # round 3: the other single-light facts and the other integrators' own kernels -- which instantiation runs, and that it changes nothing
         W, H = 64, 48
-        for flag, fact in ((A.CB_LIGHT_AREA, "feat 7"), (A.CB_LIGHT_POINT, "feat 8"), (A.CB_LIGHT_DIRECTION, "feat 8"), (A.CB_LIGHT_ENVIRONMENT, "feat 16")):
+        for flag, fact in ((A.CB_LIGHT_AREA, "feat 263"), (A.CB_LIGHT_POINT, "feat 8"), (A.CB_LIGHT_DIRECTION, "feat 8"), (A.CB_LIGHT_ENVIRONMENT, "feat 16")):
             scene = api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | flag, W, H)
             for integrator in (A.INTEGRATOR_PATH_TRACING_ITERATION, A.INTEGRATOR_DIRECT_LIGHTING, A.INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION,
                                A.INTEGRATOR_PATH_TRACING_RECURSION, A.INTEGRATOR_PATH_TRACING_RECURSION_DEFERED):
@@ -365,7 +365,7 @@ def test_specialised_instantiations_change_nothing(A, api, O, table_kernels):
                 assert "integrator %d" % integrator in kernel_on and "strategy 48" in kernel_on, kernel_on
                 if integrator != A.INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION:    # (it samples no lights: one kernel for every scene)
                     # (the iterative integrator's lamp kernel also knows the scene's tables for small: 7 + 128)
-                    assert not table_kernels or (fact if not (flag == A.CB_LIGHT_AREA and integrator == A.INTEGRATOR_PATH_TRACING_ITERATION) else "feat 135") in kernel_on, (kernel_on, fact)
+                    assert not table_kernels or (fact if not (flag == A.CB_LIGHT_AREA and integrator == A.INTEGRATOR_PATH_TRACING_ITERATION) else "feat 391") in kernel_on, (kernel_on, fact)
                 if integrator != A.INTEGRATOR_PATH_TRACING_ITERATION:
                     assert "strategy -1" in kernel_off, kernel_off
                 fin = np.isfinite(on) & np.isfinite(off)
@@ -377,7 +377,7 @@ def test_specialised_instantiations_change_nothing(A, api, O, table_kernels):
         lib.kyhip_set_specialisation(prev)
 
 
-@pytest.mark.parametrize("seed, fact", [(16, "feat 16"), (20, "feat 8"), (34, "feat 7"), (42, "feat 8"), (78, None)])
+@pytest.mark.parametrize("seed, fact", [(16, "feat 16"), (20, "feat 8"), (34, "feat 263"), (42, "feat 8"), (78, None)])
 def test_recursion_look_up_rides_along(seed, fact, A, api, O, table_kernels):
     """path_tracing_recursion_t's emitter look-up at specular vertices (ky.cpp:4341-4349) in that integrator's own instantiations: the
     look-up ray is carried by the light loop's first traversal (ky_device.hpp, RideAlong) -- under an environment light by the BSDF-sampling

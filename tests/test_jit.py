@@ -64,8 +64,8 @@ def test_instantiated_kernels_render_what_the_table_renders(A, api, O, tmp_path,
             break
     cases = [(api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | A.CB_LIGHT_POINT, W, H), api.make_params(W, H, 64), b", 142, "),                    # the table has feat 8 for it; all of the scene's facts: 8 + 2 + 4 + 128
              (api.mis_scene(W, H), api.make_params(W, H, 32, direct_sample=A.DIRECT_LIGHT_MIS), None),                             # in the table: nothing to compile
-             (room, api.make_params(W, H, 64), b"48, false, false, 13"),                                                            # two lights, shadow rays inline, this room's facts (132 or 134)
-             (room, api.make_params(W, H, 64), b"48, true, false, 13"),                                                             # the same with deferred rays (forced: kyhip_set_shadow_queue)
+             (room, api.make_params(W, H, 64), b"48, false, false, "),                                                              # two lights, shadow rays inline, this room's facts (132 / 134; + 256 when its lamps are their own carriers)
+             (room, api.make_params(W, H, 64), b"48, true, false, "),                                                               # the same with deferred rays (forced: kyhip_set_shadow_queue)
              (general_shapes_scene(A, api), api.make_params(48, 40, 64, direct_sample=A.DIRECT_LIGHT_MIS), b"32, "),               # the table: strategy at run time
              (api.cornell_box_scene(A.CB_DEFAULT_SCENE, W, H), api.make_params(W, H, 16, sampler=A.SAMPLER_DEBUG, integrator=A.INTEGRATOR_PATH_TRACING_RECURSION), b"true, 48")]
     prev = lib.kyhip_set_jit(0)

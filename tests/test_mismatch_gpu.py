@@ -78,10 +78,17 @@ def _check_scene(api, O, scene, params, pixels, n, value_tol, max_bad_fraction, 
             assert np.allclose(g_li, g[s], rtol=1e-6, atol=1e-7)          # the trace kernel walks the same path as kat_li
             kind, k = _explain(g_rows, c_rows, g_li, c[s], value_tol, geom_tol_after_phong)
             if kind == "agrees":
-                # every vertex agrees within value_tol and so does the radiance, yet it is off by more than 1e-3: legitimate only
-                # where value_tol is wider than 1e-3, i.e. through a Phong vertex (pow amplifies the rounding of its base by the exponent)
-                assert value_tol > 1e-3 and (c_rows[:, 2] == 3).any(), (x, y, int(s), "mismatching sample without a differing vertex", g[s], c[s])
-                kind = "continuous, within the Phong lobe's pow amplification"
+                # every vertex agrees within value_tol (relative to max(1, value)) and so does the radiance, yet the sample is off by more than 1e-3 OF ITS OWN
+                # VALUE.  Legitimate in two cases.  (a) value_tol is wider than 1e-3: a Phong vertex (pow amplifies the rounding of its base by the exponent).
+                # (b) A sample of small radiance whose path was reflected or refracted by a CURVED specular surface before its last vertex: the ball amplifies
+                # the hit point's rounding 10-50x per bounce (test_differences_on_the_specular_spheres_are_amplified_rounding), the last vertex then sits 1e-5
+                # beside the oracle's, and a light sample seen at a grazing angle changes by 1e-3 of its (tiny) value for that -- found once in 25 600
+                # samples on round 5's streams: pixel (18, 50) sample 254, two bounces off the mirror ball, 2.8e-5 apart at the wall, radiance 0.0059
+                # against 0.0059 + 6e-6.  Such a sample must still agree to value_tol ABSOLUTELY (it did, or the kind would not be "agrees").
+                phong = value_tol > 1e-3 and (c_rows[:, 2] == 3).any()
+                curved_specular = len(c_rows) > 1 and np.isin(c_rows[:-1, 2], (1, 2)).any() and float(np.abs(c[s]).max()) < 0.05
+                assert phong or curved_specular, (x, y, int(s), "mismatching sample without a differing vertex", g[s], c[s])
+                kind = "continuous, within the Phong lobe's pow amplification" if phong else "continuous, a dim sample after a specular bounce (amplified rounding, within value_tol absolutely)"
             kinds[kind] = kinds.get(kind, 0) + 1
     assert bad <= max_bad_fraction * tot, (bad, tot)
     return bad, tot, kinds

@@ -24,10 +24,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
 SAMPLES = {"cornell": 1024 * 768 * 1024, "veach": 1280 * 720 * 1024, "light_mis": 1024 * 768 * 1024, "generic": 1024 * 768 * 1024, "recursion": 1024 * 768 * 1024}
-LABEL = {"cornell": "render_kernel<strategy 48, feat 135 (one rectangle area light, small tables), integrator 11> on BASELINE configs[1] (Cornell 1024x768x1024)",
+LABEL = {"cornell": "render_kernel<strategy 48, feat 391 (one rectangle area light that is its own carrier, small tables), integrator 11> on BASELINE configs[1] (Cornell 1024x768x1024)",
          "veach": "render_kernel<strategy 48, deferred shadow rays, feat 228 (sphere lights, no delta lobes, small tables)> on configs[2]'s scene at 1024 spp (Veach 1280x720)",
          "light_mis": "render_kernel<strategy 32> (the light_mis instantiation) on configs[1]'s scene",
-         "recursion": "render_kernel<strategy 48, feat 7, integrator 9> (path_tracing_recursion_t) on configs[1]'s scene",
+         "recursion": "render_kernel<strategy 48, feat 263, integrator 9> (path_tracing_recursion_t) on configs[1]'s scene",
          "generic": "render_kernel<false,-1> (strategy read at run time; KYHIP_SPECIALISE=0) on configs[1]'s scene with direct_sample light_mis"}
 
 

@@ -445,6 +445,47 @@ KY_DEV bool sph_hit(const float4 c, f3 o, f3 d, float tmax, float& t_out, bool s
     return hit;
 }
 
+// The second half of sph_hit with its update, for the scan loops (KY_CMPX): the candidate root is t0 if it lies beyond the epsilon and t1 otherwise (t0 <= t1:
+// if t0 > eps is too far, so is t1; if t0 <= eps only t1 can count) -- one compare and one select; then the v_cmpx chain of the planar tests.
+// 6 VALU + 1 SALU for the nearest-hit update where four compares, three selects and the index move were 8 + 3; 5 + 1 for the any-hit flag where the lane masks'
+// bookkeeping was 4 + 7.  (A NaN root -- the line misses the sphere -- fails both range tests as before.  The two wait states between a VALU write of VCC and
+// the select that reads it are written out: the compiler's hazard recogniser does not look inside an asm statement.)
+KY_DEV void sph_update_nearest(unsigned long long ex, float neg_b, float discr, float& tmax, int& best, int i) {
+    const float sq = fsqrt(discr);
+    const float t0 = neg_b - sq, t1 = neg_b + sq;
+    unsigned long long tmp;
+    float t;
+    asm volatile(
+        "v_cmp_lt_f32_e32 vcc, %[eps], %[t0]\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e32 %[t], %[t1], %[t0], vcc\n\t"
+        "v_cmpx_lt_f32_e64 %[tmp], %[eps], %[t]\n\t"
+        "v_cmpx_lt_f32_e64 %[tmp], %[t], %[tmax]\n\t"
+        "v_mov_b32_e32 %[tmax], %[t]\n\t"
+        "v_mov_b32_e32 %[best], %[i]\n\t"
+        "s_mov_b64 exec, %[ex]"
+        : [tmax] "+v"(tmax), [best] "+v"(best), [tmp] "=&s"(tmp), [t] "=&v"(t)
+        : [t0] "v"(t0), [t1] "v"(t1), [eps] "s"(K_SHAPE_EPS), [i] "s"(i), [ex] "s"(ex)
+        : "vcc");
+}
+KY_DEV void sph_update_any(unsigned long long ex, float neg_b, float discr, float tmax, unsigned& occ) {
+    const float sq = fsqrt(discr);
+    const float t0 = neg_b - sq, t1 = neg_b + sq;
+    unsigned long long tmp;
+    float t;
+    asm volatile(
+        "v_cmp_lt_f32_e32 vcc, %[eps], %[t0]\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e32 %[t], %[t1], %[t0], vcc\n\t"
+        "v_cmpx_lt_f32_e64 %[tmp], %[eps], %[t]\n\t"
+        "v_cmpx_lt_f32_e64 %[tmp], %[t], %[tmax]\n\t"
+        "v_mov_b32_e32 %[occ], 1\n\t"
+        "s_mov_b64 exec, %[ex]"
+        : [occ] "+v"(occ), [tmp] "=&s"(tmp), [t] "=&v"(t)
+        : [t0] "v"(t0), [t1] "v"(t1), [tmax] "v"(tmax), [eps] "s"(K_SHAPE_EPS), [ex] "s"(ex)
+        : "vcc");
+}
+
 // one shape given as a generic record (KAT entry point, light shapes re-intersected by pdf_direction)
 // `general` false: the caller knows the record is a parallelogram or a sphere (SceneRef::general)
 KY_DEV bool surf_hit(const DSurf& S, const DShapeFull* __restrict__ full, f3 o, f3 d, float tmax, float& t_out, bool general = true, bool sphere_only = false, bool sparse = true) {
@@ -493,6 +534,18 @@ KY_DEV int trace_nearest(SceneRef S, f3 o, f3 d, float& tmax) {
     }
     if (n_sph > 0) {
         unsigned off = scene_off(S, &S->sph[0]);
+#if KY_CMPX
+        const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
+        for (int i = 0; i < n_sph; ++i) {
+            asm volatile("" : "+s"(off));
+            const float4 c = scene_at<DSph>(S, off).c;
+            const f3 oc = mk3(c.x, c.y, c.z) - o;
+            const float neg_b = dot(oc, d);
+            const float discr = neg_b * neg_b - dot(oc, oc) + c.w;
+            if (!S.sphere_lights() || __any(discr >= 0.f)) sph_update_nearest(ex, neg_b, discr, tmax, best, n_aar + n_par + i);   // (sph_hit's `sparse` rule)
+            off += (unsigned)sizeof(DSph);
+        }
+#else
         for (int i = 0; i < n_sph; ++i) {
             asm volatile("" : "+s"(off));
             float t;
@@ -501,6 +554,7 @@ KY_DEV int trace_nearest(SceneRef S, f3 o, f3 d, float& tmax) {
             best = ok ? n_aar + n_par + i : best;
             off += (unsigned)sizeof(DSph);
         }
+#endif
     }
     for (int i = 0; S.general && i < n_gen; ++i) {
         float t;
@@ -555,11 +609,26 @@ KY_DEV bool trace_any(SceneRef S, const DTrav& T, f3 o, f3 d, float tmax) {
     float t;
     if (n_sph > 0) {
         unsigned off = scene_off(S, &S->sph[0]);
+#if KY_CMPX
+        const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
+        unsigned occ_v = 0;
+        for (int i = 0; i < n_sph; ++i) {
+            asm volatile("" : "+s"(off));
+            const float4 c = scene_at<DSph>(S, off).c;
+            const f3 oc = mk3(c.x, c.y, c.z) - o;
+            const float neg_b = dot(oc, d);
+            const float discr = neg_b * neg_b - dot(oc, oc) + c.w;
+            if (!S.sphere_lights() || __any(discr >= 0.f)) sph_update_any(ex, neg_b, discr, tmax, occ_v);
+            off += (unsigned)sizeof(DSph);
+        }
+        occ = occ | (occ_v != 0);
+#else
         for (int i = 0; i < n_sph; ++i) {
             asm volatile("" : "+s"(off));
             occ = occ | sph_hit(scene_at<DSph>(S, off).c, o, d, tmax, t, S.sphere_lights());
             off += (unsigned)sizeof(DSph);
         }
+#endif
     }
     for (int i = 0; S.general && i < n_gen; ++i) occ = occ || full_shape_hit(S->full[S->gen[i].full], o, d, tmax, t);
     return occ;
@@ -956,8 +1025,12 @@ KY_DEV f3 uniform_sphere_sample(float u0, float u1) {  // 761-769
 // shape_t::sample_position x4 (1144, 1225, 1307, 1404); normals are the stored (unit) ones
 KY_DEV void shape_sample_position(const DLight& L, float u0, float u1, f3& position, f3& normal, int feat = 0) {
     if ((feat & KY_FEAT_RECT_LIGHTS) || (!(feat & KY_FEAT_SPHERE_LIGHTS) && L.shape_kind == KY_SHAPE_RECTANGLE)) {
-        position = ld3(L.p1) + ld3(L.e0) * u0 + ld3(L.e1) * u1;
-        normal = ld3(L.n);
+        // p1, e0, e1 and the normal as four 16-byte scalar loads (each is three floats and a fourth word of the record: DLight is laid out in 16-byte groups);
+        // read as twelve floats they were eight loads, x2 + x1 each
+        const float4 P = *reinterpret_cast<const float4*>(L.p1), E0 = *reinterpret_cast<const float4*>(L.e0), E1 = *reinterpret_cast<const float4*>(L.e1),
+                     N = *reinterpret_cast<const float4*>(L.n);
+        position = mk3(P.x, P.y, P.z) + mk3(E0.x, E0.y, E0.z) * u0 + mk3(E1.x, E1.y, E1.z) * u1;
+        normal = mk3(N.x, N.y, N.z);
     } else if ((feat & KY_FEAT_SPHERE_LIGHTS) || L.shape_kind == KY_SHAPE_SPHERE) {
         const f3 dir = uniform_sphere_sample(u0, u1);
         position = ld3(L.p1) + L.radius * dir;
@@ -1065,7 +1138,7 @@ KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0,
         // areal_radiance(light_isect, -wi) with the SAMPLED (stored) normal: one-sided (quirk 5), 2957-2960
         // (a light whose colour is black -- or not positive -- emits nothing: is_black(Li) ends the estimate in the reference, 3940 / 4045.  The test is on a
         // wave-uniform value, a scalar compare; without it such a sample would trace its shadow ray and add colour x 0 x k, NaN when k overflows.)
-        const bool lit = ok && dot(lnormal, wi) < 0 && !is_black(ld3(L.color));
+        const bool lit = ok && dot(lnormal, wi) < 0 && !is_black_bits(L.color);
         s.lit = lit;
         s.Li = mk3(lit ? L.color[0] : 0.f, lit ? L.color[1] : 0.f, lit ? L.color[2] : 0.f);
     } else if (K.is_delta(L.kind) && L.kind == KY_LIGHT_POINT) {
@@ -1438,9 +1511,9 @@ KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, f3 wo, int
 // light-sampling half: by_emitter (3933-3962, MIS=false) and by_emitter_mis (4035-4074, MIS=true)
 // scene_t::occluded for a shadow ray towards a sample of light li (wave-uniform), through the occluder tables that apply to that light
 KY_DEV bool light_sample_occluded(SceneRef S, int li, f3 o, f3 dir, float tmax) {
-    const bool ok = scene_light(S, li).occ_ok != 0;
-    const bool two = li == S->ts_light;
-    bool occ = trace_any(S, two ? S->occ_front : (ok ? S->occ : S->trav), o, dir, tmax);
+    const unsigned tab = (unsigned)scene_light(S, li).shadow_table;   // which table, decided by the host (DLight::shadow_table)
+    const bool two = (tab & 1u) != 0;
+    bool occ = trace_any(S, scene_at<DTrav>(S, tab & ~1u), o, dir, tmax);
     if (two) {   // what is mounted behind the lamp: only a ray with an end in that half-space can meet it (DScene::occ_behind)
         const float4 plane = scene_at<float4>(S, opaque_off((unsigned)__builtin_offsetof(DScene, ts_plane)));
         const f3 pn = mk3(plane.x, plane.y, plane.z);

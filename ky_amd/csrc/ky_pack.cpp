@@ -514,6 +514,8 @@ int pack_scene(const ky_scene* in, DScene* out) {
         cp3(d.color, l.color); cp3(d.position, l.position); cp3(d.direction, l.direction);
         d.kind = l.kind; d.world_radius = l.world_radius; d.shape_kind = -1;
         d.occ_ok = non.light_ok[i];
+        d.shadow_table = (i == non.ts_light) ? ((int32_t)__builtin_offsetof(DScene, occ_front) | 1)
+                                             : (int32_t)(non.light_ok[i] ? __builtin_offsetof(DScene, occ) : __builtin_offsetof(DScene, trav));
         if (l.kind == KY_LIGHT_AREA) {
             if (l.shape < 0 || l.shape >= in->shape_count) return fail(KY_ERR_INVALID_VALUE, "area light %d: shape out of range", i);
             const ky_shape& sh = in->shapes[l.shape];

@@ -95,10 +95,13 @@ struct DLight {  // light_t + the shape an area light samples; wave-uniform inde
     int32_t occ_ok;               // shadow rays towards samples of this light may use DScene::occ
     int32_t pdf_from_carrier;     // the light samples a planar shape and its ONE carrier surface has that very shape: pdf_direction's re-intersection of the light's
                                   // shape with isect.spawn_ray(wi) (1057-1061) IS the BSDF-sampling estimator's carrier hit -- same ray, same record, same arithmetic
-    int32_t pad_l;
+    int32_t shadow_table;         // byte offset (from the scene's base) of the planar table a shadow ray towards a sample of this light scans first -- DScene::occ_front for the
+                                  // two-stage light (bit 0 set: occ_behind follows for rays with an end behind its plane), DScene::occ when occ_ok, DScene::trav otherwise --
+                                  // decided once by the host instead of by three scalar loads and two compares per light sample
     DSurf isect;          // traversal record of the sampled shape (pdf_direction re-intersects it, 1057-1061)
 };
 constexpr int KY_MAX_CARRIERS = 4;
+static_assert(sizeof(DLight) % 16 == 0 && __builtin_offsetof(DLight, p1) % 16 == 0 && __builtin_offsetof(DLight, n) % 16 == 0, "DLight is read in 16-byte groups (shape_sample_position)");
 
 struct DPar {  // planar parallelogram, 48 B: q0 = (n, n.p0), q1 = (a*, a*.p1 + 0.5), q2 = (b*, b*.p1 + 0.5)
     float4 q0, q1, q2;
@@ -160,6 +163,7 @@ struct DScene {
     DMat mat[KYHIP_MAX_MATERIALS];
     DLight light[KYHIP_MAX_LIGHTS];
 };
+static_assert(__builtin_offsetof(DScene, light) % 16 == 0 && __builtin_offsetof(DScene, trav) % 16 == 0, "16-byte scalar loads of light and table records");
 
 
 // How device functions see the scene: the pointer plus one compile-time fact.  `general` = the scene may hold shapes that

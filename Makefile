@@ -58,7 +58,38 @@ build_variants/%: tools/ubench/%.hip
 	@mkdir -p build_variants
 	$(HIPCC) --offload-arch=gfx950 -O2 -Wno-unused-value -o $@ $<
 
+# ---- sanitizers on the CPU build (never on the GPU: the pool has no GPU sanitizers) --------------------------------------------------------
+# The host code that needs no GPU -- ky_pack.cpp (scene packing, occluder proof, HostPool, seam lock order), ky_jit.cpp (code cache, posix_spawn) plus
+# ky_hostcheck.cpp (entry points for them) -- the host mirror's C API (ky.hpp's scene graph) and the oracle, built by g++ with
+# -fsanitize=address,undefined, and the first three again with -fsanitize=thread.  `make sanitize-build` builds them (tests/test_sanitize.py does that
+# on demand and runs its checks in sanitized child processes); `make sanitize` also runs the CPU test suite under the address build and writes
+# profiles/<round>_sanitize_summary.txt (tools/sanitize/run.sh).
+SANDIR   := build/san
+SANFLAGS := -O1 -g -std=c++17 -fPIC -fno-omit-frame-pointer -Wall -Wno-unused-function -D__HIP_PLATFORM_AMD__ -I$(ROCM)/include
+HOSTSAN_SRC := $(CSRC)/ky_pack.cpp $(CSRC)/ky_jit.cpp $(CSRC)/ky_hostcheck.cpp
+$(SANDIR)/libkyhip_host_asan.so: $(HOSTSAN_SRC) $(HOST_HDRS) $(RTC_INC)
+	@mkdir -p $(SANDIR)
+	$(CXX) $(SANFLAGS) -fsanitize=address,undefined -shared -o $@ $(HOSTSAN_SRC) -lpthread
+$(SANDIR)/libkyhip_host_tsan.so: $(HOSTSAN_SRC) $(HOST_HDRS) $(RTC_INC)
+	@mkdir -p $(SANDIR)
+	$(CXX) $(SANFLAGS) -fsanitize=thread -shared -o $@ $(HOSTSAN_SRC) -lpthread
+$(SANDIR)/libkyhost_asan.so: ky_amd/host/ky_capi.cpp ky_amd/host/ky.hpp include/kyhip.h
+	@mkdir -p $(SANDIR)
+	$(CXX) $(SANFLAGS) -fsanitize=address,undefined -shared -o $@ ky_amd/host/ky_capi.cpp -Wl,-z,lazy   # kyhip_render* stay unresolved until called (nothing in the CPU suite renders)
+$(SANDIR)/libkyoracle_asan.so: oracle/ky_oracle.cpp oracle/smallpt_oracle.cpp oracle/smallpt_rewrite_oracle.cpp include/kyhip.h
+	@mkdir -p $(SANDIR)
+	$(CXX) $(SANFLAGS) -ffp-contract=off -fopenmp -Wno-unused-parameter -fsanitize=address,undefined -shared -o $@ oracle/ky_oracle.cpp oracle/smallpt_oracle.cpp oracle/smallpt_rewrite_oracle.cpp
+$(SANDIR)/stress_tsan: tools/sanitize/stress.cpp $(HOSTSAN_SRC) $(HOST_HDRS) $(RTC_INC)
+	@mkdir -p $(SANDIR)
+	$(CXX) $(SANFLAGS) -fsanitize=thread -o $@ tools/sanitize/stress.cpp $(HOSTSAN_SRC) -lpthread
+$(SANDIR)/stress_asan: tools/sanitize/stress.cpp $(HOSTSAN_SRC) $(HOST_HDRS) $(RTC_INC)
+	@mkdir -p $(SANDIR)
+	$(CXX) $(SANFLAGS) -fsanitize=address,undefined -o $@ tools/sanitize/stress.cpp $(HOSTSAN_SRC) -lpthread
+sanitize-build: $(SANDIR)/libkyhip_host_asan.so $(SANDIR)/libkyhip_host_tsan.so $(SANDIR)/libkyhost_asan.so $(SANDIR)/libkyoracle_asan.so $(SANDIR)/stress_tsan $(SANDIR)/stress_asan
+sanitize: sanitize-build
+	bash tools/sanitize/run.sh
+
 clean:
-	rm -rf $(LIBDIR) examples/bin $(RTC_INC) $(OBJDIR)
+	rm -rf $(LIBDIR) examples/bin $(RTC_INC) $(OBJDIR) $(SANDIR)
 	$(MAKE) -C oracle clean
-.PHONY: all oracle examples ubench clean
+.PHONY: all oracle examples ubench clean sanitize sanitize-build

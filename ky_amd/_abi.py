@@ -142,9 +142,31 @@ KYHOST_SYMBOLS = {
 }
 
 
-def _bind(lib, table):
+# KY_SANITIZE=asan (test infrastructure: `make sanitize`, tests/test_sanitize.py): load the sanitizer builds of the HOST-ONLY code under build/san
+# instead of the product libraries -- ky_pack.cpp / ky_jit.cpp as libkyhip_host_asan.so (no kernels, no HIP runtime: every entry point that needs a
+# GPU is simply absent and raises AttributeError when called), the host mirror as libkyhost_asan.so.  The process must have been started with the
+# sanitizer runtime preloaded (tools/sanitize/run.sh).  Never set in production: the product libraries are the only ones that render.
+SANITIZE = os.environ.get("KY_SANITIZE")
+SAN_DIR = os.path.join(REPO_ROOT, "build", "san")
+
+KYHOSTCHECK_SYMBOLS = {   # ky_amd/csrc/ky_hostcheck.cpp: present in the sanitizer builds only
+    "kyhostcheck_pack": (C.c_int, [SP, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "kyhostcheck_chunks": (C.c_int, [C.c_int]),
+    "kyhostcheck_shard": (C.c_longlong, [PP]),
+    "kyhostcheck_add_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "kyhostcheck_seam_stress": (C.c_int, [C.c_int]),
+    "kyhostcheck_jit_stress": (C.c_int, [C.c_int, C.c_int]),
+}
+
+
+def _bind(lib, table, partial=False):
     for name, (res, args) in table.items():
-        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        try:
+            fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        except AttributeError:
+            if partial:
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
     return lib
@@ -191,6 +213,11 @@ def load_hip_runtime():
 def load_kyhip():
     """Load the product library.  Raises if it has not been built: no fallback."""
     global _kyhip
+    if _kyhip is None and SANITIZE:
+        path = os.path.join(SAN_DIR, "libkyhip_host_%s.so" % SANITIZE)
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is missing: `make sanitize-build`")
+        _kyhip = _bind(_bind(C.CDLL(path, mode=C.RTLD_GLOBAL), KYHIP_SYMBOLS, partial=True), KYHOSTCHECK_SYMBOLS)
     if _kyhip is None:
         path = os.environ.get("KYHIP_LIB") or os.path.join(LIB_DIR, "libkyhip.so")  # KYHIP_LIB: A/B builds of the same ABI
         if not os.path.exists(path):
@@ -205,7 +232,7 @@ def load_kyhost():
     global _kyhost
     if _kyhost is None:
         load_kyhip()
-        path = os.path.join(LIB_DIR, "libkyhost.so")
+        path = os.path.join(SAN_DIR, "libkyhost_%s.so" % SANITIZE) if SANITIZE else os.path.join(LIB_DIR, "libkyhost.so")
         if not os.path.exists(path):
             raise ImportError(f"{path} is missing: build it with `make` at the repo root")
         _kyhost = _bind(C.CDLL(path), KYHOST_SYMBOLS)

@@ -12,6 +12,7 @@
 #include <functional>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 #include <sys/types.h>
 
@@ -49,6 +50,10 @@ int pack_scene(const ky_scene* in, DScene* out);
 uint64_t scene_hash(const DScene& s);
 bool scene_input(const ky_scene* in, std::vector<unsigned char>& out, uint64_t& hash);
 
+// ---- the fp64 smallpt kernels' host side ----
+constexpr int KY_SP_MAX_SPHERES = 32;   // == kysp::SP_MAX_SPHERES (ky_launch.hip asserts it)
+int smallpt_check(const ky_smallpt_sphere* spheres, int n, const ky_smallpt_params* p);
+
 // ---- launch policies (each has an environment variable and a kyhip_set_* entry) ----
 bool specialisation_enabled();
 int shadow_queue_mode();
@@ -75,6 +80,9 @@ private:
     unsigned long long generation_ = 0;
 };
 HostPool& host_pool();
+// The seam mutexes of a call's device list, taken in ascending device order whatever order the list names them in (and once per device): two calls with
+// overlapping lists cannot deadlock.  Never called while a context's enqueue mutex is held.
+std::vector<std::unique_lock<std::mutex>> lock_seams(std::vector<std::pair<int, std::mutex*>> by_device);
 }  // namespace kyh
 
 // ---- run-time instantiations: the code cache (ky_jit.cpp) ----

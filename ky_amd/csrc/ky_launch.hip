@@ -35,6 +35,7 @@
 #include "ky_smallpt.hpp"
 
 using namespace kyh;
+static_assert(kyh::KY_SP_MAX_SPHERES == kysp::SP_MAX_SPHERES, "smallpt_check (ky_pack.cpp) and the kernels' LDS table");
 
 // ------------------------------------------------------------------------------------------------
 // kernels
@@ -562,50 +563,9 @@ int kyhip_film_add_gathered_device(int device, const ky_render_params* p, int wo
     return KY_OK;
 }
 
-// ---- smallpt's scene in double precision (ky_smallpt.hpp) ----
-int kyhip_smallpt_scene(ky_smallpt_sphere* out) {
-    if (!out) return fail(KY_ERR_INVALID_VALUE, "null output");
-    struct Row { double rad, p[3], e[3], c[3]; int refl; };
-    static const Row rows[9] = {   // smallpt.cpp:42-52
-        {1e5, {1e5 + 1, 40.8, 81.6}, {0, 0, 0}, {.75, .25, .25}, KY_SP_DIFF},     // Left
-        {1e5, {-1e5 + 99, 40.8, 81.6}, {0, 0, 0}, {.25, .25, .75}, KY_SP_DIFF},   // Rght
-        {1e5, {50, 40.8, 1e5}, {0, 0, 0}, {.75, .75, .75}, KY_SP_DIFF},           // Back
-        {1e5, {50, 40.8, -1e5 + 170}, {0, 0, 0}, {0, 0, 0}, KY_SP_DIFF},          // Frnt
-        {1e5, {50, 1e5, 81.6}, {0, 0, 0}, {.75, .75, .75}, KY_SP_DIFF},           // Botm
-        {1e5, {50, -1e5 + 81.6, 81.6}, {0, 0, 0}, {.75, .75, .75}, KY_SP_DIFF},   // Top
-        {16.5, {27, 16.5, 47}, {0, 0, 0}, {1 * .999, 1 * .999, 1 * .999}, KY_SP_SPEC},   // Mirr
-        {16.5, {73, 16.5, 78}, {0, 0, 0}, {1 * .999, 1 * .999, 1 * .999}, KY_SP_REFR},   // Glas
-        {600, {50, 681.6 - .27, 81.6}, {12, 12, 12}, {0, 0, 0}, KY_SP_DIFF}};     // Lite
-    for (int i = 0; i < 9; ++i) {
-        out[i].rad = rows[i].rad;
-        for (int j = 0; j < 3; ++j) { out[i].p[j] = rows[i].p[j]; out[i].e[j] = rows[i].e[j]; out[i].c[j] = rows[i].c[j]; }
-        out[i].refl = rows[i].refl;
-        out[i].pad_ = 0;
-    }
-    return 9;
-}
-
-int kyhip_smallpt_scene_rewrite(ky_smallpt_sphere* out) {   // smallpt_rewrite.cpp:1201-1211, 1225-1242: z -> -z
-    const int n = kyhip_smallpt_scene(out);
-    if (n < 0) return n;
-    static const double z[9] = {-81.6, -81.6, -1e5, 1e5 - 170, -81.6, -81.6, -47, -78, -81.6};
-    for (int i = 0; i < n; ++i) out[i].p[2] = z[i];
-    return n;
-}
-
-static int smallpt_check(const ky_smallpt_sphere* spheres, int n, const ky_smallpt_params* p) {
-    if (!spheres || !p) return fail(KY_ERR_INVALID_VALUE, "null argument");
-    if (p->variant != KY_SP_VARIANT_SMALLPT && p->variant != KY_SP_VARIANT_REWRITE) return fail(KY_ERR_INVALID_VALUE, "unknown smallpt variant %d", p->variant);
-    if (n <= 0 || n > kysp::SP_MAX_SPHERES) return fail(KY_ERR_INVALID_VALUE, "1..%d spheres", kysp::SP_MAX_SPHERES);
-    if (p->width <= 0 || p->height <= 0 || p->width > 16384 || p->height > 16384 || p->samps <= 0 || p->max_depth < 0)
-        return fail(KY_ERR_INVALID_VALUE, "invalid smallpt params");
-    for (int i = 0; i < n; ++i)
-        if (spheres[i].refl < KY_SP_DIFF || spheres[i].refl > KY_SP_REFR || !(spheres[i].rad > 0)) return fail(KY_ERR_INVALID_VALUE, "sphere %d is invalid", i);
-    return KY_OK;
-}
-
+// ---- smallpt's scene in double precision (ky_smallpt.hpp); the scene tables and the argument check are host code: ky_pack.cpp ----
 int kyhip_smallpt_render(int device, const ky_smallpt_sphere* spheres, int n, const ky_smallpt_params* p, double* image_rgb) {
-    int rcode = smallpt_check(spheres, n, p);
+    int rcode = kyh::smallpt_check(spheres, n, p);
     if (rcode != KY_OK) return rcode;
     if (!image_rgb) return fail(KY_ERR_INVALID_VALUE, "null image");
     DeviceCtx* c = nullptr;
@@ -640,7 +600,7 @@ int kyhip_smallpt_render(int device, const ky_smallpt_sphere* spheres, int n, co
 
 int kyhip_smallpt_kat_radiance(int device, const ky_smallpt_sphere* spheres, int n_spheres, const ky_smallpt_params* p,
                                int x, int y, int sx, int sy, int s0, int n, double* out3) {
-    int rcode = smallpt_check(spheres, n_spheres, p);
+    int rcode = kyh::smallpt_check(spheres, n_spheres, p);
     if (rcode != KY_OK) return rcode;
     if (!out3 || n <= 0 || s0 < 0 || x < 0 || y < 0 || x >= p->width || y >= p->height || (sx | sy) < 0 || sx > 1 || sy > 1)
         return fail(KY_ERR_INVALID_VALUE, "bad KAT arguments");

@@ -425,7 +425,7 @@ int pack_scene(const ky_scene* in, DScene* out) {
         for (int i = 0; i < in->surface_count; ++i) {
             const ky_surface& sf = in->surfaces[i];
             const ky_shape& sh = in->shapes[sf.shape];
-            DAar aar;
+            DAar aar{};
             const int axis = recs[i].kind == TK_PARALLELOGRAM ? axis_aligned_rectangle(sh, &aar) : -1;
             const int group = axis >= 0 ? axis - 3 : (recs[i].kind == TK_PARALLELOGRAM ? 0 : (recs[i].kind == TK_SPHERE ? 1 : 2));
             if (group != pass) continue;
@@ -703,7 +703,27 @@ void HostPool::loop(int id) {
         if (--pending_ == 0) done_.notify_one();
     }
 }
+std::vector<std::unique_lock<std::mutex>> lock_seams(std::vector<std::pair<int, std::mutex*>> by_device) {
+    std::sort(by_device.begin(), by_device.end(), [](const std::pair<int, std::mutex*>& a, const std::pair<int, std::mutex*>& b) { return a.first < b.first; });
+    by_device.erase(std::unique(by_device.begin(), by_device.end(), [](const std::pair<int, std::mutex*>& a, const std::pair<int, std::mutex*>& b) { return a.first == b.first; }), by_device.end());
+    std::vector<std::unique_lock<std::mutex>> locks;
+    locks.reserve(by_device.size());
+    for (auto& d : by_device) locks.emplace_back(*d.second);
+    return locks;
+}
 HostPool& host_pool() { static HostPool* pool = new HostPool; return *pool; }   // never destroyed: no thread joins at process exit
+
+// smallpt's argument check (kyhip_smallpt_render / kyhip_smallpt_kat_radiance)
+int smallpt_check(const ky_smallpt_sphere* spheres, int n, const ky_smallpt_params* p) {
+    if (!spheres || !p) return fail(KY_ERR_INVALID_VALUE, "null argument");
+    if (p->variant != KY_SP_VARIANT_SMALLPT && p->variant != KY_SP_VARIANT_REWRITE) return fail(KY_ERR_INVALID_VALUE, "unknown smallpt variant %d", p->variant);
+    if (n <= 0 || n > KY_SP_MAX_SPHERES) return fail(KY_ERR_INVALID_VALUE, "1..%d spheres", KY_SP_MAX_SPHERES);
+    if (p->width <= 0 || p->height <= 0 || p->width > 16384 || p->height > 16384 || p->samps <= 0 || p->max_depth < 0)
+        return fail(KY_ERR_INVALID_VALUE, "invalid smallpt params");
+    for (int i = 0; i < n; ++i)
+        if (spheres[i].refl < KY_SP_DIFF || spheres[i].refl > KY_SP_REFR || !(spheres[i].rad > 0)) return fail(KY_ERR_INVALID_VALUE, "sphere %d is invalid", i);
+    return KY_OK;
+}
 
 void set_engine_raw(int v) { g_engine = v; }
 void set_specialise_raw(int v) { g_specialise = v; }
@@ -771,6 +791,37 @@ int kyhip_scene_non_occluders(const ky_scene* scene, int light, int* left_out, i
     const DTrav& T = (light < 0 || non.light_ok[light]) ? P.occ : P.trav;
     if (count != P.trav.n_aar + P.trav.n_par - T.n_aar - T.n_par) return fail(KY_ERR_DEVICE, "internal: occluder table and classification disagree");
     return count;
+}
+
+// ---- smallpt's scene in double precision (ky_smallpt.hpp) ----
+int kyhip_smallpt_scene(ky_smallpt_sphere* out) {
+    if (!out) return fail(KY_ERR_INVALID_VALUE, "null output");
+    struct Row { double rad, p[3], e[3], c[3]; int refl; };
+    static const Row rows[9] = {   // smallpt.cpp:42-52
+        {1e5, {1e5 + 1, 40.8, 81.6}, {0, 0, 0}, {.75, .25, .25}, KY_SP_DIFF},     // Left
+        {1e5, {-1e5 + 99, 40.8, 81.6}, {0, 0, 0}, {.25, .25, .75}, KY_SP_DIFF},   // Rght
+        {1e5, {50, 40.8, 1e5}, {0, 0, 0}, {.75, .75, .75}, KY_SP_DIFF},           // Back
+        {1e5, {50, 40.8, -1e5 + 170}, {0, 0, 0}, {0, 0, 0}, KY_SP_DIFF},          // Frnt
+        {1e5, {50, 1e5, 81.6}, {0, 0, 0}, {.75, .75, .75}, KY_SP_DIFF},           // Botm
+        {1e5, {50, -1e5 + 81.6, 81.6}, {0, 0, 0}, {.75, .75, .75}, KY_SP_DIFF},   // Top
+        {16.5, {27, 16.5, 47}, {0, 0, 0}, {1 * .999, 1 * .999, 1 * .999}, KY_SP_SPEC},   // Mirr
+        {16.5, {73, 16.5, 78}, {0, 0, 0}, {1 * .999, 1 * .999, 1 * .999}, KY_SP_REFR},   // Glas
+        {600, {50, 681.6 - .27, 81.6}, {12, 12, 12}, {0, 0, 0}, KY_SP_DIFF}};     // Lite
+    for (int i = 0; i < 9; ++i) {
+        out[i].rad = rows[i].rad;
+        for (int j = 0; j < 3; ++j) { out[i].p[j] = rows[i].p[j]; out[i].e[j] = rows[i].e[j]; out[i].c[j] = rows[i].c[j]; }
+        out[i].refl = rows[i].refl;
+        out[i].pad_ = 0;
+    }
+    return 9;
+}
+
+int kyhip_smallpt_scene_rewrite(ky_smallpt_sphere* out) {   // smallpt_rewrite.cpp:1201-1211, 1225-1242: z -> -z
+    const int n = kyhip_smallpt_scene(out);
+    if (n < 0) return n;
+    static const double z[9] = {-81.6, -81.6, -1e5, 1e5 - 170, -81.6, -81.6, -47, -78, -81.6};
+    for (int i = 0; i < n; ++i) out[i].p[2] = z[i];
+    return n;
 }
 
 }  // extern "C"

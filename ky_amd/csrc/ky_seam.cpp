@@ -52,11 +52,9 @@ int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene,
 
     // The cached buffers of every device of the list belong to this call until it returns: their seam mutexes are taken in ascending
     // device order (two calls with overlapping lists cannot deadlock), never while a context's enqueue mutex is held.
-    std::vector<int> order(devices, devices + n_devices);
-    std::sort(order.begin(), order.end());
-    order.erase(std::unique(order.begin(), order.end()), order.end());
-    std::vector<std::unique_lock<std::mutex>> seam_locks;
-    for (int d : order) seam_locks.emplace_back(find_ctx(d)->seam.m);
+    std::vector<std::pair<int, std::mutex*>> seams;
+    for (int i = 0; i < n_devices; ++i) seams.emplace_back(devices[i], &ctx[i]->seam.m);
+    const std::vector<std::unique_lock<std::mutex>> seam_locks = lock_seams(std::move(seams));
 
     // buffers: one gather block and the film on the root, the pinned staging film; a tile buffer per remote shard on its device
     HIP_TRY(hipSetDevice(root));

@@ -26,7 +26,9 @@ def load():
     global _lib
     if _lib is None:
         path = os.path.join(_HERE, "libkyoracle.so")
-        if not os.path.exists(path):
+        if A.SANITIZE:   # `make sanitize`: the address + undefined-behaviour build of the same sources (build/san)
+            path = os.path.join(A.SAN_DIR, "libkyoracle_%s.so" % A.SANITIZE)
+        elif not os.path.exists(path):
             build()
         _lib = C.CDLL(path)
         _lib.kyo_render.restype = C.c_int

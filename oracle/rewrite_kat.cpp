@@ -10,12 +10,16 @@
 //     SpecularReflection Sample_f              smallpt_rewrite.cpp:907-934   -> ky.cpp perfect_specular_reflection_t 2292-2307
 //     CosineSampleHemisphere's lift            smallpt_rewrite.cpp:259-265   -> ky.cpp cosine_hemisphere_sample 737-745
 //     GammaEncoding                            smallpt_rewrite.cpp:494       -> ky.cpp gamma_encoding 1548
+//     AreaLight::Le through Primitive::Intersect   smallpt_rewrite.cpp:1114-1117, 1135-1146 -> ky.cpp areal_radiance 2957-2960 / 2977 + surface_t::intersect 3077-3088
+//                                              (one-sided: the light's radiance where dot(normal, wo) > 0, black seen from behind / inside)        [round 5]
+//     Scene::Intersect                         smallpt_rewrite.cpp:1184-1197 -> ky.cpp scene_t::intersect 3172-3184: the whole list is scanned, the
+//                                              ray's distance shrinks, a later surface at EXACTLY the same distance does not replace an earlier one     [round 5]
 // Everything is fp64 there and fp32 in ky.cpp; tests/test_rewrite_kat.py compares oracle/ky_oracle.cpp's fp32 restatement (and the
 // HIP path) with these values where ky.cpp kept the formula, and lists where it did not (tests/golden/make_rewrite_kat.py).
 // Built by `make -C oracle ref` into oracle/_ref/rewrite_kat, only where /root/reference exists; run by
 // tests/golden/make_rewrite_kat.py, whose output tests/golden/rewrite_kat.npz is what travels.
 //
-// File format (little-endian): input = int64 counts {n_frame, n_sphere, n_camera_sets, n_bsdf, n_lift, n_gamma} followed by the
+// File format (little-endian): input = int64 counts {n_frame, n_sphere, n_camera_sets, n_bsdf, n_lift, n_gamma, n_le, n_scene_sets} followed by the
 // records as doubles; output = the results as doubles, in the same order.  Record layouts are at each loop.
 #define main smallpt_rewrite_main
 #include "smallpt_rewrite.cpp"   // found through -I$(REF)/smallpt2pbrt: the file is compiled where it lies
@@ -35,8 +39,8 @@ int main(int argc, char** argv) {
     if (argc != 3) { std::fprintf(stderr, "usage: rewrite_kat in.bin out.bin\n"); return 2; }
     FILE* fi = std::fopen(argv[1], "rb");
     if (!fi) return 3;
-    int64_t counts[6];
-    if (std::fread(counts, sizeof(int64_t), 6, fi) != 6) return 4;
+    int64_t counts[8];
+    if (std::fread(counts, sizeof(int64_t), 8, fi) != 8) return 4;
     double d;
     while (std::fread(&d, sizeof d, 1, fi) == 1) g_in.push_back(d);
     std::fclose(fi);
@@ -96,6 +100,57 @@ int main(int argc, char** argv) {
     }
     // GammaEncoding: in {x} -> out {byte}
     for (int64_t i = 0; i < counts[5]; ++i) out.push_back((double)GammaEncoding(next()));
+
+    // AreaLight::Le as a path ray sees it (Primitive::Intersect sets isect.emission = areaLight->Le(isect, isect.wo)): one emitting sphere per row,
+    // rays from outside and from inside.  in {center[3], radius, radiance[3], origin[3], direction[3]} -> out {hit, t, emission[3]}
+    const MatteMaterial black{Color()};
+    for (int64_t i = 0; i < counts[6]; ++i) {
+        const Vector3 c = next3();
+        const double radius = next();
+        const Vector3 L = next3(), o = next3(), dir = next3();
+        const Sphere sphere(radius, c);
+        const AreaLight light(Color(L.x, L.y, L.z), &sphere);
+        const Primitive prim{&sphere, &black, &light};
+        Ray ray(o, dir);
+        Isect isect;
+        const bool hit = prim.Intersect(ray, &isect);
+        out.push_back(hit ? 1.0 : 0.0);
+        out.push_back(hit ? ray.distance : 0.0);
+        const Color e = hit ? isect.Le() : Color();
+        out.push_back(e.x); out.push_back(e.y); out.push_back(e.z);
+    }
+    // Scene::Intersect over a list of spheres (some of them twice: exact ties).  Every primitive carries an area light of radiance (index + 1, 0, 0), so the
+    // emission of the surviving hit names the primitive the scan kept (all origins lie outside every sphere: the nearest hit faces the ray).
+    // per set: in {n_spheres, n_spheres x {center[3], radius}, n_rays, n_rays x {origin[3], direction[3], tmax}} -> out per ray {hit, t, index, position[3]}
+    for (int64_t s = 0; s < counts[7]; ++s) {
+        const int64_t ns = (int64_t)next();
+        std::vector<std::shared_ptr<Shape>> shapes;
+        std::vector<std::shared_ptr<Material>> materials{std::make_shared<MatteMaterial>(Color())};
+        std::vector<std::shared_ptr<Light>> lights;
+        std::vector<std::shared_ptr<AreaLight>> area;
+        std::vector<Primitive> prims;
+        for (int64_t k = 0; k < ns; ++k) {
+            const Vector3 c = next3();
+            const double radius = next();
+            shapes.push_back(std::make_shared<Sphere>(radius, c));
+            area.push_back(std::make_shared<AreaLight>(Color((double)(k + 1), 0, 0), shapes.back().get()));
+            lights.push_back(area.back());
+            prims.push_back(Primitive{shapes.back().get(), materials[0].get(), area.back().get()});
+        }
+        const Scene scene(shapes, materials, lights, prims);
+        const int64_t nr = (int64_t)next();
+        for (int64_t i = 0; i < nr; ++i) {
+            const Vector3 o = next3(), dir = next3();
+            const double tmax = next();
+            Ray ray(o, dir, tmax);
+            Isect isect;
+            const bool hit = scene.Intersect(ray, &isect);
+            out.push_back(hit ? 1.0 : 0.0);
+            out.push_back(hit ? ray.distance : 0.0);
+            out.push_back(hit ? isect.Le().x - 1.0 : -1.0);
+            put3(out, hit ? isect.position : Vector3());
+        }
+    }
 
     FILE* fo = std::fopen(argv[2], "wb");
     if (!fo) return 5;

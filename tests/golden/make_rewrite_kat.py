@@ -20,6 +20,10 @@ Formula by formula (checked against ky.cpp before relying on it):
                                            hemispheres (2232), the rewrite R / pi everywhere: only same-hemisphere rows compare for f
   kept    SpecularReflection::Sample_f     907-934 == 2292-2307
   kept    GammaEncoding                    494 == 1548
+  kept    AreaLight::Le                    1114-1117 == 2957-2960 (areal_radiance: the light's radiance where dot(normal, wo) > 0, else black), reached the way a path
+                                           ray reaches it: Primitive::Intersect 1135-1146 == surface_t::intersect 3077-3088 (round 5)
+  kept    Scene::Intersect                 1184-1197 == 3172-3184: every primitive is tested, ray.distance shrinks, `distance < ray.distance` is strict, so of two
+                                           surfaces at exactly the same distance the EARLIER list entry stays (round 5)
   differs CosineSampleHemisphere           the lift z = sqrt(max(0, 1 - x^2 - y^2)) is shared (259-265 == 737-745) but the disk mapping is
                                            polar there (252-257) and concentric in ky.cpp (710-733): the sampled directions differ
   differs FresnelSpecular                  Schlick's approximation there (1003-1008), the exact dielectric Fresnel in ky.cpp (1963-1996)
@@ -102,8 +106,57 @@ def main():
     lift_in = f32(rng.uniform(size=(256, 2)))
     gamma_in = f32(np.concatenate([rng.uniform(-0.2, 1.2, 1000), np.linspace(0, 1, 513), [0.0, 1.0, 0.5]]))
 
-    counts = np.array([len(frame_in), len(sphere_in), len(cams), len(bsdf_in), len(lift_in), len(gamma_in)], np.int64)
-    payload = np.concatenate([frame_in.ravel(), sphere_in.ravel()] + cam_records + [bsdf_in.ravel(), lift_in.ravel(), gamma_in.ravel()]).astype("<f8")
+    # round 5 (drawn AFTER everything above: the earlier sections of the fixture keep their values).
+    # AreaLight::Le through Primitive::Intersect: one emitting sphere per row; half of the rays start inside it (dot(normal, wo) < 0: black)
+    n_le = 384
+    le_c = rng.uniform(-1, 1, (n_le, 3))
+    le_r = rng.choice([0.5, 0.1, 0.8], n_le)
+    inside = rng.uniform(size=n_le) < 0.5
+    le_o = le_c + np.where(inside[:, None], rng.uniform(0.0, 0.8, (n_le, 1)), rng.uniform(1.3, 4.0, (n_le, 1))) * unit(rng.normal(size=(n_le, 3))) * le_r[:, None]
+    le_target = le_c + rng.uniform(-1.2, 1.2, (n_le, 3)) * le_r[:, None]
+    le_d = f32(unit(f32(le_target - le_o)))
+    le_d = f32(le_d / np.linalg.norm(le_d, axis=1, keepdims=True))
+    le_L = rng.uniform(0.5, 30.0, (n_le, 3))
+    le_in = f32(np.concatenate([le_c, le_r[:, None], le_L, le_o, le_d], 1))
+    c, r, o, d = le_in[:, 0:3], le_in[:, 3], le_in[:, 7:10], le_in[:, 10:13]
+    oc = c - o
+    nb = (oc * d).sum(1)
+    disc = nb * nb - (oc * oc).sum(1) + r * r
+    sq = np.sqrt(np.maximum(disc, 0))
+    le_in = le_in[~(near_eps(nb - sq) | near_eps(nb + sq)) & (np.abs(disc) > 1e-4)]
+    # Scene::Intersect: three lists of spheres; in each, two spheres appear TWICE (bit-identical records at different list positions: exact ties, the
+    # earlier entry must win), and rays start outside every sphere
+    scene_sets, scene_rays = [], []
+    for n_s in (6, 9, 12):
+        cs = rng.uniform(-1.2, 1.2, (n_s - 2, 3))
+        rs = rng.uniform(0.15, 0.5, n_s - 2)
+        spheres = f32(np.concatenate([cs, rs[:, None]], 1))
+        order = list(range(n_s - 2))
+        order.insert(int(rng.integers(1, n_s - 2)), 0)          # sphere 0 again, later in the list
+        order.append(int(rng.integers(1, n_s - 2)))             # another one again, last
+        spheres = spheres[order]
+        n_r = 384
+        ro = 3.0 * unit(rng.normal(size=(n_r, 3))) * rng.uniform(1.0, 1.5, (n_r, 1))
+        rt = spheres[rng.integers(0, n_s, n_r), 0:3] + rng.uniform(-0.6, 0.6, (n_r, 3))
+        rd = f32(unit(f32(rt - ro)))
+        rd = f32(rd / np.linalg.norm(rd, axis=1, keepdims=True))
+        tm = np.where(rng.uniform(size=n_r) < 0.2, rng.uniform(1.0, 4.0, n_r), np.inf)
+        rays = f32(np.concatenate([ro, rd, tm[:, None]], 1))
+        # no root of any sphere near the two sources' epsilons or near tmax, no grazing hit (a flag that fp32 and fp64 could decide differently)
+        ok = np.ones(n_r, bool)
+        for sph in spheres:
+            oc = sph[0:3] - rays[:, 0:3]
+            nb = (oc * rays[:, 3:6]).sum(1)
+            disc = nb * nb - (oc * oc).sum(1) + sph[3] ** 2
+            sq = np.sqrt(np.maximum(disc, 0))
+            ok &= (np.abs(disc) > 1e-3) & ~near_eps(nb - sq) & ~near_eps(nb + sq) & (np.abs(nb - sq - rays[:, 6]) > 1e-3) & (np.abs(nb + sq - rays[:, 6]) > 1e-3)
+        rays = rays[ok]
+        scene_sets.append(spheres)
+        scene_rays.append(rays)
+    scene_records = [np.concatenate([[len(sp)], sp.ravel(), [len(ry)], ry.ravel()]) for sp, ry in zip(scene_sets, scene_rays)]
+
+    counts = np.array([len(frame_in), len(sphere_in), len(cams), len(bsdf_in), len(lift_in), len(gamma_in), len(le_in), len(scene_sets)], np.int64)
+    payload = np.concatenate([frame_in.ravel(), sphere_in.ravel()] + cam_records + [bsdf_in.ravel(), lift_in.ravel(), gamma_in.ravel(), le_in.ravel()] + scene_records).astype("<f8")
     with tempfile.TemporaryDirectory() as tmp:
         fin, fout = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
         with open(fin, "wb") as fh:
@@ -125,15 +178,23 @@ def main():
     bsdf_out = take(len(bsdf_in), 11)
     lift_out = take(len(lift_in), 3)
     gamma_out = take(len(gamma_in), 1)[:, 0]
+    le_out = take(len(le_in), 5)
+    scene_out = [take(len(ry), 6) for ry in scene_rays]
     assert pos == out.size
     path = os.path.join(ROOT, "tests", "golden", "rewrite_kat.npz")
     np.savez_compressed(
         path, frame_in=frame_in.astype(np.float32), frame_out=frame_out, sphere_in=sphere_in.astype(np.float32), sphere_out=sphere_out,
         cam_pfilm=np.stack(cam_pfilm).astype(np.float32), cam_out=np.stack(cam_out), cam_res=np.array([c[4] for c in cams], np.int32),
         bsdf_in=bsdf_in.astype(np.float32), bsdf_out=bsdf_out, lift_in=lift_in.astype(np.float32), lift_out=lift_out,
-        gamma_in=gamma_in.astype(np.float32), gamma_out=gamma_out.astype(np.uint8))
+        gamma_in=gamma_in.astype(np.float32), gamma_out=gamma_out.astype(np.uint8),
+        le_in=le_in.astype(np.float32), le_out=le_out,
+        **{"scene%d_spheres" % i: sp.astype(np.float32) for i, sp in enumerate(scene_sets)},
+        **{"scene%d_rays" % i: ry.astype(np.float32) for i, ry in enumerate(scene_rays)},
+        **{"scene%d_out" % i: so for i, so in enumerate(scene_out)})
+    ties = sum(int(((so[:, 0] == 1) & np.isin(so[:, 2], [0])).sum()) for so in scene_out)
     print("wrote", path, os.path.getsize(path), "bytes;", dict(zip(["frame", "sphere", "camera_sets", "bsdf", "lift", "gamma"], counts.tolist())),
-          "sphere hits:", int(sphere_out[:, 0].sum()))
+          "sphere hits:", int(sphere_out[:, 0].sum()), "Le rows lit / dark / missed:", int((le_out[:, 2] > 0).sum()), int(((le_out[:, 0] == 1) & (le_out[:, 2] == 0)).sum()),
+          int((le_out[:, 0] == 0).sum()), "scene hits on the doubled first sphere:", ties)
 
 
 if __name__ == "__main__":

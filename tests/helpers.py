@@ -21,6 +21,20 @@ def hemisphere_dirs(rng, n):
     return unit(rng.normal(size=(n, 3)))
 
 
+def prove_ties(rows, gpu_answer, oracle_answer, perturb, rng, what, tries=64):
+    """Every discrete disagreement between the HIP path and the oracle must be a TIE: the oracle itself gives the GPU's answer when the input is moved by a few
+    1e-5 of the scene's size (an edge, a silhouette, a hit at epsilon or tmax, two surfaces at one distance) -- nothing else may differ.
+    rows: the disagreeing inputs; gpu_answer(i) -> what the GPU said for row i (any comparable value); oracle_answer(row) -> the oracle's answer for one input
+    row; perturb(row, rng) -> a slightly moved copy."""
+    for i, row in rows:
+        want = gpu_answer(i)
+        for _ in range(tries):
+            if oracle_answer(perturb(row, rng)) == want:
+                break
+        else:
+            raise AssertionError((what + ": the two sides differ away from any threshold", i, row, want, oracle_answer(row)))
+
+
 def rmse(a, b):
     return float(np.sqrt(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)))
 

@@ -11,9 +11,19 @@ Tolerances (fp32 path; the GPU contracts a*b+c into FMAs and uses the ROCm devic
 import numpy as np
 import pytest
 
-from helpers import explain_pixel, random_rays, rmse, rmse_with_explained_flips, unit
+from helpers import explain_pixel, prove_ties, random_rays, rmse, rmse_with_explained_flips, unit
 
 pytestmark = pytest.mark.gpu
+
+
+def moved_ray(row, rng_, box, eps=3e-5):
+    """the ray {o, d, tmax} moved by eps of the scene's size (tie proofs: helpers.prove_ties)"""
+    r = row.copy()
+    r[0:3] += (eps * box) * rng_.uniform(-1, 1, 3).astype(np.float32)
+    r[3:6] = unit(r[3:6] + eps * rng_.uniform(-1, 1, 3)).astype(np.float32)
+    if np.isfinite(r[6]):
+        r[6] *= 1 + eps * rng_.uniform(-1, 1)
+    return r
 
 
 def assert_close_q(g, c, tol, q=0.999, hard=None):
@@ -142,8 +152,17 @@ def test_kat_cornell_lights(flag, A, api, O, rng):
         wi[:2048] = unit(tgt - p[:2048])
     x = np.concatenate([p, normal, u, wi], 1).astype(np.float32)
     g, c = api.kat_light(scene, 0, x), O.kat_light(scene, 0, x)
-    assert ((g[:, 10] > 0) != (c[:, 10] > 0)).mean() < 2e-3
-    ok = ((g[:, 10] > 0) == (c[:, 10] > 0)) & np.isfinite(c).all(1)
+    differ = (g[:, 10] > 0) != (c[:, 10] > 0)      # pdf_Li's "does wi reach the light's shape" (the base class re-intersects it, 1057-1061)
+    assert differ.mean() < 2e-3
+    # ... and each such row must sit on the lamp's edge: the oracle gives the GPU's flag for a point / direction 3e-5 away (round 5: was a bare 0.2 %)
+
+    def moved(row, rng_):
+        r = row.copy()
+        r[0:3] += 3e-5 * rng_.uniform(-1, 1, 3).astype(np.float32)
+        r[8:11] = unit(r[8:11] + 3e-5 * rng_.uniform(-1, 1, 3)).astype(np.float32)
+        return r
+    prove_ties([(i, x[i]) for i in np.flatnonzero(differ)], lambda i: bool(g[i, 10] > 0), lambda row: bool(O.kat_light(scene, 0, row[None])[0, 10] > 0), moved, rng, "pdf_Li " + flag)
+    ok = ~differ & np.isfinite(c).all(1)
     assert_close_q(g[ok], c[ok], 3e-4, q=0.998)
 
 
@@ -156,7 +175,14 @@ def test_kat_veach_sphere_lights(A, api, O, rng):
         g, c = api.kat_light(scene, light, x), O.kat_light(scene, light, x)
         fin = np.isfinite(c).all(1) & np.isfinite(g).all(1)
         assert fin.mean() > 0.98
-        assert_close_q(g[fin, 0:6], c[fin, 0:6], 5e-4, q=0.998, hard=0.2)  # sampled position, wi
+        # sampled position and wi.  Cone sampling from a point just outside the sphere (sin(theta_max) -> 1: 1 - sin^2 cancels, 1470-1490) amplifies rounding by
+        # dist / sqrt(dist^2 - r^2); round 5 replaces the flat 0.2 by that factor: 5e-4 x amplification, and nothing beyond 2e-2 even there
+        centre = np.array(list(scene.c.shapes[scene.c.lights[light].shape].p[0]), np.float64)
+        radius = float(scene.c.shapes[scene.c.lights[light].shape].radius)
+        dist = np.linalg.norm(x[fin, 0:3].astype(np.float64) - centre, axis=1)
+        amp = np.where(dist > radius, dist / np.sqrt(np.maximum(dist * dist - radius * radius, 1e-12)), 1.0)
+        err = (np.abs(g[fin, 0:6].astype(np.float64) - c[fin, 0:6]) / np.maximum(1.0, np.abs(c[fin, 0:6]))).max(1)
+        assert np.quantile(err, 0.998) <= 5e-4 and (err <= np.minimum(2e-2, 5e-4 * np.maximum(amp, 1.0) * 4)).all(), (light, float(err.max()), float(np.quantile(err, 0.998)))
         scale = np.maximum(np.abs(c[fin]), 1e-3)
         err = (np.abs(g[fin] - c[fin]) / scale)[:, 6:]
         assert np.quantile(err, 0.995) < 2e-3, np.quantile(err, 0.995)
@@ -455,7 +481,10 @@ def test_general_shapes_scene(strategy, A, api, O):
         assert rmse(g, c) < film_tolerance(512), rmse(g, c)
         rays = random_rays(np.random.default_rng(5), 4096, origin_box=1.2, target=np.random.default_rng(6).uniform(-1.2, 1.2, (4096, 3)))
         gi, ci = api.kat_scene_intersect(scene, rays), O.kat_scene_intersect(scene, rays)
-        assert ((gi[:, 0] == ci[:, 0]) & (gi[:, 8] == ci[:, 8])).mean() > 0.997
+        same = (gi[:, 0] == ci[:, 0]) & (gi[:, 8] == ci[:, 8])
+        assert same.mean() > 0.997
+        prove_ties([(i, rays[i]) for i in np.flatnonzero(~same)], lambda i: (float(gi[i, 0]), float(gi[i, 8])),
+                   lambda row: tuple(float(v) for v in O.kat_scene_intersect(scene, row[None])[0, [0, 8]]), lambda row, r_: moved_ray(row, r_, 1.2), np.random.default_rng(15), "general shapes, nearest hit")
         for light in range(2):  # triangle and disk light sampling / pdf
             pts = np.random.default_rng(7 + light).uniform(-1.0, 1.0, (2048, 3))
             nrm = unit(np.random.default_rng(9).normal(size=(2048, 3)))
@@ -660,6 +689,9 @@ def test_axis_aligned_rectangles_special_rays(A, api, O):
     g, c = api.kat_scene_intersect(scene, rays), O.kat_scene_intersect(scene, rays)
     same = (g[:, 0] == c[:, 0]) & (g[:, 8] == c[:, 8])
     assert same.mean() > 0.999, same.mean()
+    # exactly the rays where a systematic error could hide in a 0.1 % allowance: every disagreement must be a tie (round 5)
+    prove_ties([(i, rays[i]) for i in np.flatnonzero(~same)], lambda i: (float(g[i, 0]), float(g[i, 8])),
+               lambda row: tuple(float(v) for v in O.kat_scene_intersect(scene, row[None])[0, [0, 8]]), lambda row, r_: moved_ray(row, r_, 1.3), rng, "special rays, nearest hit")
     hit = same & (c[:, 0] > 0)
     assert hit.sum() > 3000
     assert_close_q(g[hit][:, 1:8], c[hit][:, 1:8], 2e-5, q=0.999, hard=1e-2)
@@ -669,3 +701,10 @@ def test_axis_aligned_rectangles_special_rays(A, api, O):
     q = np.concatenate([o, nrm, tgt], 1).astype(np.float32)
     go, co = api.kat_occluded(scene, q), O.kat_occluded(scene, q)
     assert (go == co).mean() > 0.998
+
+    def moved_segment(row, r_):
+        r = row.copy()
+        r[0:3] += (3e-5 * 1.3) * r_.uniform(-1, 1, 3).astype(np.float32)
+        r[6:9] += (3e-5 * 1.3) * r_.uniform(-1, 1, 3).astype(np.float32)
+        return r
+    prove_ties([(i, q[i]) for i in np.flatnonzero(go != co)], lambda i: float(go[i]), lambda row: float(O.kat_occluded(scene, row[None])[0]), moved_segment, rng, "special rays, occlusion")

@@ -5,7 +5,9 @@ smallpt_rewrite.cpp unmodified; generator tests/golden/make_rewrite_kat.py, whic
 what it changed).  Those values are fp64; ky.cpp computes the same formulas in fp32, so the CPU restatement (oracle/ky_oracle.cpp)
 must agree to fp32 rounding -- 1e-6 relative to the magnitude of the quantity, a few ulp -- and the HIP path (hardware rcp / rsq /
 sqrt, FMA contraction) to the tolerance of its own KATs.  This carries the reference pin from SURVEY rows (f)4 to rows a3, a7,
-a10, a12, a13: frame_t, sphere_t::intersect, camera_t, the Lambert lobe's value and pdf, the mirror lobe, gamma_encoding.
+a10, a12, a13: frame_t, sphere_t::intersect, camera_t, the Lambert lobe's value and pdf, the mirror lobe, gamma_encoding -- and, since
+round 5, to a21 (areal_radiance: an area light's radiance is one-sided, seen through surface_t::intersect) and a5 (scene_t::intersect:
+the whole list is scanned with a shrinking distance and the EARLIER of two surfaces at exactly the same distance stays).
 """
 import os
 
@@ -113,6 +115,69 @@ def check_bsdfs(G, A, kat_bsdf, tol):
     assert np.all(mir[:, 6] == 1) and np.all(bout[:, 10] == 1)
 
 
+def check_area_light_le(G, A, li_fn):
+    """AreaLight::Le through Primitive::Intersect (smallpt_rewrite.cpp:1114-1117, 1135-1146 == ky.cpp:2957-2960, 3077-3088).  Each row is its own scene -- one
+    emitting sphere, a black matte material -- seen along one ray: a 1 x 1 film whose camera sits at the ray's origin and looks along its direction, the debug
+    sampler (the camera sample is the pixel centre, i.e. exactly `front`), depth 0: Li of that sample is the emission the hit reports, and nothing else."""
+    from helpers import CustomScene, make_light, make_material, make_shape
+    lin, lout = G["le_in"], G["le_out"]
+    lit = dark = missed = 0
+    for row, ref in zip(lin, lout):
+        c, r, L, o, d = row[0:3], float(row[3]), row[4:7], row[7:10], row[10:13].astype(np.float64)
+        up = np.cross(d, [1.0, 0.0, 0.0] if abs(d[0]) < 0.9 else [0.0, 1.0, 0.0])
+        up /= np.linalg.norm(up)
+        right = np.cross(up, d)
+        cam = A.Camera()
+        for j in range(3):
+            cam.position[j], cam.front[j], cam.right[j], cam.up[j] = float(o[j]), float(row[10 + j]), float(right[j] * 0.1), float(up[j] * 0.1)
+        cam.resolution[0] = cam.resolution[1] = 1.0
+        scene = CustomScene(A, cam, [make_shape(A, A.SHAPE_SPHERE, [c], radius=r)], [make_material(A, A.MATERIAL_MATTE, (0, 0, 0))],
+                            [make_light(A, A.LIGHT_AREA, tuple(float(x) for x in L), shape=0)], [A.Surface(0, 0, 0)])
+        p = A.RenderParams(A.INTEGRATOR_PATH_TRACING_ITERATION, 0, A.DIRECT_BOTH_MIS, 1, A.SAMPLER_DEBUG, 1234, 1, 1, 8, 8, 0, 1)
+        got = np.asarray(li_fn(scene, p, 0, 0, 0, 1))[0]
+        if ref[0] == 1 and ref[2] > 0:          # hit from outside: the light's own radiance, to the last bit (it is copied, not computed)
+            assert np.array_equal(got, L.astype(np.float32)) and np.allclose(ref[2:5], L), (row, got, ref)
+            lit += 1
+        else:                                    # a miss, or the inside of the sphere (dot(normal, wo) < 0): black
+            assert np.all(got == 0) and np.all(ref[2:5] == 0), (row, got, ref)
+            dark += ref[0] == 1
+            missed += ref[0] == 0
+    assert lit > 100 and dark > 100 and missed > 30, (lit, dark, missed)
+
+
+def check_scene_intersect(G, A, kat_scene_intersect, tol):
+    """Scene::Intersect over lists of spheres in which two spheres appear twice (smallpt_rewrite.cpp:1184-1197 == ky.cpp:3172-3184): which list entry the
+    scan keeps -- on an exact tie the earlier one, never the duplicate -- and the shrinking distance, for every ray of the fixture."""
+    from helpers import CustomScene, make_material, make_shape
+    ties = 0
+    for k in range(3):
+        spheres, rays, ref = G["scene%d_spheres" % k], G["scene%d_rays" % k], G["scene%d_out" % k]
+        scene = CustomScene(A, A.Camera(), [make_shape(A, A.SHAPE_SPHERE, [sp[0:3]], radius=float(sp[3])) for sp in spheres],
+                            [make_material(A, A.MATERIAL_MATTE, (0.5, 0.5, 0.5))], [], [A.Surface(i, 0, -1) for i in range(len(spheres))])
+        scene.scene.camera.resolution[0] = scene.scene.camera.resolution[1] = 1.0
+        out = np.asarray(kat_scene_intersect(scene, rays.astype(np.float32)))
+        assert np.array_equal(out[:, 0], ref[:, 0].astype(np.float32)), "hit flags differ from the reference's (scene %d)" % k
+        h = ref[:, 0] == 1
+        assert h.sum() > 100
+        assert np.array_equal(out[h, 8], ref[h, 2].astype(np.float32)), ("the scan kept another list entry than the reference's", k, np.flatnonzero(out[h, 8] != ref[h, 2]))
+        scale = 1.0 + np.linalg.norm(rays[:, 0:3], axis=1)
+        assert (np.abs(out[h, 1] - ref[h, 1]) / scale[h]).max() < 10 * tol and (np.abs(out[h, 2:5] - ref[h, 3:6]).max(1) / scale[h]).max() < 10 * tol
+        # the doubled spheres: their later copies are never reported, their first entries are
+        dup = [i for i in range(len(spheres)) if any(np.array_equal(spheres[i], spheres[j]) for j in range(i))]
+        first = [min(j for j in range(len(spheres)) if np.array_equal(spheres[i], spheres[j])) for i in dup]
+        assert len(dup) == 2 and not np.isin(ref[h, 2], dup).any() and not np.isin(out[h, 8], dup).any()
+        ties += int(np.isin(ref[h, 2], first).sum())
+    assert ties > 60, ties
+
+
+def test_oracle_area_light_le_matches_the_reference(G, O, A):
+    check_area_light_le(G, A, O.li)
+
+
+def test_oracle_scene_intersect_matches_the_reference(G, O, A):
+    check_scene_intersect(G, A, O.kat_scene_intersect, 1e-6)
+
+
 def test_oracle_frame_matches_the_reference(G, O):
     out = O.kat_frame(G["frame_in"])
     assert rel(out[:, 0:9], G["frame_out"][:, 0:9]) < 1e-6
@@ -158,3 +223,5 @@ def test_hip_path_matches_the_reference(G, api, A):
     check_spheres(G, A, api.kat_intersect, 2e-5)
     check_camera(G, api, A, api.kat_camera, 1e-6)
     check_bsdfs(G, A, api.kat_bsdf, 1e-5)
+    check_area_light_le(G, A, api.kat_li)
+    check_scene_intersect(G, A, api.kat_scene_intersect, 2e-5)

@@ -702,9 +702,20 @@ def boundary_rates(fr, dev, local_rank):
             kydist.render_distributed(fr.scene, p, 0, 1, local_rank, film=film_dev)
             torch.cuda.synchronize(dev)
         dev_ms = (time.perf_counter() - t0) / reps * 1e3
+        # the same call into a PINNED film (kyhip_film_alloc: what ky.hpp's film_t owns): the GPU adds to it in place -- no staging copy, no host pass
+        pinned = api.PinnedFilm(fr.params.height, fr.params.width)
+        api.render(fr.scene, p, film=pinned.array, device=local_rank)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            api.render(fr.scene, p, film=pinned.array, device=local_rank)
+        pinned_ms = (time.perf_counter() - t0) / reps * 1e3
+        del pinned
         out.append({"spp": spp, "calls": reps, "ms_per_call": host_ms, "value": samples / host_ms / 1e3, "unit": "Msamples/s",
-                    "device_resident_ms_per_call": dev_ms, "device_resident_value": samples / dev_ms / 1e3, "ratio_to_device_resident": dev_ms / host_ms})
-    return {"entry": "kyhip_render (host film in / out, blocking; include/kyhip.h)", "film_bytes": int(film_host.nbytes), "rates": out}
+                    "device_resident_ms_per_call": dev_ms, "device_resident_value": samples / dev_ms / 1e3, "ratio_to_device_resident": dev_ms / host_ms,
+                    "pinned_film_ms_per_call": pinned_ms, "pinned_film_value": samples / pinned_ms / 1e3, "pinned_film_ratio_to_device_resident": dev_ms / pinned_ms})
+    lib = A.load_kyhip()
+    return {"entry": "kyhip_render (host film in / out, blocking; include/kyhip.h)", "film_bytes": int(film_host.nbytes), "rates": out,
+            "host_threads_adding": int(lib.kyhip_seam_threads()), "cpus_granted": cpus_granted(), "status": lib.kyhip_multi_status(local_rank).decode()}
 
 
 def projected_scaling(fr, dev, local_rank, lib, kernel_ms_n1, ms_per_step_n1):

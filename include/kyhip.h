@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KYHIP_ABI_VERSION 3
+#define KYHIP_ABI_VERSION 4   /* 4 (round 5): + kyhip_jit_failures, kyhip_multi_status, kyhip_seam_threads, kyhip_film_alloc / _free; kyhip_set_jit mode 2 */
 
 /* ------------------------------------------------------------------------------------------
  * Scene description: a flat restatement of what scene_t holds (ky.cpp:3535-3546) and what the
@@ -290,7 +290,21 @@ int kyhip_film_add_gathered_device(int device, const ky_render_params* params, i
  * the caller's host film exactly like kyhip_render.  A device may be listed more than once (its shards then run one after
  * the other).  The image does not depend on the device list: it is bit-identical to kyhip_render's.  Blocking.
  * kyhip_render(device, ...) is kyhip_render_multi(&device, 1, ...).
+ * kyhip_multi_status(root): how the last kyhip_render_multi call whose devices[0] was `root` gathered its shards, one clause per shard -- "local" (rendered on
+ *   the root), "peer" (hipMemcpyPeerAsync over a peer mapping that hipDeviceEnablePeerAccess set up: a direct xGMI copy; the mapping is made ONCE per
+ *   (root, device) pair and remembered) or "staged" (the runtime reports no peer access: the same call, which the runtime then stages through the host) --
+ *   and how many host threads added the film.  Valid until the next call on this thread.
+ * kyhip_film_alloc(bytes) / kyhip_film_free: film memory the GPU can add to IN PLACE -- pinned, mapped host memory (hipHostMalloc).  kyhip_render /
+ *   kyhip_render_multi recognise such a film (or one the caller registered with hipHostRegister) and let the root GPU's add kernel read and write it over
+ *   PCIe: no staging copy, no host pass, no dependence on the CPUs the process is granted.  Any other film (malloc, new[], numpy) takes the banded
+ *   download + host add.  The images are bit-identical.  NULL without a device: callers fall back to ordinary memory (ky.hpp's film_t does).
+ * kyhip_seam_threads(): host threads the banded add of the next kyhip_render / kyhip_render_multi call will use (the caller's plus parked ones): the CPUs
+ *   the process is granted (affinity mask and cgroup quota), at most four (environment variable KYHIP_SEAM_THREADS overrides).  A pinned film uses none.
  */
+void*       kyhip_film_alloc(size_t bytes);
+void        kyhip_film_free(void* film);
+const char* kyhip_multi_status(int root_device);
+int kyhip_seam_threads(void);
 int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene, const ky_render_params* params,
                        float* film_rgb, size_t film_row_stride_px);
 

@@ -96,6 +96,10 @@ KYHIP_SYMBOLS = {
     "kyhip_set_jit": (C.c_int, [C.c_int]),
     "kyhip_jit_status": (C.c_char_p, []),
     "kyhip_jit_failures": (C.c_int, []),
+    "kyhip_multi_status": (C.c_char_p, [C.c_int]),
+    "kyhip_film_alloc": (C.c_void_p, [C.c_size_t]),
+    "kyhip_film_free": (None, [C.c_void_p]),
+    "kyhip_seam_threads": (C.c_int, []),
     "kyhip_jit_compile": (C.c_int64, [C.c_char_p]),
     "kyhip_kernel_source_hash": (C.c_uint64, []),
     "kyhip_abi_version": (C.c_int, []),

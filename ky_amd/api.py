@@ -87,6 +87,26 @@ def render(scene, params, film=None, device=0, row_stride_px=None, origin_px=(0,
     return film
 
 
+class PinnedFilm:
+    """A [height, width, 3] float32 numpy view of pinned host memory from kyhip_film_alloc (include/kyhip.h): a film the GPU adds to in place.
+    `array` stays valid while this object lives."""
+
+    def __init__(self, height, width):
+        lib = A.load_kyhip()
+        self._lib, self.nbytes = lib, height * width * 12
+        self._ptr = lib.kyhip_film_alloc(self.nbytes)
+        if not self._ptr:
+            raise MemoryError("kyhip_film_alloc returned NULL (no device?)")
+        self.array = np.ctypeslib.as_array((C.c_float * (height * width * 3)).from_address(self._ptr)).reshape(height, width, 3)
+        self.array[...] = 0
+
+    def __del__(self):
+        if getattr(self, "_ptr", None):
+            self.array = None
+            self._lib.kyhip_film_free(self._ptr)
+            self._ptr = None
+
+
 def render_multi(scene, params, devices, film=None, row_stride_px=None, origin_px=(0, 0)):
     """kyhip_render_multi: integrator_t::render with the frame's tiles spread over the listed GPUs (a device may repeat)."""
     lib = A.load_kyhip()

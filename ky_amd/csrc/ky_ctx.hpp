@@ -80,6 +80,8 @@ struct SeamBuffers {
     hipEvent_t band[KY_SEAM_BANDS] = {};                 // root: behind the download of each row band
     std::vector<void*> d_remote;                         // this device as a non-root member of a list: one tile buffer per occurrence
     std::vector<size_t> remote_bytes;
+    std::vector<char> peer;                              // root: per device ordinal, 0 not asked yet, 1 peer mapping enabled (direct copies), 2 no peer access (staged by the runtime)
+    std::string last_status;                             // root: kyhip_multi_status()
 };
 struct DeviceCtx {
     std::mutex m;

@@ -64,6 +64,7 @@ int current_engine();
 
 // ---- the host-film seam's CPU side ----
 int cpus_granted();
+int seam_threads();   // host threads of the banded add (kyhip_seam_threads)
 void host_add_rows(float* __restrict__ film, size_t stride_px, const float* __restrict__ src, int width, int y0, int y1);
 // A few parked host threads for the banded add (creating and joining threads per call cost 50-100 us of a 4 ms frame).  run(n, fn) calls
 // fn(0) ... fn(n - 1), fn(0) on the caller; one job at a time (the callers hold a seam mutex anyway, this one serialises across devices).

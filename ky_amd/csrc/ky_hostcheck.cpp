@@ -155,6 +155,9 @@ int kyhip_film_add_tiles_device(int, const ky_render_params*, const float*, floa
 int kyhip_film_add_gathered_device(int, const ky_render_params*, int, const float*, size_t, float*, size_t, void*) { return no_gpu(); }
 float kyhip_kernel_ms(int) { return -1.f; }
 const char* kyhip_last_kernel(int) { return ""; }
+const char* kyhip_multi_status(int) { return ""; }
+void* kyhip_film_alloc(size_t) { return nullptr; }   // no device: callers fall back to ordinary memory
+void kyhip_film_free(void*) {}
 int kyhip_kat_intersect(int, const ky_shape*, const float*, int, float*) { return no_gpu(); }
 int kyhip_kat_camera(int, const ky_camera*, const float*, int, float*) { return no_gpu(); }
 int kyhip_kat_bsdf(int, const ky_material*, const float*, int, float*) { return no_gpu(); }

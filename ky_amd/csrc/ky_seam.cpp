@@ -6,6 +6,7 @@
  * is defined here.
  */
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #include "ky_ctx.hpp"
@@ -59,16 +60,30 @@ int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene,
     // buffers: one gather block and the film on the root, the pinned staging film; a tile buffer per remote shard on its device
     HIP_TRY(hipSetDevice(root));
     SeamBuffers& sb = ctx[0]->seam;
+    // A film in PINNED host memory (kyhip_film_alloc: what ky.hpp's film_t allocates; or memory the caller registered with the runtime) is added to IN PLACE by the
+    // root GPU: the add kernel reads and writes the host film over PCIe (12 B in, 12 B out per pixel, both directions at once), and the staging film, its download and
+    // the host threads' pass drop out -- the seam then costs the same whatever CPUs the process is granted (round 5; a pageable film takes the banded path below).
+    float* film_in_place = nullptr;
+    {
+        const size_t span = ((size_t)(p->height - 1) * stride_px + (size_t)p->width) * 3 * sizeof(float);
+        hipPointerAttribute_t first{}, last{};
+        void* dptr = nullptr;
+        if (hipPointerGetAttributes(&first, film_rgb) == hipSuccess && first.type == hipMemoryTypeHost &&
+            hipPointerGetAttributes(&last, (const char*)film_rgb + span - 1) == hipSuccess && last.type == hipMemoryTypeHost &&
+            hipHostGetDevicePointer(&dptr, film_rgb, 0) == hipSuccess && dptr)
+            film_in_place = (float*)dptr;
+        (void)hipGetLastError();   // "not a registered pointer" is the ordinary answer for a pageable film
+    }
     int rcode = seam_reserve(&sb.d_gather, &sb.gather_bytes, rank_stride * n_devices * sizeof(float), false);
-    if (rcode == KY_OK) rcode = seam_reserve(&sb.d_film, &sb.film_bytes, film_floats * sizeof(float), false);
-    if (rcode == KY_OK) rcode = seam_reserve((void**)&sb.h_stage, &sb.stage_bytes, film_floats * sizeof(float), true);
+    if (rcode == KY_OK && !film_in_place) rcode = seam_reserve(&sb.d_film, &sb.film_bytes, film_floats * sizeof(float), false);
+    if (rcode == KY_OK && !film_in_place) rcode = seam_reserve((void**)&sb.h_stage, &sb.stage_bytes, film_floats * sizeof(float), true);
     if (rcode != KY_OK) return rcode;
     for (hipEvent_t& e : sb.band)
         if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     float* const d_gather = (float*)sb.d_gather;
     float* const d_film = (float*)sb.d_film;
     hipStream_t root_stream = ctx[0]->stream;
-    HIP_TRY(hipMemsetAsync(d_film, 0, film_floats * sizeof(float), root_stream));
+    if (!film_in_place) HIP_TRY(hipMemsetAsync(d_film, 0, film_floats * sizeof(float), root_stream));
     std::vector<float*> remote(n_devices, nullptr);
     std::vector<int> remote_slot(n_devices, 0);   // a device listed k times needs k tile buffers
     std::vector<hipEvent_t> done(n_devices, nullptr);
@@ -97,11 +112,17 @@ int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene,
             rcode = seam_reserve(&rb.d_remote[slot], &rb.remote_bytes[slot], rank_stride * sizeof(float), false);
             if (rcode != KY_OK) break;
             remote[i] = dst = (float*)rb.d_remote[slot];
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, root, devices[i]) == hipSuccess && can) {   // direct xGMI copies; staged otherwise
-                HIP_CHECK_BREAK(hipSetDevice(root));
-                (void)hipDeviceEnablePeerAccess(devices[i], 0);
-                (void)hipGetLastError();   // "already enabled" is not an error here
+            // the root's mapping of this device's memory: asked for ONCE per (root, device) pair and remembered (round 4 asked the runtime on every call)
+            if (sb.peer.size() <= (size_t)devices[i]) sb.peer.resize((size_t)devices[i] + 1, 0);
+            if (sb.peer[devices[i]] == 0) {
+                int can = 0;
+                sb.peer[devices[i]] = 2;
+                if (hipDeviceCanAccessPeer(&can, root, devices[i]) == hipSuccess && can) {   // direct xGMI copies; staged by the runtime otherwise
+                    HIP_CHECK_BREAK(hipSetDevice(root));
+                    const hipError_t pe = hipDeviceEnablePeerAccess(devices[i], 0);
+                    (void)hipGetLastError();   // "already enabled" is not an error here
+                    if (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) sb.peer[devices[i]] = 1;
+                }
             }
         }
         rcode = kyhip_render_tiles_device(devices[i], scene, &shard[i], dst, nullptr, 0, ctx[i]->stream);
@@ -124,12 +145,14 @@ int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene,
             if (e != hipSuccess) { rcode = fail(KY_ERR_DEVICE, "gathering shard %d failed: %s", i, hipGetErrorString(e)); failed = true; }
         }
         if (failed) break;
-        rcode = kyhip_film_add_gathered_device(root, p, n_devices, d_gather, rank_stride, d_film, (size_t)p->width, root_stream);
+        if (film_in_place) rcode = kyhip_film_add_gathered_device(root, p, n_devices, d_gather, rank_stride, film_in_place, stride_px, root_stream);   // film_t::add_color, by the GPU, in the caller's film
+        else rcode = kyhip_film_add_gathered_device(root, p, n_devices, d_gather, rank_stride, d_film, (size_t)p->width, root_stream);
     }
     // 3. the film comes home in row bands, each followed by an event
     const size_t row_bytes = (size_t)p->width * 3 * sizeof(float);
     int n_bands = (int)std::min<size_t>(KY_SEAM_BANDS, std::max<size_t>(1, film_floats * sizeof(float) / (512u << 10)));   // bands of at least 512 KB
     n_bands = std::min(n_bands, p->height);
+    if (film_in_place) n_bands = 0;   // nothing comes home: the film was added to where it lies
     auto band_row = [&](int b) { return (int)((long long)p->height * b / n_bands); };
     int bands_enqueued = 0;
     for (int b = 0; b < n_bands && rcode == KY_OK; ++b) {
@@ -142,8 +165,8 @@ int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene,
     // 4. host threads add the bands as they arrive: film_t::add_color, 1586-1590.  Every thread works on its slice of the rows of EVERY band (a band is
     // waited for once, by the thread that gets to it first under the band's flag), so the threads are all busy from the first band on.
     hipError_t sync_err = hipSuccess;
-    if (rcode == KY_OK && bands_enqueued == n_bands) {
-        const int n_threads = std::max(1, std::min({p->height, cpus_granted(), (int)KY_SEAM_THREADS}));
+    if (rcode == KY_OK && bands_enqueued == n_bands && n_bands > 0) {
+        const int n_threads = std::max(1, std::min(p->height, seam_threads()));
         std::vector<hipError_t> errs(n_threads, hipSuccess);
         auto work = [&](int t) {
             for (int b = 0; b < n_bands; ++b) {
@@ -164,9 +187,38 @@ int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene,
         if (e != hipSuccess) sync_err = e;
     }
     (void)hipSetDevice(root);
+    {   // kyhip_multi_status(root)
+        std::string st = std::to_string(n_devices) + " shard(s):";
+        for (int i = 0; i < n_devices; ++i) {
+            const char* how = devices[i] == root ? "local" : ((size_t)devices[i] < sb.peer.size() && sb.peer[devices[i]] == 1 ? "peer" : "staged");
+            st += std::string(i ? "," : "") + " device " + std::to_string(devices[i]) + " " + how;
+        }
+        st += film_in_place ? std::string("; film added in place by the GPU (pinned host film)")
+                            : "; film added by " + std::to_string(std::max(1, std::min(p->height, seam_threads()))) + " host thread(s)";
+        sb.last_status = st;
+    }
     if (rcode != KY_OK) return rcode;
     if (sync_err != hipSuccess) return fail(KY_ERR_DEVICE, "render failed: %s (the caller's film may hold a part of the frame)", hipGetErrorString(sync_err));
     return KY_OK;
+}
+
+const char* kyhip_multi_status(int root_device) {
+    static thread_local std::string s;
+    s.clear();
+    DeviceCtx* c = find_ctx(root_device);
+    if (c) { std::lock_guard<std::mutex> lock(c->seam.m); s = c->seam.last_status; }
+    return s.c_str();
+}
+
+// Film memory the root GPU can add to in place (kyhip_render_multi): pinned, mapped host memory.  NULL when there is no device or no memory; kyhip_film_free
+// takes what kyhip_film_alloc returned (and NULL).
+void* kyhip_film_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void kyhip_film_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int kyhip_render(int device, const ky_scene* scene, const ky_render_params* p, float* film_rgb, size_t stride_px) {

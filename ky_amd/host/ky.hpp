@@ -98,8 +98,18 @@ inline uint8_t gamma_encoding(float x) { return (uint8_t)(std::pow((double)clamp
 
 class film_t {
 public:
-    film_t(int width, int height) : width_(width), height_(height), pixels_((size_t)width * height) {}
-    virtual ~film_t() = default;
+    // The reference's film owns its pixels (`new color_t[]`, 1559).  Here they come from kyhip_film_alloc -- pinned host memory the GPU adds to in place
+    // (include/kyhip.h: no staging copy, no host pass at the end of render()) -- and from ordinary memory where that returns NULL (no device).
+    film_t(int width, int height) : width_(width), height_(height), count_((size_t)width * height) {
+        pixels_ = static_cast<color_t*>(kyhip_film_alloc(count_ * sizeof(color_t)));
+        pinned_ = pixels_ != nullptr;
+        if (!pixels_) pixels_ = new color_t[count_];
+        for (size_t i = 0; i < count_; ++i) pixels_[i] = color_t{};
+    }
+    virtual ~film_t() {
+        if (pinned_) kyhip_film_free(pixels_);
+        else delete[] pixels_;
+    }
     film_t(const film_t&) = delete;
     film_t& operator=(const film_t&) = delete;
 
@@ -113,7 +123,7 @@ public:
     void set_color(int x, int y, color_t c) { (*this)(x, y) = c; }
     void clear_color(int x, int y) { set_color(x, y, color_t{}); }
     void add_color(int x, int y, color_t d) { color_t& c = (*this)(x, y); c = c + d; }  // 1586-1590
-    void clear(color_t c) { for (auto& p : pixels_) p = c; }
+    void clear(color_t c) { for (size_t i = 0; i < count_; ++i) pixels_[i] = c; }
 
     // raw view for the C ABI: pointer to the first float of the current render target and its row stride
     float* data() { return &pixels_[0].r; }
@@ -180,7 +190,9 @@ public:
 
 protected:
     int32_t width_{}, height_{};
-    std::vector<color_t> pixels_;
+    size_t count_;
+    color_t* pixels_ = nullptr;
+    bool pinned_ = false;
 };
 
 // mosaic of sub-films (1802-1836): render() targets the current cell

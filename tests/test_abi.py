@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(A):
     lib = A.load_kyhip()
     for name in header_functions():
         assert hasattr(lib, name), name
-    assert lib.kyhip_abi_version() == 3
+    assert lib.kyhip_abi_version() == 4
     out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(A.LIB_DIR, "libkyhip.so")], text=True)
     exported = set(re.findall(r" T (kyhip_\w+)", out))
     assert set(header_functions()) <= exported

@@ -95,3 +95,40 @@ def test_instantiated_kernels_render_what_the_table_renders(A, api, O, tmp_path,
     finally:
         lib.kyhip_set_jit(prev)
         lib.kyhip_set_shadow_queue(-1)
+
+
+@pytest.mark.gpu
+def test_asynchronous_mode_renders_on_the_table_until_the_object_is_there(A, api, tmp_path, monkeypatch):
+    """kyhip_set_jit(2) (round 5): a launch whose instantiation is not in the table does NOT wait for the compiler -- the table's kernel renders, a background
+    thread compiles, and a later launch switches.  The first call returns in a fraction of the compile time, every frame is one of the two kernels' images
+    (which differ by at most 2e-5), the switch happens within seconds, and a multi-shard call uses one kernel for all its shards."""
+    monkeypatch.setenv("KYHIP_CACHE_DIR", str(tmp_path / "cache"))
+    lib = A.load_kyhip()
+    W, H = 96, 64
+    scene = api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | A.CB_LIGHT_AREA | A.CB_LIGHT_POINT, W, H)      # lamp + point light: no row of the table
+    p = api.make_params(W, H, 32)
+    prev = lib.kyhip_set_jit(0)
+    try:
+        table = api.render(scene, p)
+        table_kernel = lib.kyhip_last_kernel(0)
+        assert b"run-time" not in table_kernel
+        lib.kyhip_set_jit(2)
+        t0 = time.time()
+        first = api.render(scene, p)
+        dt_first = time.time() - t0
+        assert lib.kyhip_last_kernel(0) == table_kernel and np.array_equal(first, table)     # nothing compiled yet: the table's kernel, the table's image
+        assert dt_first < 1.0, dt_first                                                          # (a compile takes 2-3 s)
+        own = None
+        deadline = time.time() + 60
+        while time.time() < deadline:
+            img = api.render_multi(scene, p, [0, 0, 0])                                        # three shards per frame: all on one kernel
+            if b"run-time instantiation" in lib.kyhip_last_kernel(0):
+                own = img
+                break
+            assert np.array_equal(img, table)
+            time.sleep(0.2)
+        assert own is not None, lib.kyhip_jit_status()
+        assert np.abs(own - table).max() < 2e-5 and lib.kyhip_jit_failures() == 0
+        assert np.array_equal(api.render(scene, p), own)                                       # from here on: always the own kernel, deterministically
+    finally:
+        lib.kyhip_set_jit(prev)

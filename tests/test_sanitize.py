@@ -20,7 +20,7 @@ pytestmark = pytest.mark.skipif(os.environ.get("KY_SANITIZE") is not None, reaso
 
 
 def _make(*targets):
-    r = subprocess.run(["make", "-s", "-C", ROOT] + [os.path.join("build", "san", t) for t in targets], capture_output=True, text=True)
+    r = subprocess.run(["make", "-s", "-j4", "-C", ROOT] + [os.path.join("build", "san", t) for t in targets], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
 
 

@@ -32,6 +32,37 @@ def test_host_film_is_added_to_in_bands(A, api, rng):
         assert np.array_equal(multi, frame)
 
 
+def test_a_pinned_film_is_added_to_in_place(A, api, rng):
+    """Round 5: a film in pinned host memory (kyhip_film_alloc: what ky.hpp's film_t allocates) is added to by the GPU's add kernel where it lies -- no staging
+    film, no download, no host threads.  Same semantics as the banded path (add, row stride, nothing outside the target touched), bit-identical pixels, for the
+    single-device call and the device-list call; a pageable film right afterwards takes the banded path again."""
+    lib = A.load_kyhip()
+    for (w, h, spp) in [(24, 17, 4), (1024, 768, 2), (40, 700, 2)]:
+        scene = api.cornell_box_scene(A.CB_DEFAULT_SCENE, w, h)
+        p = api.make_params(w, h, spp)
+        frame = api.render(scene, p)                                     # pageable numpy film: the banded path
+        assert b"host thread" in lib.kyhip_multi_status(0)
+        pinned = api.PinnedFilm(h + 9, w + 13)
+        pinned.array[...] = rng.uniform(0, 1, pinned.array.shape).astype(np.float32)
+        before = pinned.array.copy()
+        api.render(scene, p, film=pinned.array, origin_px=(5, 3))
+        assert b"in place by the GPU" in lib.kyhip_multi_status(0), lib.kyhip_multi_status(0)
+        assert np.array_equal(pinned.array[3:3 + h, 5:5 + w], before[3:3 + h, 5:5 + w] + frame), (w, h)
+        rest, rest0 = pinned.array.copy(), before.copy()
+        rest[3:3 + h, 5:5 + w] = 0
+        rest0[3:3 + h, 5:5 + w] = 0
+        assert np.array_equal(rest, rest0), "pixels outside the target were touched"
+        whole = api.PinnedFilm(h, w)
+        api.render_multi(scene, p, [0, 0, 0], film=whole.array)
+        assert b"3 shard(s)" in lib.kyhip_multi_status(0) and b"in place" in lib.kyhip_multi_status(0)
+        assert np.array_equal(whole.array, frame)
+        del pinned, whole
+    # the host mirror's film_t owns pinned pixels: integrator_t::render through the C++ API takes the in-place path by itself
+    W, H = 48, 32
+    film = api.render_host_api(api.cornell_box_scene(A.CB_DEFAULT_SCENE, W, H), 11, 5, 48, A.SAMPLER_RANDOM, 8, W, H)
+    assert b"in place by the GPU" in lib.kyhip_multi_status(0) and film.max() > 0.2
+
+
 def test_debug_pixel_and_debug_area_replay_the_render(A, api):
     """integrator_t::debug_pixel / debug_area (3733-3787) on the host mirror: a red frame is ADDED around the area and its pixels are
     cleared and rendered again; the replay (per-sample radiance, summed in sample order) is the pixel render() computed, to rounding."""

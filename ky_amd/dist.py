@@ -80,6 +80,15 @@ def render_shard(scene, params, rank, world, device_index=0, out=None):
     """Render this rank's tiles on its GPU into `out` (default: a fresh zeroed tensor) [max_tiles_per_rank, tile_h, tile_w, 3]
     -- equal sizes on every rank keep the gather a single call."""
     lib = A.load_kyhip()
+    if world > 1:
+        # run-time instantiations across ranks: table and own kernel differ in the last bit of a pixel, so every rank of a frame must be on the same one.
+        # Mode 1 (blocking; the code cache is shared through flock) guarantees that as long as no rank's compile fails; mode 2 switches when each process's
+        # own background compile finishes -- a matter of timing, so it is refused here.
+        mode = lib.kyhip_set_jit(-1)
+        if mode == 2:
+            raise RuntimeError("kyhip_set_jit(2) (asynchronous run-time instantiations) would let the ranks of one frame render on different kernels; use mode 1 with world > 1")
+        if mode == 1 and lib.kyhip_jit_failures() > 0:
+            raise RuntimeError("a run-time instantiation failed on this rank (%s): its shards would come from another kernel than the other ranks'" % lib.kyhip_jit_status().decode())
     p = shard_params(params, rank, world)
     dev = torch.device("cuda", device_index)
     tiles = out

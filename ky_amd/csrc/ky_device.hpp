@@ -1383,6 +1383,12 @@ KY_DEV void estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f
 // wavefronts stay in its 4 MB L2, so pops are L2 hits).  Contributions are added in 32.32 fixed point, so the image does not
 // depend on when a ray is resolved.
 // ---------------------------------------------------------------------------------------------
+#ifndef KY_SQ_FLUSH_AT
+#define KY_SQ_FLUSH_AT 64   // rays at hand (waiting + new) that trigger a traversal: 64 fills every lane; less keeps the stack shallower and the lanes emptier (measurements)
+#endif
+#ifndef KY_SQ_FLUSH_ALL_NEW
+#define KY_SQ_FLUSH_ALL_NEW 1
+#endif
 constexpr int KY_SQ_ENTRY = 3;                                // float4 per ray: (origin, tmax) (direction, tag) (contribution, -)
 constexpr int KY_SQ_CAP = 128;                                // < 64 waiting + < 64 of a push that did not fit the wave being traced
 struct ShadowQueue {
@@ -1399,6 +1405,27 @@ struct SqRay {
     float tmax;
     unsigned tag;   // destination pixel << 6 | lane that pushed it
 };
+#ifndef KY_SQ_LDS
+#define KY_SQ_LDS 0   // 1: the stacks live in LDS (11 dwords x 63 entries per wavefront, field-major: no memory traffic at all; needs KY_SQ_FLUSH_ALL_NEW and five wavefronts per SIMD)
+#endif
+#if KY_SQ_LDS
+static_assert(KY_SQ_FLUSH_ALL_NEW, "the LDS stack holds 64 entries: the flush must not grow it");
+constexpr int KY_SQ_LDS_FIELDS = 11;
+struct SqLds { float f[4][KY_SQ_LDS_FIELDS][64]; };   // [wavefront of the workgroup][field][slot]
+__shared__ SqLds g_sq_lds;
+KY_DEV void sq_store(float4* e, const SqRay& r) {
+    float* b = &g_sq_lds.f[threadIdx.x >> 6][0][0] + (unsigned)(size_t)e;   // `e` carries the slot number (ShadowQueue::base is null in this mode)
+    b[0 * 64] = r.o.x; b[1 * 64] = r.o.y; b[2 * 64] = r.o.z; b[3 * 64] = r.tmax;
+    b[4 * 64] = r.d.x; b[5 * 64] = r.d.y; b[6 * 64] = r.d.z; b[7 * 64] = __uint_as_float(r.tag);
+    b[8 * 64] = r.c.x; b[9 * 64] = r.c.y; b[10 * 64] = r.c.z;
+}
+KY_DEV SqRay sq_load(const float4* e) {
+    const float* b = &g_sq_lds.f[threadIdx.x >> 6][0][0] + (unsigned)(size_t)e;
+    return SqRay{mk3(b[0], b[64], b[128]), mk3(b[4 * 64], b[5 * 64], b[6 * 64]), mk3(b[8 * 64], b[9 * 64], b[10 * 64]), b[3 * 64], __float_as_uint(b[7 * 64])};
+}
+#define KY_SQ_SLOT(q, i) ((float4*)(size_t)(unsigned)(i))
+#else
+#define KY_SQ_SLOT(q, i) ((q).base + (i) * KY_SQ_ENTRY)
 KY_DEV void sq_store(float4* e, const SqRay& r) {
     e[0] = make_float4(r.o.x, r.o.y, r.o.z, r.tmax);
     e[1] = make_float4(r.d.x, r.d.y, r.d.z, __uint_as_float(r.tag));
@@ -1408,6 +1435,7 @@ KY_DEV SqRay sq_load(const float4* e) {
     const float4 a = e[0], b = e[1], c = e[2];
     return SqRay{mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), a.w, __float_as_uint(b.w)};
 }
+#endif
 // traces this lane's ray (any hit occludes) and adds an unoccluded contribution to its pixel
 KY_DEV void sq_trace(SceneRef S, const ShadowQueue& q, const SqRay& r) {
     if (trace_any(S, S->occ_deferred_ok ? S->occ : S->trav, r.o, r.d, r.tmax)) return;   // rays of all lights share the stack
@@ -1431,22 +1459,37 @@ KY_DEV void sq_push(SceneRef S, ShadowQueue& q, bool push, SqRay r) {
     if (!m) return;
     const int k = __popcll(m);
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));   // pushing lanes below this one
-    if (q.n + k < 64) {   // not yet a wavefront's worth: the rays wait
-        if (push) sq_store(q.base + (q.n + rank) * KY_SQ_ENTRY, r);
+    if (q.n + k < KY_SQ_FLUSH_AT) {   // not yet a wavefront's worth: the rays wait
+        if (push) sq_store(KY_SQ_SLOT(q, q.n + rank), r);
         q.n += k;
         return;
     }
+#if KY_SQ_FLUSH_ALL_NEW
+    // 64 or more rays at hand: EVERY new ray is traced from the registers it is in, and the 64 - k lanes without one pop the top of the stack (q.n >= 64 - k).
+    // Round 5: rounds 3-4 kept only the first 64 - q.n new rays in registers and stored the others on top of the stack -- from where they were popped again a
+    // moment later by the very lanes that had stored them: k - (64 - q.n) entries written and read for nothing per flush, and a stack that grew to 2 q.n + k - 65
+    // entries for a moment (which is why its block held 128).  Now nothing is stored at a flush, the stack never holds more than 63 entries, and q.n + k - 64 of
+    // the OLD entries simply stay where they are.
+    asm volatile("" ::: "memory");   // the compiler must keep the order of earlier pushes' stores and these loads; the hardware keeps a wavefront's accesses to one address in order
+    const unsigned long long idle = ~m;
+    const int idx = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));   // lanes without a new ray below this one
+    const bool pop = !push && idx < q.n;   // (KY_SQ_FLUSH_AT < 64: there may be fewer old rays than idle lanes)
+    if (pop) r = sq_load(KY_SQ_SLOT(q, q.n - 1 - idx));
+    q.n -= min(q.n, 64 - k);
+    if (KY_SQ_FLUSH_AT == 64 || push || pop) sq_trace(S, q, r);
+    return;
+#endif
     // 64 or more: the first `take` new rays are traced from the registers they are in, the rest wait; the q.n lanes without a ray to
     // trace pop the top of the stack (which may hold rays stored a moment ago: same wavefront, same address -> in order)
     const int take = 64 - q.n;
     const bool keep = push && rank < take;
-    if (push && !keep) sq_store(q.base + (q.n + rank - take) * KY_SQ_ENTRY, r);
+    if (push && !keep) sq_store(KY_SQ_SLOT(q, q.n + rank - take), r);
     const int n1 = q.n + k - take;
     asm volatile("" ::: "memory");   // the compiler must keep the order; the hardware keeps a wavefront's accesses to one address in order by itself
     const unsigned long long others = __ballot(!keep);
     if (!keep) {
         const int j = n1 - 1 - (int)__builtin_amdgcn_mbcnt_hi((unsigned)(others >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)others, 0u));
-        r = sq_load(q.base + j * KY_SQ_ENTRY);
+        r = sq_load(KY_SQ_SLOT(q, j));
     }
     q.n = k - take;
     sq_trace(S, q, r);
@@ -1458,7 +1501,7 @@ KY_DEV void sq_push_bsdf_query(SceneRef S, ShadowQueue& q, bool push, f3 o, f3 d
 KY_DEV void sq_drain(SceneRef S, ShadowQueue& q) {
     const int lane = (int)__lane_id();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (lane < q.n) sq_trace(S, q, sq_load(q.base + lane * KY_SQ_ENTRY));
+    if (lane < q.n) sq_trace(S, q, sq_load(KY_SQ_SLOT(q, lane)));
     q.n = 0;
 }
 

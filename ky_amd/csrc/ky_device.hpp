@@ -1390,7 +1390,10 @@ KY_DEV void estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f
 #define KY_SQ_FLUSH_ALL_NEW 1
 #endif
 constexpr int KY_SQ_ENTRY = 3;                                // float4 per ray: (origin, tmax) (direction, tag) (contribution, -)
-constexpr int KY_SQ_CAP = 128;                                // < 64 waiting + < 64 of a push that did not fit the wave being traced
+#ifndef KY_SQ_CAP_ENTRIES
+#define KY_SQ_CAP_ENTRIES (KY_SQ_FLUSH_ALL_NEW ? 64 : 128)
+#endif
+constexpr int KY_SQ_CAP = KY_SQ_CAP_ENTRIES;                  // entries per wavefront's block: < 64 waiting (round 5: a flush stores nothing; rounds 3-4: + < 64 of a push that did not fit the wave being traced)
 struct ShadowQueue {
     float4* base;   // this wave's block: KY_SQ_CAP entries
     int n;          // rays on the stack (wave-uniform), < 64 between calls
@@ -1405,26 +1408,6 @@ struct SqRay {
     float tmax;
     unsigned tag;   // destination pixel << 6 | lane that pushed it
 };
-#ifndef KY_SQ_LDS
-#define KY_SQ_LDS 0   // 1: the stacks live in LDS (11 dwords x 63 entries per wavefront, field-major: no memory traffic at all; needs KY_SQ_FLUSH_ALL_NEW and five wavefronts per SIMD)
-#endif
-#if KY_SQ_LDS
-static_assert(KY_SQ_FLUSH_ALL_NEW, "the LDS stack holds 64 entries: the flush must not grow it");
-constexpr int KY_SQ_LDS_FIELDS = 11;
-struct SqLds { float f[4][KY_SQ_LDS_FIELDS][64]; };   // [wavefront of the workgroup][field][slot]
-__shared__ SqLds g_sq_lds;
-KY_DEV void sq_store(float4* e, const SqRay& r) {
-    float* b = &g_sq_lds.f[threadIdx.x >> 6][0][0] + (unsigned)(size_t)e;   // `e` carries the slot number (ShadowQueue::base is null in this mode)
-    b[0 * 64] = r.o.x; b[1 * 64] = r.o.y; b[2 * 64] = r.o.z; b[3 * 64] = r.tmax;
-    b[4 * 64] = r.d.x; b[5 * 64] = r.d.y; b[6 * 64] = r.d.z; b[7 * 64] = __uint_as_float(r.tag);
-    b[8 * 64] = r.c.x; b[9 * 64] = r.c.y; b[10 * 64] = r.c.z;
-}
-KY_DEV SqRay sq_load(const float4* e) {
-    const float* b = &g_sq_lds.f[threadIdx.x >> 6][0][0] + (unsigned)(size_t)e;
-    return SqRay{mk3(b[0], b[64], b[128]), mk3(b[4 * 64], b[5 * 64], b[6 * 64]), mk3(b[8 * 64], b[9 * 64], b[10 * 64]), b[3 * 64], __float_as_uint(b[7 * 64])};
-}
-#define KY_SQ_SLOT(q, i) ((float4*)(size_t)(unsigned)(i))
-#else
 #define KY_SQ_SLOT(q, i) ((q).base + (i) * KY_SQ_ENTRY)
 KY_DEV void sq_store(float4* e, const SqRay& r) {
     e[0] = make_float4(r.o.x, r.o.y, r.o.z, r.tmax);
@@ -1435,7 +1418,6 @@ KY_DEV SqRay sq_load(const float4* e) {
     const float4 a = e[0], b = e[1], c = e[2];
     return SqRay{mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), a.w, __float_as_uint(b.w)};
 }
-#endif
 // traces this lane's ray (any hit occludes) and adds an unoccluded contribution to its pixel
 KY_DEV void sq_trace(SceneRef S, const ShadowQueue& q, const SqRay& r) {
     if (trace_any(S, S->occ_deferred_ok ? S->occ : S->trav, r.o, r.d, r.tmax)) return;   // rays of all lights share the stack

@@ -638,7 +638,10 @@ KY_DEV bool trace_any(SceneRef S, const DTrav& T, f3 o, f3 d, float tmax) {
 KY_DEV f3 hit_normal(const DHit& H, f3 position, f3 d) {
     const f3 n = ld3(H.n);
     if (H.kind == KY_SHAPE_SPHERE) return normalize(position - n);
-    if (H.kind == KY_SHAPE_RECTANGLE) return dot(n, d) <= 0 ? n : -n;
+    if (H.kind == KY_SHAPE_RECTANGLE) {   // the normal that faces the ray (1289): the sign bit of all three components flipped by one mask, no divergent region
+        const unsigned flip = dot(n, d) <= 0 ? 0u : 0x80000000u;
+        return mk3(__uint_as_float(__float_as_uint(n.x) ^ flip), __uint_as_float(__float_as_uint(n.y) ^ flip), __uint_as_float(__float_as_uint(n.z) ^ flip));
+    }
     return n;
 }
 
@@ -853,19 +856,18 @@ KY_DEV void bsdf_eval_parts(const Vertex& v, f3 wo, f3 wi, f3& col, float& scale
     const float cos_o = dot(v.normal, wo), cos_i = dot(v.normal, wi);
     abs_cos_i = fabsf(cos_i);
     const bool same = cos_o * cos_i > 0;
-    float p;
-    if (B.lobe == LOBE_PHONG) {
+    // the Lambert lobe's three values for every lane (two selects and a multiply), the Phong lobe's over them under ONE divergent region (round 5: two regions before)
+    float p = same ? abs_cos_i * K_INV_PI : 0.f;
+    scale = same ? K_INV_PI : 0.f;
+    const bool phong = B.lobe == LOBE_PHONG;
+    col = ld3(phong ? B.m->cs : B.m->c0);
+    if (phong) {
         const float cos_alpha = dot(vertex_basis_c(v), wi);
         const float exponent = B.m->exponent;
         const float pe = phong_pow(cos_alpha, exponent, B.m->exp_flags);
         const float p0 = exponent == 0.f ? 1.f : (exponent > 0.f ? 0.f : K_INF);
-        col = ld3(B.m->cs);
         scale = same ? pe * B.m->inv_eta : 0.f;
         p = (cos_alpha > 0.f ? pe : p0) * B.m->phong_pdf_norm;
-    } else {
-        col = ld3(B.m->c0);
-        scale = same ? K_INV_PI : 0.f;
-        p = same ? abs_cos_i * K_INV_PI : 0.f;
     }
     const bool nondelta = !bsdf_is_delta(B);
     scale = nondelta ? scale : 0.f;
@@ -900,8 +902,7 @@ KY_DEV f3 bsdf_sample_dir_nondelta(const Vertex& v, f3 wo, float u0, float u1, b
     float px = cos_rev(ang) * rad, py = sin_rev(ang) * rad;
     if (!phong) {   // cosine_hemisphere_sample 737-743, flipped into wo's hemisphere (2247-2249)
         if (origin) { px = 0.f; py = 0.f; }
-        z = fsqrt(fmaxf(0.f, 1 - px * px - py * py));
-        if (cos_o < 0) z = -z;
+        z = __builtin_copysignf(fsqrt(fmaxf(0.f, 1 - px * px - py * py)), cos_o);   // `if (wo.z < 0) z = -z` as one v_bfi_b32 (no divergent region around a single negation)
     }
     const LobeBasis L = vertex_basis(v);
     f3 wi = L.a * px + L.b * py + L.c * z;
@@ -932,10 +933,10 @@ KY_DEV DeltaSample bsdf_sample_delta(const Vertex& v, f3 wo, float u0) {
     const DMat& M = *v.bsdf.m;
     const bool glass = v.bsdf.lobe == LOBE_GLASS;
     const float cos_o = dot(v.normal, wo);
-    const float eta_t = M.eta;
+    const float eta_t = M.eta, inv_eta = M.inv_eta;                  // (both read before the selects: no load under a branch)
     const bool into = cos_o > 0;
     const float nz = into ? 1.f : -1.f;
-    const float ratio = into ? M.inv_eta : eta_t;                    // eta_i / eta_t seen from wo's side
+    const float ratio = into ? inv_eta : eta_t;                      // eta_i / eta_t seen from wo's side
     const float ei = into ? 1.f : eta_t, et = into ? eta_t : 1.f;
     const float cos_theta_i = fminf(fabsf(cos_o), 1.f);
     const float sin_theta_i_sq = fmaxf(0.f, 1 - cos_theta_i * cos_theta_i);
@@ -1002,7 +1003,8 @@ KY_DEV BsdfContinue bsdf_continue(const Vertex& v, f3 wo, float u0, float u1) {
         const bool phong = v.bsdf.lobe == LOBE_PHONG;
         const f3 col = ld3(phong ? v.bsdf.m->c1 : v.bsdf.m->c0);
         c.weight = phong ? col * fabsf(cos_i) : col;
-        c.ok = (cos_o * cos_i > 0) && !is_black(col) && !(phong && !(u1 > 0.f) && v.bsdf.m->exponent > 0.f) && !back_dead;
+        const bool dead_u1 = phong & !(u1 > 0.f) & (v.bsdf.m->exponent > 0.f);   // (bitwise: every operand is at hand, no short-circuit branches)
+        c.ok = (cos_o * cos_i > 0) & !is_black(col) & !dead_u1 & !back_dead;
     }
     return c;
 }
@@ -1080,15 +1082,13 @@ KY_DEV void shape_sample_direction(const DLight& L, f3 p, f3 p_normal, float u0,
     shape_sample_position(L, u0, u1, lposition, lnormal, feat);
     const f3 wv = lposition - p;
     const float d2 = length_sq(wv);
-    if (d2 == 0) {
-        pdf = 0;
-    } else {
-        const f3 wi = wv * rsq(d2);
-        // inside-sphere case divides by the SHADE POINT's normal (quirk, 1436); the base class by the light's (1044)
-        const f3 nn = sphere ? p_normal : lnormal;
-        pdf = L.inv_area * d2 * rcp(fabsf(dot(nn, wi)));
-        if (isinf(pdf)) pdf = 0.f;
-    }
+    // Straight-line (round 5; two nested branches before): a coincident sample (d2 = 0: rsq gives inf, the direction and the quotient NaN) and an infinite quotient (the
+    // direction lies in the light's plane) both mean pdf = 0 (1041-1049) -- one class test on the quotient instead of exec-mask bookkeeping around three instructions.
+    const f3 wi = wv * rsq(d2);
+    // inside-sphere case divides by the SHADE POINT's normal (quirk, 1436); the base class by the light's (1044)
+    const f3 nn = sphere ? p_normal : lnormal;
+    const float q = L.inv_area * d2 * rcp(fabsf(dot(nn, wi)));
+    pdf = (d2 == 0 || __builtin_isinf(q) || q != q) ? 0.f : q;
 }
 
 // shape_t::pdf_direction (1055-1090) and sphere_t::pdf_direction (1503-1513)

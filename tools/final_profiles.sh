@@ -28,6 +28,8 @@ export KYHIP_SPECIALISE=0   # the run-time-dispatched kernel (what the recursive
 run generic --workload cornell --direct-sample 32
 unset KYHIP_SPECIALISE
 run recursion --workload cornell --integrator 9   # one of the recursive integrators on its own instantiation (render_multiple_integrator's cells)
+run stress --workload stress --spp 256 --steps 2   # configs[4]'s geometry at 1/64 of its spp (round 5: its own counter set)
+run batch --workload batch --spp 256 --steps 2     # configs[3]'s six frames at 1/8 of their spp (round 5: its own counter set, summed over the step's kernels)
 ./build_variants/valu_peak > gpurun_out/final/${P}_valu_peak_ubench.txt 2>&1
 ./build_variants/valu_pk > gpurun_out/final/${P}_valu_pk_ubench.txt 2>&1
 ./build_variants/salu_mix > gpurun_out/final/${P}_salu_mix_ubench.txt 2>&1

@@ -23,29 +23,44 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
-SAMPLES = {"cornell": 1024 * 768 * 1024, "veach": 1280 * 720 * 1024, "light_mis": 1024 * 768 * 1024, "generic": 1024 * 768 * 1024, "recursion": 1024 * 768 * 1024}
+SAMPLES = {"cornell": 1024 * 768 * 1024, "veach": 1280 * 720 * 1024, "light_mis": 1024 * 768 * 1024, "generic": 1024 * 768 * 1024, "recursion": 1024 * 768 * 1024,
+           "stress": 4096 * 4096 * 256,                       # configs[4]'s geometry (4096 x 4096, depth 16) at 256 of its 16 384 spp: the kernel's rate does not depend on spp
+           "batch": 1024 * 1024 * (5 * 256 + 1)}              # configs[3]'s six frames at 256 of their 2048 spp (five path frames + the 1-spp AOV pass)
 LABEL = {"cornell": "render_kernel<strategy 48, feat 391 (one rectangle area light that is its own carrier, small tables), integrator 11> on BASELINE configs[1] (Cornell 1024x768x1024)",
          "veach": "render_kernel<strategy 48, deferred shadow rays, feat 228 (sphere lights, no delta lobes, small tables)> on configs[2]'s scene at 1024 spp (Veach 1280x720)",
          "light_mis": "render_kernel<strategy 32> (the light_mis instantiation) on configs[1]'s scene",
          "recursion": "render_kernel<strategy 48, feat 263, integrator 9> (path_tracing_recursion_t) on configs[1]'s scene",
-         "generic": "render_kernel<false,-1> (strategy read at run time; KYHIP_SPECIALISE=0) on configs[1]'s scene with direct_sample light_mis"}
+         "generic": "render_kernel<false,-1> (strategy read at run time; KYHIP_SPECIALISE=0) on configs[1]'s scene with direct_sample light_mis",
+         "stress": "render_kernel<strategy 48, feat 391> on configs[4]'s geometry (Cornell 4096x4096, depth 16) at 256 spp",
+         "batch": "the six launches of configs[3]'s step (four Cornell light variants, Veach square, AOV pass; 1024x1024) at 256 spp: counters summed over its kernels"}
 
 
 def counters(path):
-    out = {}
-    disp = None
-    ms = None
+    """-> ({counter: value per launch SET}, kernel ms per launch set, scratch bytes of the first render_kernel dispatch).
+    A launch set = the render_kernel dispatches of one step of the workload: one for the single-frame workloads, six for the batch (whose frames run on
+    several instantiations: their lines are summed).  The summary lists, per kernel name, the dispatch count and the average per dispatch."""
+    sums, disp, ms_total, calls_total, scratch = {}, {}, 0.0, 0, None
     for line in open(path):
-        m = re.match(r".*render_kernel.*?\s(SQ_[A-Z_0-9]+|FETCH_SIZE|WRITE_SIZE)\s+(\d+)\s+([0-9.]+)\s*$", line)
+        m = re.match(r"(.*render_kernel.*?)\s(SQ_[A-Z_0-9]+|FETCH_SIZE|WRITE_SIZE)\s+(\d+)\s+([0-9.]+)\s*$", line)
         if m:
-            out[m.group(1)] = float(m.group(3))
+            sums[m.group(2)] = sums.get(m.group(2), 0.0) + float(m.group(4)) * int(m.group(3))
+            disp.setdefault(m.group(2), 0)
+            disp[m.group(2)] += int(m.group(3))
         m = re.match(r"void render_kernel.*?\s+(\d+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s*$", line)
         if m:
-            ms = float(m.group(3)) / 1e3
+            calls_total += int(m.group(1))
+            ms_total += float(m.group(2)) / 1e3
         m = re.search(r"render_kernel dispatch: .*scratch=(\d+)", line)
-        if m:
-            disp = int(m.group(1))
-    return out, ms, disp
+        if m and scratch is None:
+            scratch = int(m.group(1))
+    per_set = FRAMES_PER_SET.get(CURRENT[0], 1)
+    out = {k: v * per_set / disp[k] for k, v in sums.items()}
+    ms = (ms_total * per_set / calls_total) if calls_total else None
+    return out, ms, scratch
+
+
+CURRENT = ["cornell"]      # the workload whose files are being read (counters() needs its launches per set)
+FRAMES_PER_SET = {"batch": 6}
 
 
 def ubench(path):
@@ -88,9 +103,10 @@ def main():
         lib_sha = open(os.path.join(PROF, prefix + "_kernel_source_hash.txt")).read().split()[0]
     except Exception:
         lib_sha = None
-    for wl in ("cornell", "veach", "light_mis", "generic", "recursion"):
+    for wl in ("cornell", "veach", "light_mis", "generic", "recursion", "stress", "batch"):
         if not os.path.exists(os.path.join(PROF, "%s_%s_pmc_sq_issue.txt" % (prefix, wl))):
             continue
+        CURRENT[0] = wl
         base = os.path.join(PROF, "%s_%s_" % (prefix, wl))
         issue, _, scratch = counters(base + "pmc_sq_issue.txt")
         mix, _, _ = counters(base + "pmc_sq_mix.txt")

@@ -200,7 +200,7 @@ KY_DEV LdsScene stage_scene(SceneRef S) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// random numbers: one PCG stream per camera sample, keyed (seed, pixel, sample) -- DESIGN.md
+// random numbers: one xoroshiro64+ stream per camera sample, keyed (seed, pixel, sample) -- DESIGN.md section 5
 // sampler_t semantics of ky.cpp:877-975
 // ---------------------------------------------------------------------------------------------
 KY_DEV uint32_t mix32(uint32_t x) {

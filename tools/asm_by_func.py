@@ -28,7 +28,7 @@ m = re.search(r"\n(_Z\w*%s\w*):" % re.escape(key), txt)
 start = m.end(); end = txt.index("s_endpgm", start)
 loc = ("?", 0)
 last = "(kernel prologue)"
-HELPER_END = next(i for i, l in enumerate(open(os.path.join(os.environ.get("KY_SRC_DIR", root), "ky_device.hpp")).read().split("\n"), 1) if "device scene layout" in l)
+HELPER_END = next(i for i, l in enumerate(open(os.path.join(os.environ.get("KY_SRC_DIR", root), "ky_device.hpp")).read().split("\n"), 1) if "device scene layout" in l or "// random numbers:" in l)
 cnt = collections.defaultdict(collections.Counter)
 for l in txt[start:end].split("\n"):
     mm = re.match(r'\s+\.loc\s+(\d+)\s+(\d+)', l)

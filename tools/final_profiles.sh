@@ -40,4 +40,5 @@ python3 bench.py --workload veach --no-extra 2>/dev/null | tail -1 > gpurun_out/
 python3 bench.py --workload batch --no-extra 2>/dev/null | tail -1 > gpurun_out/final/${P}_bench_line_batch.json
 python3 bench.py --workload stress --steps 1 --warmup 0 2>/dev/null | tail -1 > gpurun_out/final/${P}_bench_line_stress.json
 python3 bench.py --workload cornell --direct-sample 32 2>/dev/null | tail -1 > gpurun_out/final/${P}_bench_line_cornell_light_mis.json
+rm -rf gpurun_out/prof_${P}_*   # the raw databases: 3 MB per pass, and gpurun brings home at most 64 MiB
 ls -la gpurun_out/final | tail -40

@@ -31,6 +31,17 @@
 
 #define KY_DEV __device__ __forceinline__
 
+// A/B switches of round 5's second half (each a measured default: docs/rounds/round5.md)
+#ifndef KY_IPDF
+#define KY_IPDF 1
+#endif
+#ifndef KY_AAR_OFFLOOP
+#define KY_AAR_OFFLOOP 1
+#endif
+#ifndef KY_SPH_INVR
+#define KY_SPH_INVR 1
+#endif
+
 // KY_PROBE(k) / KY_CLK(k): lane-utilisation probes and phase clocks of measurement builds (ky_measure.hpp); nothing in product builds
 #if defined(KY_PROFILE_LANES) || defined(KY_PROFILE_CLOCKS) || defined(KY_MARKS)
 #include "ky_measure.hpp"
@@ -150,6 +161,8 @@ struct SceneRef {
     }
     __device__ __forceinline__ bool may_have_env() const { return (feat & (KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_DELTA | KY_FEAT_SPHERE_LIGHTS)) == 0; }
     __device__ __forceinline__ bool sphere_lights() const { return (feat & KY_FEAT_SPHERE_LIGHTS) != 0; }
+    // the light-sampling estimators work with the RECIPROCAL of the light's density (shape_sample_direction): where every light is a sphere lamp
+    __device__ __forceinline__ bool ipdf() const { return KY_IPDF && (feat & KY_FEAT_SPHERE_LIGHTS) != 0; }   // (measured on the one-rectangle-lamp kernel too: configs[1] -0.3 %, not taken)
 };
 
 struct LdsScene {
@@ -355,6 +368,7 @@ KY_DEV const DSurf& scene_surf(SceneRef S, int i) { return scene_at<DSurf>(S, op
 #ifndef KY_CMPX
 #define KY_CMPX 1
 #endif
+
 KY_DEV void hit_update_nearest(unsigned long long ex, float u, float ru, float v, float rv, float t, float& tmax, int& best, int i) {
     unsigned long long tmp;
     asm volatile(
@@ -381,6 +395,11 @@ KY_DEV void hit_update_any(unsigned long long ex, float u, float ru, float v, fl
         : [u] "v"(u), [ru] "s"(ru), [v] "v"(v), [rv] "s"(rv), [t] "v"(t), [tmax] "v"(tmax), [eps] "s"(K_SHAPE_EPS), [ex] "s"(ex));
 }
 
+// Which form the rectangle loops take (a compile-time choice per instantiation, made by measurement: docs/rounds/round5.md): on the record's byte offset alone
+// (one scalar add per record less) in the sphere-light instantiations -- configs[2] +0.75 % -- and on index + offset elsewhere, where the shorter form measured
+// 0.3-0.7 % SLOWER on configs[1] (its register allocation spills one more SGPR in the bookkeeping block).
+KY_DEV bool aar_by_offset(SceneRef S) { return KY_AAR_OFFLOOP && KY_CMPX && S.sphere_lights(); }
+
 // the axis-aligned rectangles of one axis: records [first, first + n) of the table at byte offset `aar_off`, whose sorted surface indices are the same
 template <int AXIS, bool NEAREST>
 KY_DEV void aar_scan(SceneRef S, unsigned aar_off, int first, int n, f3 o, f3 d, f3 inv_d, float& tmax, int& best, unsigned& occ_v) {
@@ -391,6 +410,23 @@ KY_DEV void aar_scan(SceneRef S, unsigned aar_off, int first, int n, f3 o, f3 d,
     const float oa = AXIS == 0 ? o.x : (AXIS == 1 ? o.y : o.z), ia = AXIS == 0 ? inv_d.x : (AXIS == 1 ? inv_d.y : inv_d.z);
     const float ou_ = AXIS == 0 ? o.y : (AXIS == 1 ? o.z : o.x), du_ = AXIS == 0 ? d.y : (AXIS == 1 ? d.z : d.x);
     const float ov_ = AXIS == 0 ? o.z : (AXIS == 1 ? o.x : o.y), dv_ = AXIS == 0 ? d.z : (AXIS == 1 ? d.x : d.y);
+    if (aar_by_offset(S)) {
+        // the loop runs on the record's byte offset alone; a nearest-hit scan notes the surface as that offset (trace_nearest turns it into the index once per traversal)
+        const unsigned end = off + (unsigned)n * (unsigned)sizeof(DAar);
+        do {
+            asm volatile("" : "+s"(off));
+            const DAar& r = scene_at<DAar>(S, off);
+            const float4 q0 = r.q0;
+            const float rv = r.q1.x;
+            const float t = (q0.x - oa) * ia;                 // aar_hit
+            const float u = (ou_ + t * du_) - q0.y;
+            const float v = (ov_ + t * dv_) - q0.w;
+            if (NEAREST) hit_update_nearest(ex, u, q0.z, v, rv, t, tmax, best, (int)off);
+            else hit_update_any(ex, u, q0.z, v, rv, t, tmax, occ_v);
+            off += (unsigned)sizeof(DAar);
+        } while (off != end);
+        return;
+    }
     int i = first;
     for (; i < first + n; ++i) {
         asm volatile("" : "+s"(off));
@@ -507,9 +543,12 @@ KY_DEV int trace_nearest(SceneRef S, f3 o, f3 d, float& tmax) {
         unsigned unused = 0;
         const int n0 = axis.x, n1 = axis.y, n2 = axis.z;
         const unsigned aar_off = t_off + (unsigned)__builtin_offsetof(DTrav, aar);
+        if (aar_by_offset(S)) best = (int)aar_off - (int)sizeof(DAar);   // the scans note a surface as its record's byte offset (aar_scan): "none" is the record before the first
         aar_scan<0, true>(S, aar_off, 0, n0, o, d, inv_d, tmax, best, unused);
         aar_scan<1, true>(S, aar_off, n0, n1, o, d, inv_d, tmax, best, unused);
         aar_scan<2, true>(S, aar_off, n0 + n1, n2, o, d, inv_d, tmax, best, unused);
+        if (aar_by_offset(S)) best = (best - (int)aar_off) >> 5;         // ... and becomes the sorted surface index here, once per traversal (-1: none)
+        static_assert(sizeof(DAar) == 32, "DAar");
     }
     if (n_par > 0) {
         unsigned off = t_off + (unsigned)__builtin_offsetof(DTrav, par);
@@ -1052,7 +1091,10 @@ KY_DEV void shape_sample_position(const DLight& L, float u0, float u1, f3& posit
 }
 
 // shape_t::sample_direction (1028-1051) and sphere_t::sample_direction (1419-1501)
-KY_DEV void shape_sample_direction(const DLight& L, f3 p, f3 p_normal, float u0, float u1, f3& lposition, f3& lnormal, float& pdf, int feat = 0) {
+// `ipdf` (a compile-time constant at every call; the callers that pass true: KY_IPDF): `pdf` receives the RECIPROCAL of the density -- for the cone that is
+// 2 pi (1 - cos theta_max) itself, and the estimators' weights 2 / (p_l + p_b) become 2 x / (1 + p_b x): one quarter-rate reciprocal per light sample instead of two.
+// A density of zero is an infinite reciprocal.
+KY_DEV void shape_sample_direction(const DLight& L, f3 p, f3 p_normal, float u0, float u1, f3& lposition, f3& lnormal, float& pdf, int feat = 0, bool ipdf = false) {
     const bool sphere = (feat & KY_FEAT_SPHERE_LIGHTS) ? true : ((feat & KY_FEAT_RECT_LIGHTS) == 0 && L.shape_kind == KY_SHAPE_SPHERE);
     const f3 c = ld3(L.p1);
     const float dc2 = length_sq(p - c);
@@ -1061,7 +1103,11 @@ KY_DEV void shape_sample_direction(const DLight& L, f3 p, f3 p_normal, float u0,
         const float inv_dist = rsq(dc2);
         const float sin_theta_max = L.radius * inv_dist;
         const float sin_theta_max_sq = sin_theta_max * sin_theta_max;
+#if KY_SPH_INVR
+        const float inv_sin_theta_max = (dc2 * inv_dist) * L.e0[0];   // distance x 1 / radius (the host's, DLight::e0[0] of a sphere light): two multiplies for a quarter-rate reciprocal
+#else
         const float inv_sin_theta_max = rcp(sin_theta_max);
+#endif
         const float cos_theta_max = fsqrt(fmaxf(0.f, 1 - sin_theta_max_sq));
         float cos_theta = (cos_theta_max - 1) * u0 + 1;
         float sin_theta_sq = 1 - cos_theta * cos_theta;
@@ -1076,7 +1122,7 @@ KY_DEV void shape_sample_direction(const DLight& L, f3 p, f3 p_normal, float u0,
         const f3 world_normal = (sin_alpha * cos_rev(u1)) * (-fr.s) + (sin_alpha * sin_rev(u1)) * (-fr.t) + cos_alpha * (-fr.n);  // 431-439
         lposition = c + L.radius * world_normal;
         lnormal = world_normal;
-        pdf = rcp(2 * K_PI * (1 - cos_theta_max));
+        pdf = ipdf ? 2 * K_PI * (1 - cos_theta_max) : rcp(2 * K_PI * (1 - cos_theta_max));
         return;
     }
     shape_sample_position(L, u0, u1, lposition, lnormal, feat);
@@ -1087,30 +1133,40 @@ KY_DEV void shape_sample_direction(const DLight& L, f3 p, f3 p_normal, float u0,
     const f3 wi = wv * rsq(d2);
     // inside-sphere case divides by the SHADE POINT's normal (quirk, 1436); the base class by the light's (1044)
     const f3 nn = sphere ? p_normal : lnormal;
+    if (ipdf) {
+        // the reciprocal density area |cos| / d^2 from the reciprocal root the direction was made with: no further quarter-rate instruction.  A coincident sample
+        // (r = inf, the cosine NaN) and a direction in the light's plane (cosine 0) are not positive: "density zero"
+        const float r = rsq(d2);
+        const float x = (L.area * fabsf(dot(nn, wi))) * (r * r);
+        pdf = x > 0.f ? x : K_INF;
+        return;
+    }
     const float q = L.inv_area * d2 * rcp(fabsf(dot(nn, wi)));
     pdf = (d2 == 0 || __builtin_isinf(q) || q != q) ? 0.f : q;
 }
 
 // shape_t::pdf_direction (1055-1090) and sphere_t::pdf_direction (1503-1513)
-KY_DEV float shape_pdf_direction(const DLight& L, const DShapeFull* __restrict__ full, f3 p, f3 p_normal, f3 wi, bool general = true, int feat = 0) {
+KY_DEV float shape_pdf_direction(const DLight& L, const DShapeFull* __restrict__ full, f3 p, f3 p_normal, f3 wi, bool general = true, int feat = 0, bool ipdf = false) {
     const bool sphere = (feat & KY_FEAT_SPHERE_LIGHTS) ? true : ((feat & KY_FEAT_RECT_LIGHTS) == 0 && L.shape_kind == KY_SHAPE_SPHERE);
     const f3 c = ld3(L.p1);
     const float dc2 = length_sq(p - c);
     if (sphere && !(dc2 <= L.radius * L.radius)) {
         const float sin_theta_max_sq = L.radius * L.radius * rcp(dc2);
         const float cos_theta_max = fsqrt(fmaxf(0.f, 1 - sin_theta_max_sq));
-        return rcp(2 * K_PI * (1 - cos_theta_max));  // uniform_cone_pdf, 798; never tests the hit (quirk 13)
+        const float x = 2 * K_PI * (1 - cos_theta_max);
+        return ipdf ? x : rcp(x);  // uniform_cone_pdf, 798; never tests the hit (quirk 13)
     }
+
     // base class: re-intersect the light's OWN shape with isect.spawn_ray(wi)
     const f3 o = offset_ray_origin(p, p_normal, wi);
     float t;
-    if (!surf_hit(L.isect, full, o, wi, K_INF, t, general)) return 0.f;
+    if (!surf_hit(L.isect, full, o, wi, K_INF, t, general)) return ipdf ? K_INF : 0.f;
     const f3 hp = o + t * wi;
     f3 ln = ld3(L.n);
     if (sphere) ln = normalize(hp - c);
     float pdf = length_sq(p - hp) * rcp(fabsf(dot(ln, wi)) * L.area);   // |dot| makes the ray-facing flip (1289) irrelevant
     if (isinf(pdf)) pdf = 0.f;
-    return pdf;
+    return ipdf ? rcp(pdf) : pdf;
 }
 
 // environment_light_t's pdf (3032-3036, 3046-3052): 1 / (2 pi^2 sin(theta)), theta = acos(clamp(wi.z)):
@@ -1122,17 +1178,17 @@ KY_DEV float env_pdf(float wz) {
 }
 
 // light_t::sample_Li x4 (2825, 2891, 2964, 3026)
-KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0, float u1, int feat = 0) {
+KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0, float u1, int feat = 0, bool ipdf = false) {
     LightSample s;   // every kind (wave-uniform) assigns every field
     s.lit = true;
     const SceneRef K{nullptr, false, feat};   // the kind predicates only
     if (K.is_area(L.kind)) {
         f3 lposition, lnormal;
-        shape_sample_direction(L, p, p_normal, u0, u1, lposition, lnormal, s.pdf, feat);
+        shape_sample_direction(L, p, p_normal, u0, u1, lposition, lnormal, s.pdf, feat, ipdf);
         s.position = lposition;
         const f3 dv = lposition - p;
         const float d2 = length_sq(dv);
-        const bool ok = !(s.pdf == 0 || d2 == 0);
+        const bool ok = !((ipdf ? __builtin_isinf(s.pdf) : s.pdf == 0) || d2 == 0);
         const f3 wi = dv * rsq(d2);
         s.wi = mk3(ok ? wi.x : 0.f, ok ? wi.y : 0.f, ok ? wi.z : 0.f);
         // areal_radiance(light_isect, -wi) with the SAMPLED (stored) normal: one-sided (quirk 5), 2957-2960
@@ -1164,9 +1220,9 @@ KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0,
 }
 
 // light_t::pdf_Li x4 (2855, 2903, 2984, 3043)
-KY_DEV float light_pdf_Li(const DLight& L, const DShapeFull* __restrict__ full, f3 p, f3 p_normal, f3 wi, bool general = true, int feat = 0) {
+KY_DEV float light_pdf_Li(const DLight& L, const DShapeFull* __restrict__ full, f3 p, f3 p_normal, f3 wi, bool general = true, int feat = 0, bool ipdf = false) {
     const SceneRef K{nullptr, false, feat};
-    if (K.is_area(L.kind)) return shape_pdf_direction(L, full, p, p_normal, wi, general, feat);
+    if (K.is_area(L.kind)) return shape_pdf_direction(L, full, p, p_normal, wi, general, feat, ipdf);
     if (K.is_env(L.kind)) return env_pdf(wi.z);
     return 0;
 }
@@ -1355,11 +1411,19 @@ KY_DEV void estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f
             float light_pdf;
             if (fast && L.pdf_from_carrier) {   // (wave-uniform) shape_t::pdf_direction, 1055-1090, from the hit the carrier test found
                 const f3 hp = o + t_l * bs.wi;
-                light_pdf = length_sq(v.position - hp) * rcp(fabsf(dot(ld3(L.n), bs.wi)) * L.area);
-                if (isinf(light_pdf)) light_pdf = 0.f;
+                if (S.ipdf()) {   // its reciprocal (an infinite density -- cosine zero -- counts as zero, 1086-1088: both are "not positive" here)
+                    light_pdf = (fabsf(dot(ld3(L.n), bs.wi)) * L.area) * rcp(length_sq(v.position - hp));
+                    if (!(light_pdf > 0.f)) light_pdf = K_INF;
+                } else {
+                    light_pdf = length_sq(v.position - hp) * rcp(fabsf(dot(ld3(L.n), bs.wi)) * L.area);
+                    if (isinf(light_pdf)) light_pdf = 0.f;
+                }
             } else {
-                light_pdf = light_pdf_Li(L, S->full, v.position, v.normal, bs.wi, S.general, S.feat);
+                light_pdf = light_pdf_Li(L, S->full, v.position, v.normal, bs.wi, S.general, S.feat, S.ipdf());
             }
+            if (S.ipdf()) {   // light_pdf is the density's reciprocal x: 2 / (p_b + 1 / x) = 2 x / (p_b x + 1); a density of zero is x = inf
+                if (light_pdf < K_INF) acc = acc + w * ((f_cos * Li) * ((2.f * light_pdf) * rcp(bs.pdf * light_pdf + 1.f)));
+            } else
             if (light_pdf > 0) acc = acc + w * ((f_cos * Li) * (2.f * rcp(bs.pdf + light_pdf)));  // 4028
         } else {
             acc = acc + w * ((f_cos * Li) * rcp(bs.pdf));  // 3924
@@ -1501,7 +1565,8 @@ KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, f3 wo, int
         // Straight-line from here: every lane runs every instruction and `push` says whether its values mean anything.  (Skipping the
         // work of a dead sample would need ALL lanes of the wave dead; the nested version paid for its structure with defaults and
         // exec-mask bookkeeping at every level instead.)
-        const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1, S.feat);
+        const bool ip = S.ipdf();   // (compile-time) ls.pdf is the density's reciprocal: shape_sample_direction
+        const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1, S.feat, ip);
         // scene_t::occluded(isect, ls.position), 3187-3201: the ray
         const f3 to = ls.position - v.position;
         const float d2 = length_sq(to);
@@ -1517,13 +1582,15 @@ KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, f3 wo, int
         // f |cos| Li / pdf (3956) or 2 f |cos| Li / (p_l + p_b) (4057 / 4070), times throughput and strategy weight: the scalar factors first, the three channels once;
         // an area light's Li is its colour where the sample is lit (a wave-uniform value: scalar operands) and the predicate below says whether it is
         const float fc = scale * abs_cos_i;   // f |cos| = col x fc
-        const float k = fc * ((!MIS || delta_light) ? rcp(ls.pdf) : 2.f * rcp(ls.pdf + bsdf_pdf)) * weight;
+        const float k = fc * (ip ? ((!MIS || delta_light) ? ls.pdf : (2.f * ls.pdf) * rcp(1.f + bsdf_pdf * ls.pdf))
+                                 : ((!MIS || delta_light) ? rcp(ls.pdf) : 2.f * rcp(ls.pdf + bsdf_pdf))) * weight;
         const bool area = S.is_area(L.kind);
         const f3 Li = area ? ld3(L.color) : ls.Li;
         r.c = ((col * Li) * beta) * k;
         // !is_black(f |cos|) (3952 / 4052) without the product: a positive factor (a Phong lobe's odd power of a negative cosine is negative: black) and a material that is
         // not black; a NaN factor counts.  (A light whose colour is not finite must not meet a zero here: 0 x inf.)
-        push = (area ? ls.lit : !is_black(ls.Li)) && !(MIS ? ls.pdf <= 0 : ls.pdf == 0) && !(fc <= 0.f) && !is_black(col);
+        // (with reciprocal densities every light is an area light, whose `lit` already says that the density is not zero)
+        push = (area ? ls.lit : !is_black(ls.Li)) && (ip || !(MIS ? ls.pdf <= 0 : ls.pdf == 0)) && !(fc <= 0.f) && !is_black(col);
         // the sampled shape itself is the likeliest occluder (quirk 1): one test here saves the ray a full traversal
         if (S.is_area(L.kind) && L.sampled_is_surface) {   // wave-uniform
             float t;
@@ -1555,9 +1622,10 @@ template <bool MIS>
 KY_DEV void estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, int li, float u0, float u1, f3& acc, f3 w) {
     const DLight& L = scene_light(S, li);
     KY_PROBE(3);
-    const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1, S.feat);
+    const bool ip = S.ipdf();   // (compile-time) ls.pdf is the density's reciprocal: shape_sample_direction
+    const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1, S.feat, ip);
     const bool area = S.is_area(L.kind);   // (wave-uniform)
-    const bool dead = (area ? !ls.lit : is_black(ls.Li)) || (MIS ? (ls.pdf <= 0) : (ls.pdf == 0));
+    const bool dead = (area ? !ls.lit : is_black(ls.Li)) || (!ip && (MIS ? (ls.pdf <= 0) : (ls.pdf == 0)));   // (an area light's `lit` says that the density is not zero)
     KY_CLK(5);
     if (!dead) {
         // scene_t::occluded(isect, ls.position), 3187-3201
@@ -1580,7 +1648,8 @@ KY_DEV void estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v
             if (!(fc <= 0.f) && !is_black(col)) {    // !is_black(f |cos|), 3952 / 4052: some channel positive (colours are not negative; a NaN factor counts)
                 const bool delta_light = S.is_delta(L.kind);
                 // 3956 / 4057 / 4070, the scalar factors first; an area light's Li is its colour where the sample is lit (wave-uniform: scalar operands)
-                const float k = fc * ((!MIS || delta_light) ? rcp(ls.pdf) : 2.f * rcp(ls.pdf + bsdf_pdf));
+                const float k = fc * (ip ? ((!MIS || delta_light) ? ls.pdf : (2.f * ls.pdf) * rcp(1.f + bsdf_pdf * ls.pdf))
+                                         : ((!MIS || delta_light) ? rcp(ls.pdf) : 2.f * rcp(ls.pdf + bsdf_pdf)));
                 acc = acc + ((col * (area ? ld3(L.color) : ls.Li)) * w) * k;
             }
             KY_CLK(7);

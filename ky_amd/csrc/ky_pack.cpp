@@ -531,6 +531,7 @@ int pack_scene(const ky_scene* in, DScene* out) {
                 cp3(d.p1, sh.p[0]); cp3(d.e0, sh.p[1]); cp3(d.e1, sh.p[2]);
             } else {
                 cp3(d.p1, sh.p[0]);
+                if (sh.kind == KY_SHAPE_SPHERE) d.e0[0] = 1.f / sh.radius;   // sphere lights: 1 / radius (the cone sampler's 1 / sin(theta_max) = distance / radius)
             }
             pack_shape(sh, KYHIP_MAX_SURFACES + i, &d.isect, &out->full[KYHIP_MAX_SURFACES + i]);
             if (d.isect.kind != TK_PARALLELOGRAM && d.isect.kind != TK_SPHERE) out->general = 1;   // a quad / triangle / disk light

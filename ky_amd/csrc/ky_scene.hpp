@@ -84,7 +84,7 @@ struct DLight {  // light_t + the shape an area light samples; wave-uniform inde
     int32_t shape_kind;   // ky_shape_kind of the sampled shape
     float p1[3];          // rectangle: p1, e0 = p0 - p1, e1 = p2 - p1 (1310); triangle: p0, p1, p2; sphere / disk: centre
     float radius;
-    float e0[3];
+    float e0[3];          // (a sphere light: e0[0] = 1 / radius)
     float area;
     float e1[3];
     float inv_area;

@@ -95,6 +95,7 @@ ITER = {"cornell": 4.168, "veach": 2.711, "cornell_d16": 4.266, "cornell_other_l
 # loaded kernels (`valu_model_exceeds_executed`), and reports the executed fraction (`lane_slot_frac`) beside `frac`.
 LANE_OP = {
     "aar_test": 12,        # rectangle in an axis plane, incl. the nearest / any update: sub, mul, 2 x (fma, sub), 4 compares, 2 moves
+    "box_test": 40,        # up to six rectangles that are whole faces of one axis-aligned box (round 5, DESIGN.md 3 "boxes"): 6 x (sub, mul), 6 tags, 3 min, 3 max, max3, min3, 2 x (and, 4 compares, 2 moves)
     "par_test": 26,        # planar parallelogram: 2 dots (6), rcp, mul, hit point (3), 2 dual-basis dots + offsets (8), 4 compares, 2 moves
     "sphere_test": 21,     # oc (3), b (3), |oc|^2 (3), discriminant (2), sqrt, 2 roots, 4 compares, select, 2 selects
     "sphere_reject": 11,   # the same up to the discriminant's sign (a lamp that subtends a thousandth of the directions: sph_hit's `sparse` form)
@@ -111,16 +112,17 @@ LANE_OP = {
     "rng_draw": 8,         # xoroshiro64+ (add, xor, 2 rotates, shift, three-way xor) incl. the two-instruction conversion to [0, 1)
     "film": 4,             # Lo / spp into the pixel's sum
 }
-# per frame: the whole scene (rectangles in an axis plane, other parallelograms, spheres), the light kind of each light estimate, what an MIS BSDF ray must
+# per frame: the whole scene (rectangles in an axis plane that are no box's face, other parallelograms, spheres, boxes: the Cornell room's five walls are one box,
+# the lamp housing's five rectangles another -- 40 lane-instructions instead of 5 x 12, so the floor prices the box), the light kind of each light estimate, what an MIS BSDF ray must
 # test (LANE_OP key; None: the light has no BSDF-sampling half or no carrier surface), and the occluder table an UNOCCLUDED shadow ray scans (same triple;
 # spheres of a sphere-lights scene at the reject price).  The Cornell lamp's table is DScene::occ_front (the lamp's rectangle + the two balls); the delta
 # lights' is DScene::occ (the room's five walls proved away: two balls); the environment light's rays leave the room: every surface; Veach: no wall
 # qualifies (its floor reaches under the back wall), every surface.
 SCENE_SHAPES = {
-    "cornell": ((10, 0, 2), "rect", "par_test", (1, 0, 2)), "cornell_area": ((10, 0, 2), "rect", "par_test", (1, 0, 2)), "cornell_d16": ((10, 0, 2), "rect", "par_test", (1, 0, 2)),
-    "cornell_point": ((5, 0, 2), "point", None, (0, 0, 2)), "cornell_direction": ((5, 0, 2), "direction", None, (5, 0, 2)),
-    "cornell_environment": ((5, 0, 2), "environment", None, (5, 0, 2)),
-    "veach": ((2, 4, 5), "sphere", "sphere_reject", (2, 4, 5)), "veach_square": ((2, 4, 5), "sphere", "sphere_reject", (2, 4, 5)),
+    "cornell": ((0, 0, 2, 2), "rect", "par_test", (1, 0, 2)), "cornell_area": ((0, 0, 2, 2), "rect", "par_test", (1, 0, 2)), "cornell_d16": ((0, 0, 2, 2), "rect", "par_test", (1, 0, 2)),
+    "cornell_point": ((0, 0, 2, 1), "point", None, (0, 0, 2)), "cornell_direction": ((0, 0, 2, 1), "direction", None, (5, 0, 2)),
+    "cornell_environment": ((0, 0, 2, 1), "environment", None, (5, 0, 2)),
+    "veach": ((2, 4, 5, 0), "sphere", "sphere_reject", (2, 4, 5)), "veach_square": ((2, 4, 5, 0), "sphere", "sphere_reject", (2, 4, 5)),
 }
 
 
@@ -137,9 +139,9 @@ def useful_lane_ops(label, counters):
     c = counters.get(label)
     if not c or label not in SCENE_SHAPES:
         return None, None
-    (n_aar, n_par, n_sph), light, mis_test, (o_aar, o_par, o_sph) = SCENE_SHAPES[label]
+    (n_aar, n_par, n_sph, n_box), light, mis_test, (o_aar, o_par, o_sph) = SCENE_SHAPES[label]
     sphere_lamps = light == "sphere"
-    per_nearest = n_aar * LANE_OP["aar_test"] + n_par * LANE_OP["par_test"] + n_sph * LANE_OP["sphere_test"] + LANE_OP["traversal_setup"]
+    per_nearest = (n_aar * LANE_OP["aar_test"] + n_par * LANE_OP["par_test"] + n_sph * LANE_OP["sphere_test"] + n_box * LANE_OP["box_test"] + LANE_OP["traversal_setup"])
     per_unoccluded = (o_aar * LANE_OP["aar_test"] + o_par * LANE_OP["par_test"] + o_sph * LANE_OP["sphere_reject" if sphere_lamps else "sphere_test"]
                       + LANE_OP["traversal_setup"])
     per_occluded = LANE_OP["sphere_test"] if sphere_lamps else LANE_OP["aar_test"]   # the blocker itself: a lamp's own sphere (quirk 1) / the Cornell lamp's rectangle

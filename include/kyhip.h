@@ -195,6 +195,12 @@ int         kyhip_set_engine(int engine);
    compiler contracts a few multiply-adds differently once code around them is gone).  Returns the previous setting.
    A tuning knob, like kyhip_set_engine. */
 int         kyhip_set_specialisation(int on);
+/* Boxes: axis-aligned rectangles that are whole faces of a common axis-aligned box -- the five walls of a Cornell box, its lamp housing -- are tested by the
+   nearest-hit traversal with ONE slab test per box instead of face by face (kernels with the fact KY_FEAT_BOXES; kyhip_scene_boxes says which surfaces).  The slab
+   test's hit distance differs from the rectangle test's by up to 15 units in the last place, so unlike the switch above this one moves an image beyond its last bit
+   (tests/test_boxes.py: by how much).  on = 1 (default; environment variable KYHIP_BOXES=0 turns it off) / off = 0; needs kyhip_set_specialisation(1).  Returns the
+   previous setting.  A tuning knob. */
+int         kyhip_set_boxes(int on);
 /* Deferred shadow rays (the render kernels' QUEUE instantiations: light samples wait on a per-wavefront stack until 64 of them fill a traversal).
    mode -1 (default): by the scene -- when its sphere area lights outnumber its point / directional lights by five or more (create_mis_scene's five
    lamps; measured crossing, tools/queue_policy.py); 0: never; 1: for every scene with lights.  The environment variable KYHIP_SHADOW_QUEUE = 0 / 1 sets the
@@ -356,6 +362,11 @@ int kyhip_kat_occluded_between(int device, const ky_scene* scene, int light, con
    what is mounted behind a lamp), 0 when it is always tested.  n = entries in left_out, at least scene->surface_count.  Returns the
    number of 1s, or a negative ky_status. */
 int kyhip_scene_non_occluders(const ky_scene* scene, int light, int* left_out, int n);
+/* Host only (no GPU needed): the axis-aligned boxes whose faces are surfaces of the scene, which a nearest-hit traversal (scene_t::intersect, ky.cpp:3172-3184) tests
+   with one slab test each instead of face by face ("boxes"): box_face[i] = 8 * box + 2 * axis + side (side 0: the box's low plane on that axis, 1: its high
+   plane) when surface i (the caller's index) is such a face, -1 otherwise.  n = entries in box_face, at least scene->surface_count.  Returns the number of boxes
+   (0 with kyhip_set_specialisation(0)), or a negative ky_status. */
+int kyhip_scene_boxes(const ky_scene* scene, int* box_face, int n);
 
 /* integrator_t::Li per camera sample (3714-3717): for pixel (x, y) and samples [s0, s0+n) writes the
    unclamped radiance Li (3 floats per sample) -- the quantity `dL` is built from. */

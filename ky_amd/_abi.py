@@ -92,6 +92,7 @@ KYHIP_SYMBOLS = {
     "kyhip_last_error": (C.c_char_p, []),
     "kyhip_set_engine": (C.c_int, [C.c_int]),
     "kyhip_set_specialisation": (C.c_int, [C.c_int]),
+    "kyhip_set_boxes": (C.c_int, [C.c_int]),
     "kyhip_set_shadow_queue": (C.c_int, [C.c_int]),
     "kyhip_set_jit": (C.c_int, [C.c_int]),
     "kyhip_jit_status": (C.c_char_p, []),
@@ -128,6 +129,7 @@ KYHIP_SYMBOLS = {
     "kyhip_kat_occluded": (C.c_int, [C.c_int, SP, C.c_void_p, C.c_int, C.c_void_p]),
     "kyhip_kat_occluded_between": (C.c_int, [C.c_int, SP, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "kyhip_scene_non_occluders": (C.c_int, [SP, C.c_int, C.c_void_p, C.c_int]),
+    "kyhip_scene_boxes": (C.c_int, [SP, C.c_void_p, C.c_int]),
     "kyhip_kat_li": (C.c_int, [C.c_int, SP, PP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 

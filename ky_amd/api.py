@@ -222,6 +222,18 @@ def scene_non_occluders(scene, light=-1):
     return out[:n].copy()
 
 
+def scene_boxes(scene):
+    """kyhip_scene_boxes (host only): (number of boxes, per surface 8 * box + 2 * axis + side for a surface that is a whole face of an axis-aligned box
+    the nearest-hit traversal tests with one slab test, -1 otherwise)."""
+    lib = A.load_kyhip()
+    n = _scene_ptr(scene).contents.surface_count
+    out = np.zeros(max(1, n), np.int32)
+    rc = lib.kyhip_scene_boxes(_scene_ptr(scene), out.ctypes.data_as(C.c_void_p), n)
+    if rc < 0:
+        _check(rc)
+    return rc, out[:n].copy()
+
+
 def kat_li(scene, params, x, y, s0, n, device=0):
     lib = A.load_kyhip()
     out = np.zeros((n, 3), np.float32)

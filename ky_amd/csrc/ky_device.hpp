@@ -161,6 +161,7 @@ struct SceneRef {
     }
     __device__ __forceinline__ bool may_have_env() const { return (feat & (KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_DELTA | KY_FEAT_SPHERE_LIGHTS)) == 0; }
     __device__ __forceinline__ bool sphere_lights() const { return (feat & KY_FEAT_SPHERE_LIGHTS) != 0; }
+    __device__ __forceinline__ bool boxes() const { return (feat & KY_FEAT_BOXES) != 0; }   // nearest-hit traversals scan DScene::boxtrav
     // the light-sampling estimators work with the RECIPROCAL of the light's density (shape_sample_direction): where every light is a sphere lamp
     __device__ __forceinline__ bool ipdf() const { return KY_IPDF && (feat & KY_FEAT_SPHERE_LIGHTS) != 0; }   // (measured on the one-rectangle-lamp kernel too: configs[1] -0.3 %, not taken)
 };
@@ -396,7 +397,7 @@ KY_DEV void hit_update_any(unsigned long long ex, float u, float ru, float v, fl
 }
 
 // Which form the rectangle loops take (a compile-time choice per instantiation, made by measurement: docs/rounds/round5.md): on the record's byte offset alone
-// (one scalar add per record less) in the sphere-light instantiations -- configs[2] +0.75 % -- and on index + offset elsewhere, where the shorter form measured
+// (one scalar add per record less) in the sphere-light instantiations -- configs[2] +0.75 % -- and on a counter + offset elsewhere, where the shorter form measured
 // 0.3-0.7 % SLOWER on configs[1] (its register allocation spills one more SGPR in the bookkeeping block).
 KY_DEV bool aar_by_offset(SceneRef S) { return KY_AAR_OFFLOOP && KY_CMPX && S.sphere_lights(); }
 
@@ -411,7 +412,7 @@ KY_DEV void aar_scan(SceneRef S, unsigned aar_off, int first, int n, f3 o, f3 d,
     const float ou_ = AXIS == 0 ? o.y : (AXIS == 1 ? o.z : o.x), du_ = AXIS == 0 ? d.y : (AXIS == 1 ? d.z : d.x);
     const float ov_ = AXIS == 0 ? o.z : (AXIS == 1 ? o.x : o.y), dv_ = AXIS == 0 ? d.z : (AXIS == 1 ? d.x : d.y);
     if (aar_by_offset(S)) {
-        // the loop runs on the record's byte offset alone; a nearest-hit scan notes the surface as that offset (trace_nearest turns it into the index once per traversal)
+        // the loop runs on the record's byte offset alone
         const unsigned end = off + (unsigned)n * (unsigned)sizeof(DAar);
         do {
             asm volatile("" : "+s"(off));
@@ -421,7 +422,7 @@ KY_DEV void aar_scan(SceneRef S, unsigned aar_off, int first, int n, f3 o, f3 d,
             const float t = (q0.x - oa) * ia;                 // aar_hit
             const float u = (ou_ + t * du_) - q0.y;
             const float v = (ov_ + t * dv_) - q0.w;
-            if (NEAREST) hit_update_nearest(ex, u, q0.z, v, rv, t, tmax, best, (int)off);
+            if (NEAREST) hit_update_nearest(ex, u, q0.z, v, rv, t, tmax, best, __float_as_int(r.q1.y));   // the surface's sorted index travels in its record
             else hit_update_any(ex, u, q0.z, v, rv, t, tmax, occ_v);
             off += (unsigned)sizeof(DAar);
         } while (off != end);
@@ -436,7 +437,7 @@ KY_DEV void aar_scan(SceneRef S, unsigned aar_off, int first, int n, f3 o, f3 d,
         const float t = (q0.x - oa) * ia;                 // aar_hit
         const float u = (ou_ + t * du_) - q0.y;
         const float v = (ov_ + t * dv_) - q0.w;
-        if (NEAREST) hit_update_nearest(ex, u, q0.z, v, rv, t, tmax, best, i);
+        if (NEAREST) hit_update_nearest(ex, u, q0.z, v, rv, t, tmax, best, __float_as_int(r.q1.y));   // the surface's sorted index travels in its record
         else hit_update_any(ex, u, q0.z, v, rv, t, tmax, occ_v);
         off += (unsigned)sizeof(DAar);
     }
@@ -450,7 +451,7 @@ KY_DEV void aar_scan(SceneRef S, unsigned aar_off, int first, int n, f3 o, f3 d,
         const bool ok = aar_hit<AXIS>(q0, ov, o, d, inv_d, tmax, t);
         if (NEAREST) {
             tmax = ok ? t : tmax;
-            best = ok ? i : best;
+            best = ok ? __float_as_int(r.q1.y) : best;
         } else {
             occ_v |= ok ? 1u : 0u;
         }
@@ -522,6 +523,45 @@ KY_DEV void sph_update_any(unsigned long long ex, float neg_b, float discr, floa
         : "vcc");
 }
 
+// A box's faces in one slab test (DBox, ky_scene.hpp; host: find_boxes).  A ray meets the boundary of a convex box at the two ends of the segment it has inside
+// it: where it enters -- the LARGEST of the three near-plane distances -- and where it leaves -- the smallest of the three far-plane distances --, and it meets
+// the box at all iff enter <= leave.  So the nearest hit among up to six rectangles that are whole faces is: the entry point if its face is a surface and its
+// distance lies in (eps, tmax), else the exit point under the same conditions (a ray from inside, or one that came in through an open side).
+// Which SURFACE a distance belongs to travels IN the distance: its four lowest mantissa bits are replaced by the face's sorted surface index (15: an open side)
+// before the min / max network, which costs the hit distance up to fifteen units in the last place (1.8e-6 relative) and saves carrying six indices through
+// twelve selects and looking the winner's surface up.  The distances are (c - o) * (1 / d) like the rectangle test's, with 1 / d clamped to +-1e30 so that a
+// ray parallel to a pair of planes gives +-huge, not inf - inf.
+// min / max as asm: the compiler's fminf / fmaxf add a canonicalising v_max_f32 x, x per operand it cannot prove quiet (the tagged values are bit patterns to it).
+KY_DEV float vmin(float a, float b) { float r; asm("v_min_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+KY_DEV float vmax(float a, float b) { float r; asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+KY_DEV float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+KY_DEV float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+KY_DEV float face_tag(float t, float surface_bits) { return __uint_as_float((__float_as_uint(t) & ~15u) | __float_as_uint(surface_bits)); }   // v_and_or_b32 (the surface from its SGPR)
+// one candidate (the entry or the exit point) as a v_cmpx chain like hit_update_nearest's: the box is met, eps < t < tmax, the face is a surface
+KY_DEV void box_candidate(unsigned long long ex, float t_enter, float t_leave, float t, float& tmax, int& best) {
+    unsigned long long tmp;
+    const unsigned surface = __float_as_uint(t) & 15u;
+    asm volatile(
+        "v_cmpx_le_f32_e64 %[tmp], %[te], %[tl]\n\t"
+        "v_cmpx_lt_f32_e64 %[tmp], %[eps], %[t]\n\t"
+        "v_cmpx_lt_f32_e64 %[tmp], %[t], %[tmax]\n\t"
+        "v_cmpx_ne_u32_e64 %[tmp], %[none], %[s]\n\t"
+        "v_mov_b32_e32 %[tmax], %[t]\n\t"
+        "v_mov_b32_e32 %[best], %[s]\n\t"
+        "s_mov_b64 exec, %[ex]"
+        : [tmax] "+v"(tmax), [best] "+v"(best), [tmp] "=&s"(tmp)
+        : [te] "v"(t_enter), [tl] "v"(t_leave), [t] "v"(t), [s] "v"(surface), [eps] "s"(K_SHAPE_EPS), [none] "n"(KY_BOX_NO_FACE), [ex] "s"(ex));
+}
+KY_DEV void box_update_nearest(unsigned long long ex, const float4 q0, const float4 q1, const float4 q2, f3 o, f3 inv_c, float& tmax, int& best) {
+    const float xl = face_tag((q0.x - o.x) * inv_c.x, q0.w), xh = face_tag((q1.x - o.x) * inv_c.x, q1.w);
+    const float yl = face_tag((q0.y - o.y) * inv_c.y, q2.x), yh = face_tag((q1.y - o.y) * inv_c.y, q2.y);
+    const float zl = face_tag((q0.z - o.z) * inv_c.z, q2.z), zh = face_tag((q1.z - o.z) * inv_c.z, q2.w);
+    const float t_enter = vmax3(vmin(xl, xh), vmin(yl, yh), vmin(zl, zh));
+    const float t_leave = vmin3(vmax(xl, xh), vmax(yl, yh), vmax(zl, zh));
+    box_candidate(ex, t_enter, t_leave, t_enter, tmax, best);
+    box_candidate(ex, t_enter, t_leave, t_leave, tmax, best);   // (after a hit at the entry point tmax <= t_leave: the chain's third compare keeps the entry)
+}
+
 // one shape given as a generic record (KAT entry point, light shapes re-intersected by pdf_direction)
 // `general` false: the caller knows the record is a parallelogram or a sphere (SceneRef::general)
 KY_DEV bool surf_hit(const DSurf& S, const DShapeFull* __restrict__ full, f3 o, f3 d, float tmax, float& t_out, bool general = true, bool sphere_only = false, bool sparse = true) {
@@ -538,17 +578,36 @@ KY_DEV int trace_nearest(SceneRef S, f3 o, f3 d, float& tmax) {
     const unsigned t_off = opaque_off((unsigned)__builtin_offsetof(DScene, trav));
     const int4 head = scene_at<int4>(S, t_off), axis = scene_at<int4>(S, t_off + 16u);   // n_aar, n_par; n_aar_axis[3]
     const int n_aar = head.x, n_par = head.y, n_sph = S->n_sph, n_gen = S->n_gen;
+    if (S.boxes()) {   // KY_FEAT_BOXES: the boxes whole, then the rectangles that are no box's face (DScene::boxtrav)
+        const unsigned b_off = opaque_off((unsigned)__builtin_offsetof(DScene, boxtrav));
+        const int4 bhead = scene_at<int4>(S, b_off), baxis = scene_at<int4>(S, b_off + 16u);   // n_box, n_aar; n_aar_axis[3]
+        const f3 inv_d = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
+        const f3 inv_c = mk3(__builtin_amdgcn_fmed3f(inv_d.x, -1e30f, 1e30f), __builtin_amdgcn_fmed3f(inv_d.y, -1e30f, 1e30f), __builtin_amdgcn_fmed3f(inv_d.z, -1e30f, 1e30f));
+        const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
+        unsigned off = b_off + (unsigned)__builtin_offsetof(DBoxTrav, box);
+        for (int k = 0; k < bhead.x; ++k) {
+            asm volatile("" : "+s"(off));
+            const DBox& B = scene_at<DBox>(S, off);
+            box_update_nearest(ex, B.q0, B.q1, B.q2, o, inv_c, tmax, best);
+            off += (unsigned)sizeof(DBox);
+        }
+        if (bhead.y > 0) {
+            unsigned unused = 0;
+            const int n0 = baxis.x, n1 = baxis.y, n2 = baxis.z;
+            const unsigned aar_off = b_off + (unsigned)__builtin_offsetof(DBoxTrav, aar);
+            aar_scan<0, true>(S, aar_off, 0, n0, o, d, inv_d, tmax, best, unused);
+            aar_scan<1, true>(S, aar_off, n0, n1, o, d, inv_d, tmax, best, unused);
+            aar_scan<2, true>(S, aar_off, n0 + n1, n2, o, d, inv_d, tmax, best, unused);
+        }
+    } else
     if (n_aar > 0) {
         const f3 inv_d = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
         unsigned unused = 0;
         const int n0 = axis.x, n1 = axis.y, n2 = axis.z;
         const unsigned aar_off = t_off + (unsigned)__builtin_offsetof(DTrav, aar);
-        if (aar_by_offset(S)) best = (int)aar_off - (int)sizeof(DAar);   // the scans note a surface as its record's byte offset (aar_scan): "none" is the record before the first
         aar_scan<0, true>(S, aar_off, 0, n0, o, d, inv_d, tmax, best, unused);
         aar_scan<1, true>(S, aar_off, n0, n1, o, d, inv_d, tmax, best, unused);
         aar_scan<2, true>(S, aar_off, n0 + n1, n2, o, d, inv_d, tmax, best, unused);
-        if (aar_by_offset(S)) best = (best - (int)aar_off) >> 5;         // ... and becomes the sorted surface index here, once per traversal (-1: none)
-        static_assert(sizeof(DAar) == 32, "DAar");
     }
     if (n_par > 0) {
         unsigned off = t_off + (unsigned)__builtin_offsetof(DTrav, par);

@@ -46,6 +46,13 @@ struct NonOccluders {
     std::vector<char> ts_behind;             // [surface]
 };
 void find_non_occluders(const ky_scene* in, NonOccluders& R);
+// Axis-aligned boxes whose faces are surfaces of the scene (DBox, ky_scene.hpp): which, and which surface is which face.
+struct Boxes {
+    struct Box { float lo[3], hi[3]; int face[6]; };   // face[2 axis + side] = the caller's surface index, -1: an open side
+    std::vector<Box> box;
+    std::vector<int> box_of;                            // [surface] -> box, -1: none
+};
+void find_boxes(const ky_scene* in, Boxes& B);
 int pack_scene(const ky_scene* in, DScene* out);
 uint64_t scene_hash(const DScene& s);
 bool scene_input(const ky_scene* in, std::vector<unsigned char>& out, uint64_t& hash);
@@ -56,6 +63,7 @@ int smallpt_check(const ky_smallpt_sphere* spheres, int n, const ky_smallpt_para
 
 // ---- launch policies (each has an environment variable and a kyhip_set_* entry) ----
 bool specialisation_enabled();
+bool boxes_enabled();
 int shadow_queue_mode();
 bool shadow_queue_wanted(const ky_scene* scene);
 int blocks_per_cu_cap();

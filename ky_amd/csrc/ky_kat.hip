@@ -68,7 +68,9 @@ __global__ void kat_light_kernel(const DScene* __restrict__ S, int li, const flo
     q[6] = ls.pdf; q[7] = ls.Li.x; q[8] = ls.Li.y; q[9] = ls.Li.z; q[10] = pdf;
 }
 
-__global__ void kat_scene_intersect_kernel(const DScene* __restrict__ S, const float* __restrict__ rays7, int n, float* __restrict__ out9) {
+template <bool BOXES>   // the scene has boxes (KY_FEAT_BOXES): the traversal the box kernels run
+__global__ void kat_scene_intersect_kernel(const DScene* __restrict__ S_, const float* __restrict__ rays7, int n, float* __restrict__ out9) {
+    const SceneRef S{S_, true, BOXES ? KY_FEAT_BOXES : 0, true};
     const LdsScene Lds = stage_scene<true>(S);   // KAT kernels: always the scene-sized dynamic block
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -242,7 +244,10 @@ int kyhip_kat_scene_intersect(int device, const ky_scene* scene, const float* ra
     return kat_run(device, rays7, (size_t)n * 7 * 4, out9, (size_t)n * 9 * 4, [&](DeviceCtx* c, const float* d_in, float* d_out) {
         SceneSlot* sc; int r = upload_scene(c, scene, 0, &sc);
         if (r != KY_OK) return r;
-        hipLaunchKernelGGL(kat_scene_intersect_kernel, dim3((n + 255) / 256), dim3(256), lds_scene_bytes(scene->surface_count, scene->material_count, scene->light_count), 0, (const DScene*)sc->d, d_in, n, d_out);
+        if (sc->h->feat & KY_FEAT_BOXES)
+            hipLaunchKernelGGL(kat_scene_intersect_kernel<true>, dim3((n + 255) / 256), dim3(256), lds_scene_bytes(scene->surface_count, scene->material_count, scene->light_count), 0, (const DScene*)sc->d, d_in, n, d_out);
+        else
+            hipLaunchKernelGGL(kat_scene_intersect_kernel<false>, dim3((n + 255) / 256), dim3(256), lds_scene_bytes(scene->surface_count, scene->material_count, scene->light_count), 0, (const DScene*)sc->d, d_in, n, d_out);
         return (int)KY_OK;
     });
 }

@@ -265,6 +265,88 @@ static void shape_extent(const ky_shape& sh, const double* n, double& lo, double
     const int np = sh.kind == KY_SHAPE_TRIANGLE ? 3 : 4;
     for (int q = 0; q < np; ++q) { const double c = dotp(sh.p[q]); lo = std::min(lo, c); hi = std::max(hi, c); }
 }
+// find_boxes: groups of axis-aligned rectangles that are WHOLE faces of one axis-aligned box (exact float equality of every coordinate: the corners a scene
+// builder copies from one table, 3299-3314 / 3336-3351).  A ray crosses the boundary of a convex box where it enters and where it leaves, so the nearest hit
+// among a box's faces needs no test per face (box_update_nearest, ky_device.hpp).  A box is taken when
+//   * at least KY_BOX_MIN_FACES of its six faces are surfaces (fewer: testing them one by one is cheaper), no face twice;
+//   * no OTHER axis-aligned rectangle of the scene lies in the plane of one of those faces: a hit at exactly the same distance on two surfaces goes to the
+//     earlier one in the reference's list (3177-3180), which the per-rectangle scan reproduces and a box cannot -- so a box never takes part in such a tie
+//     (ties with parallelograms, spheres and general shapes have measure zero, as between the traversal's groups anyway).
+// Rectangles are two-sided (1289), so faces count whichever way their stored normal points.
+static bool aar_extent(const ky_shape& sh, int* axis, float lo[3], float hi[3]) {
+    DAar unused;
+    const int a = sh.kind == KY_SHAPE_RECTANGLE ? axis_aligned_rectangle(sh, &unused) : -1;
+    if (a < 0) return false;
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = hi[k] = sh.p[0][k];
+        for (int q = 1; q < 4; ++q) { lo[k] = std::min(lo[k], sh.p[q][k]); hi[k] = std::max(hi[k], sh.p[q][k]); }
+    }
+    *axis = a;
+    return true;
+}
+void find_boxes(const ky_scene* in, Boxes& B) {
+    const int ns = in->surface_count;
+    B.box.clear();
+    B.box_of.assign(ns, -1);
+    struct R { int axis; float lo[3], hi[3]; };
+    std::vector<R> r(ns);
+    std::vector<char> is_aar(ns, 0);
+    for (int i = 0; i < ns; ++i) {
+        const ky_surface& sf = in->surfaces[i];
+        if (sf.shape < 0 || sf.shape >= in->shape_count) return;   // (pack_scene reports it)
+        is_aar[i] = aar_extent(in->shapes[sf.shape], &r[i].axis, r[i].lo, r[i].hi) ? 1 : 0;
+    }
+    auto face_of = [&](const Boxes::Box& b, int i) {   // which face of b surface i is exactly, -1: none
+        const R& q = r[i];
+        const int a = q.axis;
+        for (int k = 0; k < 3; ++k)
+            if (k != a && !(q.lo[k] == b.lo[k] && q.hi[k] == b.hi[k])) return -1;
+        if (q.lo[a] == b.lo[a]) return 2 * a;
+        if (q.lo[a] == b.hi[a]) return 2 * a + 1;
+        return -1;
+    };
+    for (int i = 0; i < ns && (int)B.box.size() < KY_MAX_BOXES; ++i) {
+        if (!is_aar[i] || B.box_of[i] >= 0) continue;
+        const int a = r[i].axis;
+        bool taken = false;
+        for (int j = 0; j < ns && !taken; ++j) {
+            if (j == i || !is_aar[j] || B.box_of[j] >= 0 || r[j].axis == a) continue;
+            const int b = r[j].axis, e = 3 - a - b;
+            // rectangle j closes an edge of rectangle i: same extent along the third axis, each one's plane an end of the other's extent
+            if (!(r[j].lo[e] == r[i].lo[e] && r[j].hi[e] == r[i].hi[e])) continue;
+            if (!(r[j].lo[b] == r[i].lo[b] || r[j].lo[b] == r[i].hi[b])) continue;
+            if (!(r[i].lo[a] == r[j].lo[a] || r[i].lo[a] == r[j].hi[a])) continue;
+            Boxes::Box box{};
+            box.lo[a] = r[j].lo[a]; box.hi[a] = r[j].hi[a];
+            box.lo[b] = r[i].lo[b]; box.hi[b] = r[i].hi[b];
+            box.lo[e] = r[i].lo[e]; box.hi[e] = r[i].hi[e];
+            if (!(box.lo[0] < box.hi[0] && box.lo[1] < box.hi[1] && box.lo[2] < box.hi[2])) continue;
+            for (int f = 0; f < 6; ++f) box.face[f] = -1;
+            int n_faces = 0;
+            bool ok = true;
+            for (int k = 0; k < ns; ++k) {
+                if (!is_aar[k] || B.box_of[k] >= 0) continue;
+                const int f = face_of(box, k);
+                if (f >= 0 && box.face[f] < 0) { box.face[f] = k; ++n_faces; }
+            }
+            for (int k = 0; k < ns && ok; ++k) {
+                // any other rectangle in the plane of one of the box's FACES (a second copy of a face, a face of another box, a free rectangle): no box here
+                // (the plane of an open side is nobody's: a lamp housing may reach the ceiling)
+                if (!is_aar[k]) continue;
+                const int ka = r[k].axis;
+                for (int side = 0; side < 2; ++side) {
+                    const int f = 2 * ka + side;
+                    if (box.face[f] >= 0 && box.face[f] != k && r[k].lo[ka] == (side ? box.hi[ka] : box.lo[ka])) ok = false;
+                }
+            }
+            if (!ok || n_faces < KY_BOX_MIN_FACES) continue;
+            for (int f = 0; f < 6; ++f) if (box.face[f] >= 0) B.box_of[box.face[f]] = (int)B.box.size();
+            B.box.push_back(box);
+            taken = true;
+        }
+    }
+}
+
 void find_non_occluders(const ky_scene* in, NonOccluders& R) {
     const int ns = in->surface_count, nl = in->light_count;
     R.wall.assign(ns, 0);
@@ -381,6 +463,18 @@ bool specialisation_enabled() {
     return g_specialise != 0;
 }
 
+// The boxes (find_boxes, KY_FEAT_BOXES) can be switched off on their own: KYHIP_BOXES=0 or kyhip_set_boxes(0).  A box's slab test computes a hit distance that
+// differs from the per-rectangle test's by up to 15 units in the last place (box_update_nearest), so this switch -- unlike the one above -- moves an image beyond
+// its last bit (tests/test_boxes.py measures by how much); it exists for that test, for the tests that compare two kernels bit for bit, and for A/B measurements.
+static int g_boxes = -1;
+bool boxes_enabled() {
+    if (g_boxes < 0) {
+        const char* e = std::getenv("KYHIP_BOXES");
+        g_boxes = (e && std::atoi(e) == 0) ? 0 : 1;
+    }
+    return g_boxes != 0;
+}
+
 int pack_scene(const ky_scene* in, DScene* out) {
     if (!in) return fail(KY_ERR_INVALID_VALUE, "scene is NULL");
     if (in->surface_count < 0 || in->shape_count < 0 || in->material_count < 0 || in->light_count < 0)
@@ -431,6 +525,8 @@ int pack_scene(const ky_scene* in, DScene* out) {
             const int group = axis >= 0 ? axis - 3 : (recs[i].kind == TK_PARALLELOGRAM ? 0 : (recs[i].kind == TK_SPHERE ? 1 : 2));
             if (group != pass) continue;
             if (pass < 0) {
+                const int32_t sorted_index = j;
+                std::memcpy(&aar.q1.y, &sorted_index, 4);   // DAar: the scans note the surface from the record
                 planar.push_back(PlanarEntry{i, axis, aar, DPar{}});
             } else if (pass == 0) {
                 PlanarEntry e{i, -1, DAar{}, DPar{}};
@@ -468,6 +564,35 @@ int pack_scene(const ky_scene* in, DScene* out) {
     };
     build_trav(out->trav, [](int) { return false; });
     build_trav(out->occ, [&](int i) { return non.wall[i] != 0; });
+    // KY_FEAT_BOXES: the boxes and the rectangles that are no box's face (DScene::boxtrav)
+    std::memset(&out->boxtrav, 0, sizeof out->boxtrav);
+    if (specialisation_enabled() && boxes_enabled()) {
+        Boxes bx;
+        find_boxes(in, bx);
+        std::vector<int> sorted_of(in->surface_count, -1);
+        for (int k = 0; k < j; ++k) sorted_of[out->orig[k]] = k;
+        std::vector<char> boxed(in->surface_count, 0);
+        DBoxTrav& BT = out->boxtrav;
+        for (const Boxes::Box& b : bx.box) {
+            uint32_t tag[6];
+            bool fits = true;
+            for (int f = 0; f < 6; ++f) {
+                const int sidx = b.face[f] >= 0 ? sorted_of[b.face[f]] : KY_BOX_NO_FACE;
+                fits = fits && sidx >= 0 && (b.face[f] < 0 || sidx < KY_BOX_NO_FACE);   // four bits per face
+                tag[f] = (uint32_t)sidx;
+            }
+            if (!fits) continue;
+            DBox& d = BT.box[BT.n_box++];
+            d.q0 = make_float4(b.lo[0], b.lo[1], b.lo[2], 0.f);
+            d.q1 = make_float4(b.hi[0], b.hi[1], b.hi[2], 0.f);
+            std::memcpy(&d.q0.w, &tag[0], 4); std::memcpy(&d.q1.w, &tag[1], 4);
+            std::memcpy(&d.q2.x, &tag[2], 4); std::memcpy(&d.q2.y, &tag[3], 4); std::memcpy(&d.q2.z, &tag[4], 4); std::memcpy(&d.q2.w, &tag[5], 4);
+            for (int f = 0; f < 6; ++f) if (b.face[f] >= 0) boxed[b.face[f]] = 1;
+        }
+        for (const PlanarEntry& e : planar)
+            if (e.axis >= 0 && !boxed[e.surface]) { BT.n_aar_axis[e.axis]++; BT.aar[BT.n_aar++] = e.aar; }
+        if (BT.n_aar > 0) BT.aar[BT.n_aar] = BT.aar[BT.n_aar - 1];
+    }
     out->occ_deferred_ok = non.deferred_ok ? 1 : 0;
     out->ts_light = non.ts_light;
     out->feat = 0;
@@ -490,6 +615,7 @@ int pack_scene(const ky_scene* in, DScene* out) {
         for (int i = 0; i < in->material_count; ++i) no_delta = no_delta && in->materials[i].kind != KY_MATERIAL_MIRROR && in->materials[i].kind != KY_MATERIAL_GLASS;
         if (no_delta) out->feat |= KY_FEAT_NO_DELTA;
         if (in->surface_count <= KY_LDS_SURFACES_SMALL && in->material_count <= KY_LDS_MATERIALS_SMALL) out->feat |= KY_FEAT_SMALL_TABLES;
+        if (out->boxtrav.n_box > 0) out->feat |= KY_FEAT_BOXES;
     }
     if (non.ts_light >= 0) {
         build_trav(out->occ_front, [&](int i) { return non.wall[i] != 0 || non.ts_behind[i] != 0; });
@@ -628,7 +754,7 @@ bool scene_input(const ky_scene* in, std::vector<unsigned char>& out, uint64_t& 
         in->shape_count > KYHIP_MAX_SHAPES || in->material_count > KYHIP_MAX_MATERIALS || in->light_count > KYHIP_MAX_LIGHTS)
         return false;   // pack_scene reports what is wrong
     auto put = [&](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; out.insert(out.end(), b, b + n); };
-    const int32_t head[6] = {in->shape_count, in->material_count, in->light_count, in->surface_count, in->environment_light, specialisation_enabled() ? 1 : 0};
+    const int32_t head[6] = {in->shape_count, in->material_count, in->light_count, in->surface_count, in->environment_light, (specialisation_enabled() ? 1 : 0) | (boxes_enabled() ? 2 : 0)};
     put(head, sizeof head);
     put(&in->camera, sizeof in->camera);
     if (in->shape_count) put(in->shapes, sizeof(ky_shape) * (size_t)in->shape_count);
@@ -744,6 +870,7 @@ int smallpt_check(const ky_smallpt_sphere* spheres, int n, const ky_smallpt_para
 
 void set_engine_raw(int v) { g_engine = v; }
 void set_specialise_raw(int v) { g_specialise = v; }
+void set_boxes_raw(int v) { g_boxes = v; }
 void set_shadow_queue_raw(int v) { g_shadow_queue = v; }
 }  // namespace kyh
 
@@ -764,6 +891,11 @@ int kyhip_set_engine(int engine) {
 int kyhip_set_specialisation(int on) {
     const int prev = specialisation_enabled() ? 1 : 0;
     if (on == 0 || on == 1) kyh::set_specialise_raw(on);
+    return prev;
+}
+int kyhip_set_boxes(int on) {
+    const int prev = boxes_enabled() ? 1 : 0;
+    if (on == 0 || on == 1) kyh::set_boxes_raw(on);
     return prev;
 }
 int kyhip_set_shadow_queue(int mode) {
@@ -809,6 +941,27 @@ int kyhip_scene_non_occluders(const ky_scene* scene, int light, int* left_out, i
     const DTrav& T = (light < 0 || non.light_ok[light]) ? P.occ : P.trav;
     if (count != P.trav.n_aar + P.trav.n_par - T.n_aar - T.n_par) return fail(KY_ERR_DEVICE, "internal: occluder table and classification disagree");
     return count;
+}
+
+// host only: the boxes the nearest-hit traversal tests whole (find_boxes): box_face[i] = 8 box + face (face = 2 axis + side) for a surface that is a box's face, -1 otherwise
+int kyhip_scene_boxes(const ky_scene* scene, int* box_face, int n) {
+    if (!scene || !box_face || n < 0) return fail(KY_ERR_INVALID_VALUE, "bad arguments");
+    std::vector<DScene> packed(1);   // pack_scene validates the scene
+    const int rc = pack_scene(scene, &packed[0]);
+    if (rc != KY_OK) return rc;
+    if (n < scene->surface_count) return fail(KY_ERR_INVALID_VALUE, "box_face holds %d entries, the scene has %d surfaces", n, scene->surface_count);
+    for (int i = 0; i < scene->surface_count; ++i) box_face[i] = -1;
+    const DScene& P = packed[0];
+    for (int b = 0; b < P.boxtrav.n_box; ++b) {
+        const DBox& d = P.boxtrav.box[b];
+        const float* src[6] = {&d.q0.w, &d.q1.w, &d.q2.x, &d.q2.y, &d.q2.z, &d.q2.w};
+        for (int f = 0; f < 6; ++f) {
+            uint32_t sidx;
+            std::memcpy(&sidx, src[f], 4);
+            if (sidx != (uint32_t)KY_BOX_NO_FACE) box_face[P.orig[sidx]] = 8 * b + f;
+        }
+    }
+    return P.boxtrav.n_box;
 }
 
 // ---- smallpt's scene in double precision (ky_smallpt.hpp) ----

@@ -112,9 +112,28 @@ struct DSph {  // sphere, 16 B: centre, radius^2
 // axis-aligned rectangle in the plane x_axis = c, 32 B.  With (u, v) = the other two axes in cyclic order and [lo, hi] the
 // rectangle's extent along them: q0 = (c, mu, ru, mv), q1.x = rv with m = (lo + hi) / 2, r = (hi - lo) / 2: a point h of
 // the plane is inside iff |h_u - mu| <= ru and |h_v - mv| <= rv (borders inclusive, like the parallelogram test; each
-// test is one subtract and one compare with a single scalar operand).
+// test is one subtract and one compare with a single scalar operand).  q1.y = the surface's SORTED index (an int's bits): the nearest-hit scans
+// note it straight from the record, so a table's order carries no meaning beyond the order of exact ties (DBoxTrav::aar leaves rectangles out).
 struct DAar {
     float4 q0, q1;
+};
+
+// An axis-aligned BOX some of whose six faces are surfaces of the scene, each exactly a whole face (host: find_boxes -- the room of a Cornell box, its lamp
+// housing): 48 B.  q0 = (lo, s[0]), q1 = (hi, s[1]), q2 = (s[2], s[3], s[4], s[5]) with s[f] = the sorted surface index of face f = 2 axis + (0: the lo plane,
+// 1: the hi plane) as an integer's bits, KY_BOX_NO_FACE = 15 for an open side -- so a box's faces have sorted indices below 15.  A ray meets the boundary of a
+// convex box where it enters and where it leaves it, so the nearest hit among up to six rectangles is one slab test (box_update_nearest, ky_device.hpp:
+// 40 VALU instructions against 12 per rectangle).
+struct DBox {
+    float4 q0, q1, q2;
+};
+constexpr int KY_MAX_BOXES = 4, KY_BOX_MIN_FACES = 4, KY_BOX_NO_FACE = 15;
+// What a nearest-hit traversal of an instantiation with KY_FEAT_BOXES scans instead of DTrav::aar: the boxes, then the axis-aligned rectangles that are no
+// box's face (grouped by axis like DTrav::aar); parallelograms, spheres and general shapes as ever.
+struct DBoxTrav {
+    int32_t n_box, n_aar, pad_b0, pad_b1;
+    int32_t n_aar_axis[3], pad_b2;
+    DBox box[KY_MAX_BOXES];
+    DAar aar[KYHIP_MAX_SURFACES + 1];
 };
 
 // The surfaces are stored SORTED BY TRAVERSAL KIND -- axis-aligned rectangles (x, y, z planes), other parallelograms, then
@@ -154,6 +173,7 @@ struct DScene {
     int32_t ts_light, feat, ts_pad[2];   // feat: the KY_FEAT_* facts that hold for this scene (host: pack_scene)
     float ts_plane[4];
     DTrav occ_front, occ_behind;
+    DBoxTrav boxtrav;                   // KY_FEAT_BOXES: the nearest-hit traversal's planar part with the boxes' faces taken out of the rectangle lists
     DSph sph[KYHIP_MAX_SURFACES + 1];
     DSurf gen[KYHIP_MAX_SURFACES];
     DSurf all[KYHIP_MAX_SURFACES];      // every surface as a generic record, sorted order (carrier tests, surface-parallel queries)
@@ -163,7 +183,8 @@ struct DScene {
     DMat mat[KYHIP_MAX_MATERIALS];
     DLight light[KYHIP_MAX_LIGHTS];
 };
-static_assert(__builtin_offsetof(DScene, light) % 16 == 0 && __builtin_offsetof(DScene, trav) % 16 == 0, "16-byte scalar loads of light and table records");
+static_assert(__builtin_offsetof(DScene, light) % 16 == 0 && __builtin_offsetof(DScene, trav) % 16 == 0 && __builtin_offsetof(DScene, boxtrav) % 16 == 0 &&
+              __builtin_offsetof(DBoxTrav, box) % 16 == 0, "16-byte scalar loads of light, table and box records");
 
 
 // How device functions see the scene: the pointer plus one compile-time fact.  `general` = the scene may hold shapes that
@@ -188,6 +209,8 @@ enum : int {
     KY_FEAT_OWN_CARRIER = 256,   // every area light samples a planar parallelogram and is carried by exactly ONE surface, which has that very shape (a lamp that is its own
                                  // emitting rectangle: DLight::pdf_from_carrier for every light): the BSDF-sampling estimators test DLight::isect directly -- no carrier
                                  // list, no dispatch on the carrier's kind, no look-up of its normal (a rectangle seen by a ray emits on both sides, 1289 / 2957)
+    KY_FEAT_BOXES = 512,         // some axis-aligned rectangles are whole faces of common boxes (DBox; at least KY_BOX_MIN_FACES faces each): the nearest-hit traversal
+                                 // tests a box with one slab test instead of its faces one by one (DScene::boxtrav)
     KY_FEAT_SMALL_TABLES = 128   // at most KY_LDS_SURFACES_SMALL surfaces and KY_LDS_MATERIALS_SMALL materials: the per-lane tables' LDS block is 1.1 KB instead of
                                  // 3.8 (what lets the sphere-lights kernel with its deferred rays' sums fit a seventh workgroup per CU)
 };

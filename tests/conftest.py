@@ -69,3 +69,14 @@ def table_kernels():
     picked are skipped then, every numeric assertion stays."""
     import os
     return os.environ.get("KYHIP_JIT", "0") in ("", "0")
+
+
+@pytest.fixture
+def no_boxes(A):
+    """For tests that compare two KERNELS of the library bit for bit (or to a few ulp): the box traversal (kyhip_set_boxes) is the one switch that
+    changes arithmetic -- a slab test's hit distance differs from the rectangle test's by up to 15 units in the last place -- and only some kernels have it, so
+    these tests run without it; tests/test_boxes.py bounds what the switch itself moves."""
+    lib = A.load_kyhip()
+    prev = lib.kyhip_set_boxes(0)
+    yield
+    lib.kyhip_set_boxes(prev)

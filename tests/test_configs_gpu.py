@@ -311,7 +311,7 @@ def test_c2_headline_frame_through_the_cpp_driver(A, api, O, tmp_path):
     assert got == FW.bmp_bytes(api.render(scene, params))
 
 
-def test_specialised_instantiations_change_nothing(A, api, O, table_kernels):
+def test_specialised_instantiations_change_nothing(A, api, O, table_kernels, no_boxes):
     """A scene lit by one rectangle area light runs a both_mis kernel compiled without the other light kinds, the environment term, the
     lights loop and the other light shapes (SceneRef::feat); the other five strategies of the iterative integrator have kernels of their
     own instead of the run-time-dispatched one.  Same arithmetic, same random streams: the image must be the same either way

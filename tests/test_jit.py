@@ -50,7 +50,7 @@ def test_a_missing_compiler_is_a_status_not_a_crash(A, tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_instantiated_kernels_render_what_the_table_renders(A, api, O, tmp_path, monkeypatch):
+def test_instantiated_kernels_render_what_the_table_renders(A, api, O, tmp_path, monkeypatch, no_boxes):
     from test_random_scenes_gpu import random_room
     from test_parity_gpu import general_shapes_scene
     monkeypatch.setenv("KYHIP_CACHE_DIR", str(tmp_path / "cache"))
@@ -98,7 +98,7 @@ def test_instantiated_kernels_render_what_the_table_renders(A, api, O, tmp_path,
 
 
 @pytest.mark.gpu
-def test_asynchronous_mode_renders_on_the_table_until_the_object_is_there(A, api, tmp_path, monkeypatch):
+def test_asynchronous_mode_renders_on_the_table_until_the_object_is_there(A, api, tmp_path, monkeypatch, no_boxes):
     """kyhip_set_jit(2) (round 5): a launch whose instantiation is not in the table does NOT wait for the compiler -- the table's kernel renders, a background
     thread compiles, and a later launch switches.  The first call returns in a fraction of the compile time, every frame is one of the two kernels' images
     (which differ by at most 2e-5), the switch happens within seconds, and a multi-shard call uses one kernel for all its shards."""

@@ -537,7 +537,7 @@ def test_integrators_agree_in_expectation(A, api):
     assert abs(means[9] - means[11]) < 0.04 * means[11] and abs(means[10] - means[11]) < 0.04 * means[11], means
 
 
-def test_engines_agree(A, api):
+def test_engines_agree(A, api, no_boxes):
     """The queue engine (ky_queue.hpp: path state in LDS, one queue per path state) runs the lane engine's per-sample
     arithmetic and random streams; only the float summation order of a pixel differs (per sample instead of per chunk),
     so the two images agree to a few ulp -- for every direct-lighting strategy, on both scenes, with edge tiles and shards.

@@ -414,7 +414,10 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
         const int jit_mode = kyjit::mode();
         if (jit_mode != 0 && specialisation_enabled() && p->integrator >= KY_INTEGRATOR_DIRECT_LIGHTING) {   // (kyhip_set_specialisation(0) asks for the fact-free kernels: nothing to instantiate)
             const bool dbg = p->sampler == KY_SAMPLER_DEBUG, general = sc->h->general != 0;
-            const int feat = (dbg || general) ? 0 : sc->h->feat;
+            int feat = (dbg || general) ? 0 : sc->h->feat;
+            // the box traversal pays where it was measured to (one lamp, one point / directional light: +3-4 %); in instantiations that inline the nearest-hit
+            // traversal more than once (an environment light's BSDF-sampled rays, several lights) it measured 7-10 % SLOWER: those keep the rectangle scan
+            if (!(feat & (KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_DELTA))) feat &= ~KY_FEAT_BOXES;
             const bool want_queue = (p->direct_sample == KY_DIRECT_BOTH_MIS || p->direct_sample == KY_DIRECT_LIGHT_MIS || p->direct_sample == KY_DIRECT_LIGHT) &&
                                     p->integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION && sh.n_pix < (1 << 26) && !general && shadow_queue_wanted(scene);
             const bool same = v->dbg == dbg && v->strategy == p->direct_sample && v->queue == want_queue && v->general == general && v->feat == feat &&

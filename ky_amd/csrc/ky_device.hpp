@@ -35,6 +35,9 @@
 #ifndef KY_IPDF
 #define KY_IPDF 1
 #endif
+#ifndef KY_SPH_ANY_BOUND
+#define KY_SPH_ANY_BOUND 1
+#endif
 #ifndef KY_AAR_OFFLOOP
 #define KY_AAR_OFFLOOP 1
 #endif
@@ -716,7 +719,15 @@ KY_DEV bool trace_any(SceneRef S, const DTrav& T, f3 o, f3 d, float tmax) {
             const f3 oc = mk3(c.x, c.y, c.z) - o;
             const float neg_b = dot(oc, d);
             const float discr = neg_b * neg_b - dot(oc, oc) + c.w;
+#if KY_SPH_ANY_BOUND
+            // sphere-light scenes: a shadow ray is AIMED at a lamp, so its line always meets that lamp -- 2e-3 beyond tmax (3187-3201) -- and with five lamps every sphere is
+            // some lane's target.  The root is needed only if some lane's nearer crossing can lie before tmax: neg_b - sqrt(discr) < tmax <=> e < 0 or e^2 < discr, e = neg_b - tmax
+            // (no square root; conservative: the far crossing and eps are left to the full test).
+            const float e = neg_b - tmax;
+            if (!S.sphere_lights() || __any((discr >= 0.f) & ((e < 0.f) | (e * e < discr)))) sph_update_any(ex, neg_b, discr, tmax, occ_v);
+#else
             if (!S.sphere_lights() || __any(discr >= 0.f)) sph_update_any(ex, neg_b, discr, tmax, occ_v);
+#endif
             off += (unsigned)sizeof(DSph);
         }
         occ = occ | (occ_v != 0);

@@ -130,6 +130,7 @@ KYHIP_SYMBOLS = {
     "kyhip_kat_occluded_between": (C.c_int, [C.c_int, SP, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "kyhip_scene_non_occluders": (C.c_int, [SP, C.c_int, C.c_void_p, C.c_int]),
     "kyhip_scene_boxes": (C.c_int, [SP, C.c_void_p, C.c_int]),
+    "kyhip_scene_facts": (C.c_int, [SP]),
     "kyhip_kat_li": (C.c_int, [C.c_int, SP, PP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 

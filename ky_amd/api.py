@@ -222,6 +222,15 @@ def scene_non_occluders(scene, light=-1):
     return out[:n].copy()
 
 
+def scene_facts(scene):
+    """kyhip_scene_facts (host only): the KY_FEAT_* mask the library finds for the scene."""
+    lib = A.load_kyhip()
+    rc = lib.kyhip_scene_facts(_scene_ptr(scene))
+    if rc < 0:
+        _check(rc)
+    return rc
+
+
 def scene_boxes(scene):
     """kyhip_scene_boxes (host only): (number of boxes, per surface 8 * box + 2 * axis + side for a surface that is a whole face of an axis-aligned box
     the nearest-hit traversal tests with one slab test, -1 otherwise)."""

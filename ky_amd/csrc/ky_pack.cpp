@@ -616,6 +616,7 @@ int pack_scene(const ky_scene* in, DScene* out) {
         if (no_delta) out->feat |= KY_FEAT_NO_DELTA;
         if (in->surface_count <= KY_LDS_SURFACES_SMALL && in->material_count <= KY_LDS_MATERIALS_SMALL) out->feat |= KY_FEAT_SMALL_TABLES;
         if (out->boxtrav.n_box > 0) out->feat |= KY_FEAT_BOXES;
+        if (out->trav.n_aar > 0 && out->trav.n_par == 0 && out->n_gen == 0) out->feat |= KY_FEAT_AXIS_ALIGNED;   // (n_gen: the surfaces are laid out above)
     }
     if (non.ts_light >= 0) {
         build_trav(out->occ_front, [&](int i) { return non.wall[i] != 0 || non.ts_behind[i] != 0; });
@@ -650,6 +651,12 @@ int pack_scene(const ky_scene* in, DScene* out) {
             if (!shape_normal_ok(sh)) return fail(KY_ERR_INVALID_VALUE, "shape %d: the stored normal must be unit length", l.shape);
             d.shape_kind = sh.kind; d.radius = sh.radius; d.area = host_shape_area(sh); d.inv_area = 1 / d.area;  // area_pdf = 1 / area(), 1313
             cp3(d.n, sh.normal);
+            d.aar_axis = -1;
+            if (sh.kind == KY_SHAPE_RECTANGLE) {
+                DAar a{};
+                d.aar_axis = axis_aligned_rectangle(sh, &a);
+                if (d.aar_axis >= 0) { d.aar[0] = a.q0.x; d.aar[1] = a.q0.y; d.aar[2] = a.q0.z; d.aar[3] = a.q0.w; d.aar[4] = a.q1.x; }
+            }
             if (sh.kind == KY_SHAPE_RECTANGLE) {  // p1 + (p0 - p1) u0 + (p2 - p1) u1, 1310
                 cp3(d.p1, sh.p[1]);
                 for (int j = 0; j < 3; ++j) { d.e0[j] = sh.p[0][j] - sh.p[1][j]; d.e1[j] = sh.p[2][j] - sh.p[1][j]; }
@@ -941,6 +948,14 @@ int kyhip_scene_non_occluders(const ky_scene* scene, int light, int* left_out, i
     const DTrav& T = (light < 0 || non.light_ok[light]) ? P.occ : P.trav;
     if (count != P.trav.n_aar + P.trav.n_par - T.n_aar - T.n_par) return fail(KY_ERR_DEVICE, "internal: occluder table and classification disagree");
     return count;
+}
+
+// host only: the KY_FEAT_* facts pack_scene finds for the scene (what a render-kernel instantiation may assume: ky_scene.hpp)
+int kyhip_scene_facts(const ky_scene* scene) {
+    if (!scene) return fail(KY_ERR_INVALID_VALUE, "bad arguments");
+    std::vector<DScene> packed(1);
+    const int rc = pack_scene(scene, &packed[0]);
+    return rc != KY_OK ? rc : packed[0].feat;
 }
 
 // host only: the boxes the nearest-hit traversal tests whole (find_boxes): box_face[i] = 8 box + face (face = 2 axis + side) for a surface that is a box's face, -1 otherwise

@@ -98,6 +98,9 @@ struct DLight {  // light_t + the shape an area light samples; wave-uniform inde
     int32_t shadow_table;         // byte offset (from the scene's base) of the planar table a shadow ray towards a sample of this light scans first -- DScene::occ_front for the
                                   // two-stage light (bit 0 set: occ_behind follows for rays with an end behind its plane), DScene::occ when occ_ok, DScene::trav otherwise --
                                   // decided once by the host instead of by three scalar loads and two compares per light sample
+    float aar[5];                 // the sampled shape as a rectangle in an axis plane (DAar's c, mu, ru, mv, rv) when it is one ...
+    int32_t aar_axis;             // ... in the plane x_axis = c; -1: it is not (KY_FEAT_AXIS_ALIGNED kernels test the lamp with it: estimate_by_bsdf)
+    int32_t pad_a[2];
     DSurf isect;          // traversal record of the sampled shape (pdf_direction re-intersects it, 1057-1061)
 };
 constexpr int KY_MAX_CARRIERS = 4;
@@ -211,6 +214,8 @@ enum : int {
                                  // list, no dispatch on the carrier's kind, no look-up of its normal (a rectangle seen by a ray emits on both sides, 1289 / 2957)
     KY_FEAT_BOXES = 512,         // some axis-aligned rectangles are whole faces of common boxes (DBox; at least KY_BOX_MIN_FACES faces each): the nearest-hit traversal
                                  // tests a box with one slab test instead of its faces one by one (DScene::boxtrav)
+    KY_FEAT_AXIS_ALIGNED = 1024, // every planar surface is a rectangle in an axis plane and there are no general shapes: no parallelogram loops in the traversals, and a lamp
+                                 // that is its own carrier (KY_FEAT_OWN_CARRIER) is tested as such a rectangle
     KY_FEAT_SMALL_TABLES = 128   // at most KY_LDS_SURFACES_SMALL surfaces and KY_LDS_MATERIALS_SMALL materials: the per-lane tables' LDS block is 1.1 KB instead of
                                  // 3.8 (what lets the sphere-lights kernel with its deferred rays' sums fit a seventh workgroup per CU)
 };

@@ -56,6 +56,31 @@ def test_boxes_of_the_shipped_scenes(A, api):
     assert api.scene_boxes(area)[0] == 2
 
 
+def test_scene_facts(A, api):
+    """kyhip_scene_facts: what decides the instantiation a launch takes (ky_scene.hpp's KY_FEAT_*)."""
+    lib = A.load_kyhip()
+    area = api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | A.CB_LIGHT_AREA, 64, 64)
+    # one area light (1) that samples a rectangle (2), few carriers (4), small tables (128), the lamp is its own carrier (256), boxes (512), all planar surfaces axis rectangles (1024)
+    assert api.scene_facts(area) == 1 + 2 + 4 + 128 + 256 + 512 + 1024
+    assert api.scene_facts(api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | A.CB_LIGHT_POINT, 64, 64)) == 2 + 4 + 8 + 128 + 512 + 1024   # (no area light: 2 and 4 hold vacuously)
+    assert api.scene_facts(api.mis_scene(96, 54)) == 4 + 32 + 64 + 128                  # sphere lamps, no delta lobes; its planks are tilted: no 1024
+    prev = lib.kyhip_set_boxes(0)
+    try:
+        assert api.scene_facts(area) == 1 + 2 + 4 + 128 + 256 + 1024
+    finally:
+        lib.kyhip_set_boxes(prev)
+    prev = lib.kyhip_set_specialisation(0)
+    try:
+        assert api.scene_facts(area) == 0
+    finally:
+        lib.kyhip_set_specialisation(prev)
+    # a tilted wall among axis rectangles: no 1024
+    c, s = np.cos(0.3), np.sin(0.3)
+    tilted = make_shape(A, A.SHAPE_RECTANGLE, [(0, 0, 0), (c, s, 0), (c, s, 1), (0, 0, 1)])
+    facts = api.scene_facts(_scene(A, api, _box_faces(A, (-1, -1, 0), (1, 1, 2), (0, 1, 2, 3, 4)) + [tilted]))
+    assert facts & 512 and not facts & 1024, facts
+
+
 def test_box_rules(A, api):
     lo, hi = (-1.0, -0.5, 0.0), (1.0, 0.75, 2.0)
     ball = make_shape(A, A.SHAPE_SPHERE, [(0, 0, 1)], radius=0.3)
@@ -165,7 +190,8 @@ def test_images_with_and_without_boxes(A, api):
         finally:
             lib.kyhip_set_boxes(prev)
         if flag == A.CB_LIGHT_AREA and "render_kernel<strategy 48" in kernel:
-            assert "feat 903" in kernel and "feat 391" in kernel_off, (kernel, kernel_off)
+            # 1 + 2 + 4 + 128 + 256 (the lamp kernel's facts) + 512 (boxes) + 1024 (every planar surface an axis rectangle); without boxes the 391 row (1415 has no row of its own)
+            assert "feat 1927" in kernel and "feat 391" in kernel_off, (kernel, kernel_off)
         fin = np.isfinite(on) & np.isfinite(off)
         d = np.abs(on - off)[fin]
         # a sample whose path takes another discrete decision (a shadow ray at its threshold) moves its pixel by up to 1 / spp of the clamp range: few of them

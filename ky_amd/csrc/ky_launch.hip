@@ -277,6 +277,8 @@ static const Variant g_variants[] = {
     // the iterative integrator, both_mis: by scene facts
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES | KY_FEAT_BOXES | KY_FEAT_AXIS_ALIGNED, IT),   // ... and nothing planar but axis rectangles: configs[1], [4]
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES | KY_FEAT_BOXES, IT),   // ... whose walls / lamp housing are faces of boxes
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES | KY_FEAT_AXIS_ALIGNED, IT),   // ... axis rectangles only, no boxes (kyhip_set_boxes(0): the
+                                                                                                           // kernel the tests hold against the fact-free one to 2.4e-7)
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES, IT),   // one rectangle area light, at most 16 surfaces and 8 materials
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL, IT),                  // one rectangle area light
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_DELTA | KY_FEAT_BOXES | KY_FEAT_AXIS_ALIGNED, IT),   // one point / directional light in a room that is a box (configs[3]'s frames)

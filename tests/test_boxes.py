@@ -190,8 +190,8 @@ def test_images_with_and_without_boxes(A, api):
         finally:
             lib.kyhip_set_boxes(prev)
         if flag == A.CB_LIGHT_AREA and "render_kernel<strategy 48" in kernel:
-            # 1 + 2 + 4 + 128 + 256 (the lamp kernel's facts) + 512 (boxes) + 1024 (every planar surface an axis rectangle); without boxes the 391 row (1415 has no row of its own)
-            assert "feat 1927" in kernel and "feat 391" in kernel_off, (kernel, kernel_off)
+            # 1 + 2 + 4 + 128 + 256 (the lamp kernel's facts) + 512 (boxes) + 1024 (every planar surface an axis rectangle); without boxes the 1415 row
+            assert "feat 1927" in kernel and "feat 1415" in kernel_off, (kernel, kernel_off)
         fin = np.isfinite(on) & np.isfinite(off)
         d = np.abs(on - off)[fin]
         # a sample whose path takes another discrete decision (a shadow ray at its threshold) moves its pixel by up to 1 / spp of the clamp range: few of them

@@ -365,7 +365,7 @@ def test_specialised_instantiations_change_nothing(A, api, O, table_kernels, no_
                 assert "integrator %d" % integrator in kernel_on and "strategy 48" in kernel_on, kernel_on
                 if integrator != A.INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION:    # (it samples no lights: one kernel for every scene)
                     # (the iterative integrator's lamp kernel also knows the scene's tables for small: 7 + 128)
-                    assert not table_kernels or (fact if not (flag == A.CB_LIGHT_AREA and integrator == A.INTEGRATOR_PATH_TRACING_ITERATION) else "feat 391") in kernel_on, (kernel_on, fact)
+                    assert not table_kernels or (fact if not (flag == A.CB_LIGHT_AREA and integrator == A.INTEGRATOR_PATH_TRACING_ITERATION) else "feat 1415") in kernel_on, (kernel_on, fact)
                 if integrator != A.INTEGRATOR_PATH_TRACING_ITERATION:
                     assert "strategy -1" in kernel_off, kernel_off
                 fin = np.isfinite(on) & np.isfinite(off)

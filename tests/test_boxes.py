@@ -201,3 +201,86 @@ def test_images_with_and_without_boxes(A, api):
         assert (d > 2e-3).sum() <= 24 and (d > 2e-5).sum() <= 0.005 * d.size, (flag, int((d > 2e-3).sum()), int((d > 2e-5).sum()), float(d.max()))
         worst = max(worst, float(d.max()))
     assert worst > 0.0   # (the switch did switch something)
+
+
+def _boxy_room(A, api, seed, W, H):
+    """A room nobody tuned for: an axis-aligned room (five or six walls), one or two axis-aligned crates standing in it (four to six faces each), a sphere or two,
+    every second seed a tilted panel (a parallelogram that is no axis rectangle: no KY_FEAT_AXIS_ALIGNED), and ONE light -- a point light or a rectangle lamp under
+    the ceiling (the kernels with the box traversal are the one-light ones).  The camera looks in through the open side or from inside."""
+    g = np.random.default_rng(9000 + seed)
+    half = g.uniform(1.0, 1.6, 3)
+    lo, hi = tuple(-half), tuple(half)
+    shapes = _box_faces(A, lo, hi, (0, 1, 2, 4, 5) if seed % 3 else (0, 1, 2, 3, 4, 5))          # open towards +y for two seeds of three
+    for _ in range(int(g.integers(1, 3))):
+        c = g.uniform(-0.6, 0.6, 3)
+        c[2] = -half[2]                                                                        # standing on the floor
+        ext = g.uniform(0.15, 0.4, 3)
+        faces = [f for f in range(6) if f != 4]                                                # no bottom face
+        if g.random() < 0.5:
+            faces.remove(int(g.choice([0, 1, 2, 3])))                                          # a side missing: four faces
+        shapes += _box_faces(A, (c[0] - ext[0], c[1] - ext[1], c[2]), (c[0] + ext[0], c[1] + ext[1], c[2] + 2 * ext[2]), tuple(faces))
+    for _ in range(int(g.integers(1, 3))):
+        r = float(g.uniform(0.15, 0.3))
+        p = g.uniform(-0.7, 0.7, 3)
+        shapes.append(make_shape(A, A.SHAPE_SPHERE, [(float(p[0]), float(p[1]), float(-half[2] + r + g.uniform(0.0, 0.8)))], radius=r))
+    if seed % 2:
+        a = float(g.uniform(0.2, 0.6))
+        shapes.append(make_shape(A, A.SHAPE_RECTANGLE, [(-0.5, 0.2, 0.0), (0.0, 0.2 + a, 0.0), (0.0, 0.2 + a, 0.5), (-0.5, 0.2, 0.5)]))
+    mats = [make_material(A, A.MATERIAL_MATTE, tuple(g.uniform(0.3, 0.8, 3))), make_material(A, A.MATERIAL_MIRROR, (0.9, 0.9, 0.9)),
+            make_material(A, A.MATERIAL_PLASTIC, (0.2, 0.2, 0.2), (0.6, 0.6, 0.6), exponent=40.0)]
+    lights, light_of = [], {}
+    if seed % 4 < 2:
+        lights.append(make_light(A, A.LIGHT_POINT, (3, 3, 3), position=(0.1, -0.2, float(half[2] - 0.3))))
+    else:
+        z = float(half[2] - 0.05)
+        shapes.append(make_shape(A, A.SHAPE_RECTANGLE, [(-0.3, -0.3, z), (-0.3, 0.3, z), (0.3, 0.3, z), (0.3, -0.3, z)]))
+        lights.append(make_light(A, A.LIGHT_AREA, (12, 12, 12), shape=len(shapes) - 1))
+        light_of[len(shapes) - 1] = 0
+    cam = A.Camera.from_buffer_copy(api.cornell_box_scene(A.CB_DEFAULT_SCENE, W, H).c.camera)
+    if seed % 3 == 0:                                                                          # closed room: the camera inside, at the +y wall looking in
+        cam.position[0], cam.position[1], cam.position[2] = 0.0, float(half[1] - 0.05), 0.1
+    is_sphere = [sh.kind == A.SHAPE_SPHERE for sh in shapes]
+    surfaces = [A.Surface(i, (1 if (is_sphere[i] and i % 2) else (2 if i == 3 else 0)), light_of.get(i, -1)) for i in range(len(shapes))]
+    return CustomScene(A, cam, shapes, mats, lights, surfaces)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_boxy_rooms_nobody_tuned_for(A, api, O, seed):
+    """The box traversal on scenes it was not written against: several boxes with four to six faces, rays from inside and outside, a camera inside a closed room,
+    with and without a tilted panel (KY_FEAT_AXIS_ALIGNED), a point light or a lamp -- the kernels' rows with KY_FEAT_BOXES against the oracle."""
+    lib = A.load_kyhip()
+    W, H = 48, 40
+    scene = _boxy_room(A, api, seed, W, H)
+    n_box, faces = api.scene_boxes(scene)
+    assert n_box >= 2, (seed, n_box)
+    facts = api.scene_facts(scene)
+    assert facts & 512 and bool(facts & 1024) == (seed % 2 == 0), (seed, facts)
+    rng = np.random.default_rng(100 + seed)
+    rays = random_rays(rng, 4096, origin_box=2.0, target=rng.uniform(-1.2, 1.2, (4096, 3)), tmax_inf_fraction=0.8)
+    g, c = api.kat_scene_intersect(scene, rays), O.kat_scene_intersect(scene, rays)
+    same = (g[:, 0] == c[:, 0]) & (g[:, 8] == c[:, 8])
+    hit = same & (c[:, 0] > 0)
+    assert (~same).sum() <= 0.003 * len(rays), (seed, int((~same).sum()))
+    assert np.abs(g[hit, 1] - c[hit, 1]).max() <= 2e-5 * max(1.0, float(c[hit, 1].max())) and np.abs(g[hit, 2:5] - c[hit, 2:5]).max() <= 5e-5, seed
+
+    def oracle_answer(row):
+        h = O.kat_scene_intersect(scene, row[None, :])[0]
+        return (float(h[0]), float(h[8]))
+
+    def moved(row, gen):
+        r = row.copy()
+        r[0:3] += gen.normal(0, 3e-5, 3).astype(np.float32)
+        return r
+    prove_ties([(int(i), rays[i]) for i in np.flatnonzero(~same)], lambda i: (float(g[i, 0]), float(g[i, 8])), oracle_answer, moved, rng, "boxy room %d" % seed)
+    # the film through the render kernel the facts select
+    p = api.make_params(W, H, 128, tile_w=16, tile_h=8)
+    film, ref = api.render(scene, p), O.render(scene, p)
+    kernel = lib.kyhip_last_kernel(0).decode()
+    if "render_kernel<strategy 48" in kernel and seed % 2 == 0:
+        assert "feat %d" % (facts & ((8 | 512 | 1024) if seed % 4 < 2 else (1 | 2 | 4 | 128 | 256 | 512 | 1024))) in kernel, (seed, facts, kernel)
+    fin = np.isfinite(ref).all(axis=2)
+    assert np.isfinite(film).all() and fin.mean() > 0.995 and ref.mean() > 0.002, (seed, float(ref.mean()))
+    e = rmse(film[fin], ref[fin])
+    print("boxy room %d: %d boxes, facts %d, kernel %s, film RMSE %.2e" % (seed, n_box, facts, kernel.split(" =")[0], e))
+    assert e < 1.5e-3, (seed, e, kernel)

@@ -296,6 +296,9 @@ void find_boxes(const ky_scene* in, Boxes& B) {
         if (sf.shape < 0 || sf.shape >= in->shape_count) return;   // (pack_scene reports it)
         is_aar[i] = aar_extent(in->shapes[sf.shape], &r[i].axis, r[i].lo, r[i].hi) ? 1 : 0;
     }
+    // a box's faces must have sorted surface indices below 15 (DBox), and the axis rectangles come first in the sorted order: a scene with many of them has at
+    // most a few faces to offer -- and the search below is cubic in their number
+    if (std::count(is_aar.begin(), is_aar.end(), (char)1) > 64) return;
     auto face_of = [&](const Boxes::Box& b, int i) {   // which face of b surface i is exactly, -1: none
         const R& q = r[i];
         const int a = q.axis;

@@ -1126,6 +1126,11 @@ struct LightSample {
     f3 position, wi, Li;
     float pdf;
     bool lit;   // area lights: the sample sees the light's emitting side, i.e. Li is the light's colour (a wave-uniform value) and not black by position
+    // area lights: the unit vector towards the sample and the distance, as sample_Li made them on the way to `wi` (before `wi` is zeroed for a sample that does not
+    // count).  The shadow ray of scene_t::occluded (3187-3201) is the same subtraction, the same squared length, the same reciprocal root: the estimators take them
+    // from here -- written out a second time after the sampler's branches had joined, the compiler computed them a second time (3 sub, 3 fma, v_rsq_f32, 3 mul per light sample).
+    f3 dir;
+    float dist;
 };
 
 KY_DEV f3 uniform_sphere_sample(float u0, float u1) {  // 761-769
@@ -1252,6 +1257,8 @@ KY_DEV float env_pdf(float wz) {
 KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0, float u1, int feat = 0, bool ipdf = false) {
     LightSample s;   // every kind (wave-uniform) assigns every field
     s.lit = true;
+    s.dir = any3();   // (read for area lights only)
+    s.dist = any_f();
     const SceneRef K{nullptr, false, feat};   // the kind predicates only
     if (K.is_area(L.kind)) {
         f3 lposition, lnormal;
@@ -1260,12 +1267,16 @@ KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0,
         const f3 dv = lposition - p;
         const float d2 = length_sq(dv);
         const bool ok = !((ipdf ? __builtin_isinf(s.pdf) : s.pdf == 0) || d2 == 0);
-        const f3 wi = dv * rsq(d2);
+        const float inv_d = rsq(d2);
+        const f3 wi = dv * inv_d;
+        s.dir = wi;
+        s.dist = d2 * inv_d;
         s.wi = mk3(ok ? wi.x : 0.f, ok ? wi.y : 0.f, ok ? wi.z : 0.f);
         // areal_radiance(light_isect, -wi) with the SAMPLED (stored) normal: one-sided (quirk 5), 2957-2960
         // (a light whose colour is black -- or not positive -- emits nothing: is_black(Li) ends the estimate in the reference, 3940 / 4045.  The test is on a
         // wave-uniform value, a scalar compare; without it such a sample would trace its shadow ray and add colour x 0 x k, NaN when k overflows.)
-        const bool lit = ok && dot(lnormal, wi) < 0 && !is_black_bits(L.color);
+        // (bitwise: the three tests are at hand -- short-circuit evaluation put the colour's scalar loads and their wait inside two nested divergent regions)
+        const bool lit = ok & (dot(lnormal, wi) < 0) & !is_black_bits(L.color);
         s.lit = lit;
         s.Li = mk3(lit ? L.color[0] : 0.f, lit ? L.color[1] : 0.f, lit ? L.color[2] : 0.f);
     } else if (K.is_delta(L.kind) && L.kind == KY_LIGHT_POINT) {
@@ -1652,11 +1663,16 @@ KY_DEV void estimate_by_emitter_deferred(SceneRef S, const Vertex& v, f3 wo, int
         const bool ip = S.ipdf();   // (compile-time) ls.pdf is the density's reciprocal: shape_sample_direction
         const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1, S.feat, ip);
         // scene_t::occluded(isect, ls.position), 3187-3201: the ray
-        const f3 to = ls.position - v.position;
-        const float d2 = length_sq(to);
-        const float inv_d = rsq(d2);
-        r.d = to * inv_d;
-        r.tmax = d2 * inv_d - 2e-3f;
+        if (S.is_area(L.kind)) {   // (compile-time in the kernels that defer: every light an area light)
+            r.d = ls.dir;
+            r.tmax = ls.dist - 2e-3f;
+        } else {
+            const f3 to = ls.position - v.position;
+            const float d2 = length_sq(to);
+            const float inv_d = rsq(d2);
+            r.d = to * inv_d;
+            r.tmax = d2 * inv_d - 2e-3f;
+        }
         r.o = offset_ray_origin(v.position, v.normal, r.d);
         f3 col;
         float scale, bsdf_pdf, abs_cos_i;
@@ -1712,12 +1728,19 @@ KY_DEV void estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v
     const bool dead = (area ? !ls.lit : is_black(ls.Li)) || (!ip && (MIS ? (ls.pdf <= 0) : (ls.pdf == 0)));   // (an area light's `lit` says that the density is not zero)
     KY_CLK(5);
     if (!dead) {
-        // scene_t::occluded(isect, ls.position), 3187-3201
-        const f3 to = ls.position - v.position;
-        const float d2 = length_sq(to);
-        const float inv_d = rsq(d2);
-        const f3 dir = to * inv_d;
-        const float dist = d2 * inv_d;
+        // scene_t::occluded(isect, ls.position), 3187-3201 (an area light's direction and distance: LightSample::dir)
+        f3 dir;
+        float dist;
+        if (area) {
+            dir = ls.dir;
+            dist = ls.dist;
+        } else {
+            const f3 to = ls.position - v.position;
+            const float d2 = length_sq(to);
+            const float inv_d = rsq(d2);
+            dir = to * inv_d;
+            dist = d2 * inv_d;
+        }
         const f3 o = offset_ray_origin(v.position, v.normal, dir);
         KY_PROBE(4);
         const bool occ = light_sample_occluded(S, li, o, dir, dist - 2e-3f);
@@ -1747,7 +1770,7 @@ KY_DEV void estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v
 template <bool MIS>
 KY_DEV void estimate_by_emitter_ride(SceneRef S, const LdsScene& Lds, const Vertex& v, f3 wo, int li, float u0, float u1, bool active, RideAlong& ra, f3& acc, f3 w) {
     const DLight& L = scene_light(S, li);
-    LightSample ls{any3(), any3(), any3(), any_f(), false};
+    LightSample ls{any3(), any3(), any3(), any_f(), false, any3(), any_f()};
     const bool area = S.is_area(L.kind);   // (wave-uniform)
     bool dead = true;
     if (active) {
@@ -1757,11 +1780,16 @@ KY_DEV void estimate_by_emitter_ride(SceneRef S, const LdsScene& Lds, const Vert
     f3 o = any3(), dir = any3();
     float tmax = any_f();
     if (!dead) {  // scene_t::occluded(isect, ls.position), 3187-3201
-        const f3 to = ls.position - v.position;
-        const float d2 = length_sq(to);
-        const float inv_d = rsq(d2);
-        dir = to * inv_d;
-        tmax = d2 * inv_d - 2e-3f;
+        if (area) {
+            dir = ls.dir;
+            tmax = ls.dist - 2e-3f;
+        } else {
+            const f3 to = ls.position - v.position;
+            const float d2 = length_sq(to);
+            const float inv_d = rsq(d2);
+            dir = to * inv_d;
+            tmax = d2 * inv_d - 2e-3f;
+        }
         o = offset_ray_origin(v.position, v.normal, dir);
     }
     bool occ = true;

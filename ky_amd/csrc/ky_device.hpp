@@ -35,6 +35,9 @@
 #ifndef KY_IPDF
 #define KY_IPDF 1
 #endif
+#ifndef KY_PDF_CLASS
+#define KY_PDF_CLASS 1
+#endif
 #ifndef KY_SPH_ANY_BOUND
 #define KY_SPH_ANY_BOUND 1
 #endif
@@ -1218,7 +1221,13 @@ KY_DEV void shape_sample_direction(const DLight& L, f3 p, f3 p_normal, float u0,
         return;
     }
     const float q = L.inv_area * d2 * rcp(fabsf(dot(nn, wi)));
+#if KY_PDF_CLASS
+    // q is a product of non-negative factors: "d2 == 0 (q is NaN then: 0 x rcp(|NaN|)), infinite or NaN -> 0" is "keep it iff it is a positive finite number": one
+    // v_cmp_class_f32 (+normal | +denormal) instead of three compares and two scalar ors
+    pdf = __builtin_amdgcn_classf(q, 0x180) ? q : 0.f;
+#else
     pdf = (d2 == 0 || __builtin_isinf(q) || q != q) ? 0.f : q;
+#endif
 }
 
 // shape_t::pdf_direction (1055-1090) and sphere_t::pdf_direction (1503-1513)
@@ -1266,7 +1275,8 @@ KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0,
         s.position = lposition;
         const f3 dv = lposition - p;
         const float d2 = length_sq(dv);
-        const bool ok = !((ipdf ? __builtin_isinf(s.pdf) : s.pdf == 0) || d2 == 0);
+        // (a coincident sample of a planar shape has a NaN direction and therefore density 0 already: only the cone sampler's needs the second test)
+        const bool ok = !((ipdf ? __builtin_isinf(s.pdf) : s.pdf == 0) || ((KY_PDF_CLASS && (feat & KY_FEAT_RECT_LIGHTS)) ? false : d2 == 0));
         const float inv_d = rsq(d2);
         const f3 wi = dv * inv_d;
         s.dir = wi;
@@ -1725,7 +1735,7 @@ KY_DEV void estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v
     const bool ip = S.ipdf();   // (compile-time) ls.pdf is the density's reciprocal: shape_sample_direction
     const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1, S.feat, ip);
     const bool area = S.is_area(L.kind);   // (wave-uniform)
-    const bool dead = (area ? !ls.lit : is_black(ls.Li)) || (!ip && (MIS ? (ls.pdf <= 0) : (ls.pdf == 0)));   // (an area light's `lit` says that the density is not zero)
+    const bool dead = (area ? !ls.lit : is_black(ls.Li)) || (!(ip || (KY_PDF_CLASS && area)) && (MIS ? (ls.pdf <= 0) : (ls.pdf == 0)));   // (an area light's `lit` says that the density is not zero -- and it is never negative)
     KY_CLK(5);
     if (!dead) {
         // scene_t::occluded(isect, ls.position), 3187-3201 (an area light's direction and distance: LightSample::dir)

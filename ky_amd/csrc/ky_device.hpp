@@ -35,6 +35,9 @@
 #ifndef KY_IPDF
 #define KY_IPDF 1
 #endif
+#ifndef KY_CARRIER_IN_LIGHT
+#define KY_CARRIER_IN_LIGHT 1
+#endif
 #ifndef KY_PDF_CLASS
 #define KY_PDF_CLASS 1
 #endif
@@ -1414,7 +1417,12 @@ KY_DEV void estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f
         } else {
         for (int k = 0; k < L.n_carriers; ++k) {
             float t;
-            const bool ok = act & surf_hit(scene_surf(S, L.carrier[k]), S->full, o, bs.wi, t_l, t, S.general, S.sphere_lights());
+            bool hit;
+            if (KY_CARRIER_IN_LIGHT && S.sphere_lights() && k == 0)   // the first carrier's sphere from the light's own record (DLight::aar): one load, not index -> table
+                hit = sph_hit(make_float4(L.aar[0], L.aar[1], L.aar[2], L.aar[3]), o, bs.wi, t_l, t, true);
+            else
+                hit = surf_hit(scene_surf(S, L.carrier[k]), S->full, o, bs.wi, t_l, t, S.general, S.sphere_lights());
+            const bool ok = act & hit;
             t_l = ok ? t : t_l;
             c = ok ? L.carrier[k] : c;
         }

@@ -681,6 +681,9 @@ int pack_scene(const ky_scene* in, DScene* out) {
                 else d.n_carriers = -1;
             }
             d.pdf_from_carrier = (d.n_carriers == 1 && d.isect.kind == TK_PARALLELOGRAM && in->surfaces[out->orig[d.carrier[0]]].shape == l.shape) ? 1 : 0;
+            // a sphere lamp's first carrier, if it is a sphere: its record (centre, radius^2) beside the light's own fields -- the BSDF-sampling estimators of the sphere-light
+            // kernels test it from here (DLight::aar is free: the sampled shape is no rectangle) instead of through the carrier's index and the surface table, two dependent loads
+            if (d.aar_axis < 0 && d.n_carriers >= 1 && out->all[d.carrier[0]].kind == TK_SPHERE) std::memcpy(d.aar, out->all[d.carrier[0]].f, 16);
         }
     }
     if (out->n_gen > 0) out->general = 1;

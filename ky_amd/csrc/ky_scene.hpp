@@ -98,7 +98,8 @@ struct DLight {  // light_t + the shape an area light samples; wave-uniform inde
     int32_t shadow_table;         // byte offset (from the scene's base) of the planar table a shadow ray towards a sample of this light scans first -- DScene::occ_front for the
                                   // two-stage light (bit 0 set: occ_behind follows for rays with an end behind its plane), DScene::occ when occ_ok, DScene::trav otherwise --
                                   // decided once by the host instead of by three scalar loads and two compares per light sample
-    float aar[5];                 // the sampled shape as a rectangle in an axis plane (DAar's c, mu, ru, mv, rv) when it is one ...
+    float aar[5];                 // the sampled shape as a rectangle in an axis plane (DAar's c, mu, ru, mv, rv) when it is one (a lamp that is no rectangle: aar[0..3] = its first
+                                  // carrier's sphere record, centre and radius^2, when that carrier is a sphere) ...
     int32_t aar_axis;             // ... in the plane x_axis = c; -1: it is not (KY_FEAT_AXIS_ALIGNED kernels test the lamp with it: estimate_by_bsdf)
     int32_t pad_a[2];
     DSurf isect;          // traversal record of the sampled shape (pdf_direction re-intersects it, 1057-1061)

@@ -1404,9 +1404,20 @@ KY_DEV void estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f
                 const float4 q0 = make_float4(L.aar[0], L.aar[1], L.aar[2], L.aar[3]);
                 const float rv = L.aar[4];
                 const int ax = L.aar_axis;
-                if (ax == 0) hit = aar_hit<0>(q0, rv, o, bs.wi, mk3(rcp(bs.wi.x), 0.f, 0.f), K_INF, t);
-                else if (ax == 1) hit = aar_hit<1>(q0, rv, o, bs.wi, mk3(0.f, rcp(bs.wi.y), 0.f), K_INF, t);
-                else hit = aar_hit<2>(q0, rv, o, bs.wi, mk3(0.f, 0.f, rcp(bs.wi.z)), K_INF, t);
+                // (each copy ends in an asm statement of its own: without them the compiler merges the three bodies into one behind six to eighteen register moves that
+                // permute its operands -- more than the test's own arithmetic)
+                float u_, v_;
+                if (ax == 0) {
+                    t = (q0.x - o.x) * rcp(bs.wi.x); u_ = (o.y + t * bs.wi.y) - q0.y; v_ = (o.z + t * bs.wi.z) - q0.w;
+                    asm volatile("; lamp in an x plane" : "+v"(t), "+v"(u_), "+v"(v_));
+                } else if (ax == 1) {
+                    t = (q0.x - o.y) * rcp(bs.wi.y); u_ = (o.z + t * bs.wi.z) - q0.y; v_ = (o.x + t * bs.wi.x) - q0.w;
+                    asm volatile("; lamp in a y plane" : "+v"(t), "+v"(u_), "+v"(v_));
+                } else {
+                    t = (q0.x - o.z) * rcp(bs.wi.z); u_ = (o.x + t * bs.wi.x) - q0.y; v_ = (o.y + t * bs.wi.y) - q0.w;
+                    asm volatile("; lamp in a z plane" : "+v"(t), "+v"(u_), "+v"(v_));
+                }
+                hit = (fabsf(u_) <= q0.z) & (fabsf(v_) <= rv) & (t > K_SHAPE_EPS);   // aar_hit with tmax = inf
             } else {
                 hit = par_hit(make_float4(R.f[0], R.f[1], R.f[2], R.f[3]), make_float4(R.f[4], R.f[5], R.f[6], R.f[7]), make_float4(R.f[8], R.f[9], R.f[10], R.f[11]), o, bs.wi, K_INF, t);
             }

@@ -171,6 +171,7 @@ struct SceneRef {
     __device__ __forceinline__ bool may_have_env() const { return (feat & (KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_DELTA | KY_FEAT_SPHERE_LIGHTS)) == 0; }
     __device__ __forceinline__ bool sphere_lights() const { return (feat & KY_FEAT_SPHERE_LIGHTS) != 0; }
     __device__ __forceinline__ bool boxes() const { return (feat & KY_FEAT_BOXES) != 0; }
+    __device__ __forceinline__ bool flat_phong() const { return (feat & KY_FEAT_FLAT_PHONG) != 0; }   // every plastic surface is a rectangle (bsdf_sample_dir_nondelta)
     __device__ __forceinline__ bool no_par() const { return (feat & KY_FEAT_AXIS_ALIGNED) != 0; }   // every planar surface is a rectangle in an axis plane: no parallelogram loops   // nearest-hit traversals scan DScene::boxtrav
     // the light-sampling estimators work with the RECIPROCAL of the light's density (shape_sample_direction): where every light is a sphere lamp
     __device__ __forceinline__ bool ipdf() const { return KY_IPDF && (feat & KY_FEAT_SPHERE_LIGHTS) != 0; }   // (measured on the one-rectangle-lamp kernel too: configs[1] -0.3 %, not taken)
@@ -998,7 +999,7 @@ KY_DEV void bsdf_eval_parts(const Vertex& v, f3 wo, f3 wi, f3& col, float& scale
 // `back_dead` (bsdf_continue): set when a Phong sample taken from the BACK side of its surface (wo.z < 0: the flip of 2539 moves wi away from
 // the lobe's axis) has pdf_ = 0 -- the reference clamps cos_alpha at 0 there (2549) and ends the path (4588); from the front side
 // cos_alpha = z and the caller's u1 > 0 test decides.
-KY_DEV f3 bsdf_sample_dir_nondelta(const Vertex& v, f3 wo, float u0, float u1, bool* back_dead = nullptr) {
+KY_DEV f3 bsdf_sample_dir_nondelta(const Vertex& v, f3 wo, float u0, float u1, bool* back_dead = nullptr, bool flat_phong = false) {
     const bool phong = v.bsdf.lobe == LOBE_PHONG;
     const float cos_o = dot(v.normal, wo);
     float ang, rad, z = any_f();
@@ -1022,6 +1023,9 @@ KY_DEV f3 bsdf_sample_dir_nondelta(const Vertex& v, f3 wo, float u0, float u1, b
     }
     const LobeBasis L = vertex_basis(v);
     f3 wi = L.a * px + L.b * py + L.c * z;
+    // (`flat_phong`, KY_FEAT_FLAT_PHONG: every plastic surface is a rectangle, so wo is never below a Phong lobe's normal and this block is dead -- which matters because the
+    // compiler turns it into a dot product, three multiply-adds and three selects that EVERY direction sample executes: ten instructions, twice per Cornell vertex, six times per Veach vertex)
+    if (!flat_phong)
     if (phong && cos_o < 0) {   // `if (wo.z < 0) wi.z *= -1` (2539) in world space; rectangles face the ray (1289), so this is the inside of a plastic sphere
         const float nw = dot(v.normal, wi);
         wi = wi - (2.f * nw) * v.normal;
@@ -1104,7 +1108,7 @@ struct BsdfContinue {
     f3 wi, weight;
     bool ok, specular;
 };
-KY_DEV BsdfContinue bsdf_continue(const Vertex& v, f3 wo, float u0, float u1) {
+KY_DEV BsdfContinue bsdf_continue(const Vertex& v, f3 wo, float u0, float u1, bool flat_phong = false) {
     BsdfContinue c;
     c.specular = bsdf_is_delta(v.bsdf);
     if (c.specular) {
@@ -1114,7 +1118,7 @@ KY_DEV BsdfContinue bsdf_continue(const Vertex& v, f3 wo, float u0, float u1) {
         c.ok = !is_black(c.weight) && d.percent != 0.f;
     } else {
         bool back_dead = false;
-        c.wi = bsdf_sample_dir_nondelta(v, wo, u0, u1, &back_dead);
+        c.wi = bsdf_sample_dir_nondelta(v, wo, u0, u1, &back_dead, flat_phong);
         const float cos_o = dot(v.normal, wo), cos_i = dot(v.normal, c.wi);
         const bool phong = v.bsdf.lobe == LOBE_PHONG;
         const f3 col = ld3(phong ? v.bsdf.m->c1 : v.bsdf.m->c0);
@@ -1382,7 +1386,7 @@ KY_DEV void estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f
         // (Delta lobes never get here: sample_all_light runs for non-delta vertices only, 4571.)
         const bool act = active && !bsdf_is_delta(v.bsdf);
         if (act) {
-            bs.wi = bsdf_sample_dir_nondelta(v, wo, u0, u1);
+            bs.wi = bsdf_sample_dir_nondelta(v, wo, u0, u1, nullptr, S.flat_phong());
             o = offset_ray_origin(v.position, v.normal, bs.wi);  // isect.spawn_ray, 665-668
         }
         // (a) nearest carrier surface along the ray, and what it emits towards the ray (3084, 2957-2960)
@@ -2099,7 +2103,7 @@ KY_DEV bool path_shade(PathState& ps, Vertex& v, SceneRef S, const LdsScene& Lds
         // path_tracing_iteration_t, 4586-4616, with the sample's value, cosine and pdf folded into one factor (bsdf_continue).
         // Straight-line: a path that ends here never reads its ray or throughput again, so every lane updates them and `cont` alone says
         // whether the path goes on -- no copies of the old state on the ways out, no exec-mask bookkeeping around them.
-        const BsdfContinue c = bsdf_continue(v, wo, u0, u1);
+        const BsdfContinue c = bsdf_continue(v, wo, u0, u1, S.flat_phong());
         bool cont = c.ok;  // 4588
         ps.beta = ps.beta * c.weight;  // 4592
         ps.prev_specular = c.specular;  // 4596

@@ -268,25 +268,26 @@ struct Variant {
 constexpr int IT = KY_INTEGRATOR_PATH_TRACING_ITERATION;
 static const Variant g_variants[] = {
 #ifdef KY_FEW_VARIANTS   // measurement builds (tools/mkvariant.sh -DKY_FEW_VARIANTS): the headline kernels and one catch-all, compiled in a sixth of the time
-    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES | KY_FEAT_BOXES | KY_FEAT_AXIS_ALIGNED, IT),
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES | KY_FEAT_BOXES | KY_FEAT_AXIS_ALIGNED | KY_FEAT_FLAT_PHONG, IT),
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES | KY_FEAT_BOXES, IT),
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES, IT),
-    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, KY_FEAT_VEACH, IT),
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, KY_FEAT_VEACH | KY_FEAT_FLAT_PHONG, IT),
     KY_VARIANT(false, -1, false, false, 0, IT),
 #else
     // the iterative integrator, both_mis: by scene facts
-    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES | KY_FEAT_BOXES | KY_FEAT_AXIS_ALIGNED, IT),   // ... and nothing planar but axis rectangles: configs[1], [4]
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES | KY_FEAT_BOXES | KY_FEAT_AXIS_ALIGNED | KY_FEAT_FLAT_PHONG, IT),   // ... and nothing planar but axis rectangles: configs[1], [4]
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES | KY_FEAT_BOXES, IT),   // ... whose walls / lamp housing are faces of boxes
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES | KY_FEAT_AXIS_ALIGNED, IT),   // ... axis rectangles only, no boxes (kyhip_set_boxes(0): the
                                                                                                            // kernel the tests hold against the fact-free one to 2.4e-7)
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES, IT),   // one rectangle area light, at most 16 surfaces and 8 materials
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL, IT),                  // one rectangle area light
-    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_DELTA | KY_FEAT_BOXES | KY_FEAT_AXIS_ALIGNED, IT),   // one point / directional light in a room that is a box (configs[3]'s frames)
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_DELTA | KY_FEAT_BOXES | KY_FEAT_AXIS_ALIGNED | KY_FEAT_FLAT_PHONG, IT),   // one point / directional light in a room that is a box (configs[3]'s frames)
     // (measured and not taken: KY_FEAT_SINGLE_ENV | KY_FEAT_BOXES -- the environment-light frame of configs[3] 153.9 -> 164.1 ms: its BSDF-sampled rays are nearest-hit
     // traversals too and the instantiation's allocation does not take the second copy of the box code well)
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_DELTA, IT),             // one point / directional light
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_ENV, IT),               // one environment light
-    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, KY_FEAT_VEACH, IT),                     // several sphere lights, no mirror / glass: configs[2]
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, KY_FEAT_VEACH | KY_FEAT_FLAT_PHONG, IT),   // several sphere lights, no mirror / glass, plastic on rectangles only: configs[2]
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, KY_FEAT_VEACH, IT),                     // several sphere lights, no mirror / glass
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, 0, IT),                                 // many sphere lamps (shadow_queue_wanted): deferred shadow rays
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, 0, IT),
     // the iterative integrator, the other five strategies (render_direct_sample_enum 4779, render_mis_scene 4878)

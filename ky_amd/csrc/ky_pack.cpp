@@ -619,6 +619,10 @@ int pack_scene(const ky_scene* in, DScene* out) {
         if (no_delta) out->feat |= KY_FEAT_NO_DELTA;
         if (in->surface_count <= KY_LDS_SURFACES_SMALL && in->material_count <= KY_LDS_MATERIALS_SMALL) out->feat |= KY_FEAT_SMALL_TABLES;
         if (out->boxtrav.n_box > 0) out->feat |= KY_FEAT_BOXES;
+        bool flat_phong = true;
+        for (int i = 0; i < in->surface_count; ++i)
+            if (in->materials[in->surfaces[i].material].kind == KY_MATERIAL_PLASTIC && in->shapes[in->surfaces[i].shape].kind != KY_SHAPE_RECTANGLE) flat_phong = false;
+        if (flat_phong) out->feat |= KY_FEAT_FLAT_PHONG;
         if (out->trav.n_aar > 0 && out->trav.n_par == 0 && out->n_gen == 0) out->feat |= KY_FEAT_AXIS_ALIGNED;   // (n_gen: the surfaces are laid out above)
     }
     if (non.ts_light >= 0) {

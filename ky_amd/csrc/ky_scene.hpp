@@ -217,6 +217,8 @@ enum : int {
                                  // tests a box with one slab test instead of its faces one by one (DScene::boxtrav)
     KY_FEAT_AXIS_ALIGNED = 1024, // every planar surface is a rectangle in an axis plane and there are no general shapes: no parallelogram loops in the traversals, and a lamp
                                  // that is its own carrier (KY_FEAT_OWN_CARRIER) is tested as such a rectangle
+    KY_FEAT_FLAT_PHONG = 2048,   // every surface with a plastic material is a rectangle -- a shape that reports the normal facing the ray (1289) --, so no Phong lobe is ever
+                                 // entered from below its normal: the `if (wo.z < 0) wi.z *= -1` of 2539 is dead code
     KY_FEAT_SMALL_TABLES = 128   // at most KY_LDS_SURFACES_SMALL surfaces and KY_LDS_MATERIALS_SMALL materials: the per-lane tables' LDS block is 1.1 KB instead of
                                  // 3.8 (what lets the sphere-lights kernel with its deferred rays' sums fit a seventh workgroup per CU)
 };

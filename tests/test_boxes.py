@@ -60,13 +60,14 @@ def test_scene_facts(A, api):
     """kyhip_scene_facts: what decides the instantiation a launch takes (ky_scene.hpp's KY_FEAT_*)."""
     lib = A.load_kyhip()
     area = api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | A.CB_LIGHT_AREA, 64, 64)
-    # one area light (1) that samples a rectangle (2), few carriers (4), small tables (128), the lamp is its own carrier (256), boxes (512), all planar surfaces axis rectangles (1024)
-    assert api.scene_facts(area) == 1 + 2 + 4 + 128 + 256 + 512 + 1024
-    assert api.scene_facts(api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | A.CB_LIGHT_POINT, 64, 64)) == 2 + 4 + 8 + 128 + 512 + 1024   # (no area light: 2 and 4 hold vacuously)
-    assert api.scene_facts(api.mis_scene(96, 54)) == 4 + 32 + 64 + 128                  # sphere lamps, no delta lobes; its planks are tilted: no 1024
+    # one area light (1) that samples a rectangle (2), few carriers (4), small tables (128), the lamp is its own carrier (256), boxes (512), all planar surfaces axis rectangles (1024),
+    # the one plastic surface (the floor) a rectangle (2048)
+    assert api.scene_facts(area) == 1 + 2 + 4 + 128 + 256 + 512 + 1024 + 2048
+    assert api.scene_facts(api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | A.CB_LIGHT_POINT, 64, 64)) == 2 + 4 + 8 + 128 + 512 + 1024 + 2048   # (no area light: 2 and 4 hold vacuously)
+    assert api.scene_facts(api.mis_scene(96, 54)) == 4 + 32 + 64 + 128 + 2048                  # sphere lamps, no delta lobes; its planks are tilted: no 1024
     prev = lib.kyhip_set_boxes(0)
     try:
-        assert api.scene_facts(area) == 1 + 2 + 4 + 128 + 256 + 1024
+        assert api.scene_facts(area) == 1 + 2 + 4 + 128 + 256 + 1024 + 2048
     finally:
         lib.kyhip_set_boxes(prev)
     prev = lib.kyhip_set_specialisation(0)
@@ -190,8 +191,8 @@ def test_images_with_and_without_boxes(A, api):
         finally:
             lib.kyhip_set_boxes(prev)
         if flag == A.CB_LIGHT_AREA and "render_kernel<strategy 48" in kernel:
-            # 1 + 2 + 4 + 128 + 256 (the lamp kernel's facts) + 512 (boxes) + 1024 (every planar surface an axis rectangle); without boxes the 1415 row
-            assert "feat 1927" in kernel and "feat 1415" in kernel_off, (kernel, kernel_off)
+            # 1 + 2 + 4 + 128 + 256 (the lamp kernel's facts) + 512 (boxes) + 1024 (every planar surface an axis rectangle) + 2048 (plastic on rectangles only); without boxes the 1415 row
+            assert "feat 3975" in kernel and "feat 1415" in kernel_off, (kernel, kernel_off)
         fin = np.isfinite(on) & np.isfinite(off)
         d = np.abs(on - off)[fin]
         # a sample whose path takes another discrete decision (a shadow ray at its threshold) moves its pixel by up to 1 / spp of the clamp range: few of them
@@ -278,7 +279,7 @@ def test_boxy_rooms_nobody_tuned_for(A, api, O, seed):
     film, ref = api.render(scene, p), O.render(scene, p)
     kernel = lib.kyhip_last_kernel(0).decode()
     if "render_kernel<strategy 48" in kernel and seed % 2 == 0:
-        assert "feat %d" % (facts & ((8 | 512 | 1024) if seed % 4 < 2 else (1 | 2 | 4 | 128 | 256 | 512 | 1024))) in kernel, (seed, facts, kernel)
+        assert "feat %d" % (facts & ((8 | 512 | 1024 | 2048) if seed % 4 < 2 else (1 | 2 | 4 | 128 | 256 | 512 | 1024 | 2048))) in kernel, (seed, facts, kernel)
     fin = np.isfinite(ref).all(axis=2)
     assert np.isfinite(film).all() and fin.mean() > 0.995 and ref.mean() > 0.002, (seed, float(ref.mean()))
     e = rmse(film[fin], ref[fin])

@@ -62,8 +62,8 @@ def test_instantiated_kernels_render_what_the_table_renders(A, api, O, tmp_path,
         if len(kinds) >= 2:
             room = cand
             break
-    cases = [(api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | A.CB_LIGHT_POINT, W, H), api.make_params(W, H, 64), b", 1166, "),                   # the table has feat 8 for it (boxes off here); all of the scene's facts: 8 + 2 + 4 + 128 + 1024
-             (api.mis_scene(W, H), api.make_params(W, H, 32, direct_sample=A.DIRECT_LIGHT_MIS), None),                             # in the table: nothing to compile
+    cases = [(api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | A.CB_LIGHT_POINT, W, H), api.make_params(W, H, 64), b", 3214, "),                   # the table has feat 8 for it (boxes off here); all of the scene's facts: 8 + 2 + 4 + 128 + 1024 + 2048
+             (api.mis_scene(W, H), api.make_params(W, H, 32), None),                                                                # in the table with ALL of its facts (2276): nothing to compile
              (room, api.make_params(W, H, 64), b"48, false, false, "),                                                              # two lights, shadow rays inline, this room's facts (132 / 134; + 256 when its lamps are their own carriers)
              (room, api.make_params(W, H, 64), b"48, true, false, "),                                                               # the same with deferred rays (forced: kyhip_set_shadow_queue)
              (general_shapes_scene(A, api), api.make_params(48, 40, 64, direct_sample=A.DIRECT_LIGHT_MIS), b"32, "),               # the table: strategy at run time

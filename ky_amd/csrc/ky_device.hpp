@@ -79,8 +79,26 @@ KY_DEV float any_reg() { return any_f(); }
 KY_DEV unsigned any_reg_u() { unsigned x; asm volatile("" : "=v"(x)); return x; }
 // (The compiler puts an `s_nop 0` next to every such statement -- its hazard recogniser cannot see inside an inline asm -- 44 per loop turn of the hot kernel.  They are
 // free: round 5 measured one statement with thirteen outputs against thirteen statements at 42.92 against 42.95-42.99 ms on configs[1]; s_nop does not take a scalar-ALU slot.)
+// v_mul_legacy_f32: the product with 0 x anything = 0 (inf and NaN included), otherwise the IEEE product bit for bit.  It turns two special cases into no case at all:
+// pow(x, 0) = 1 for every x (0 x log2(x) = 0 also for log2(0) = -inf and for NaN, as std::pow has it), and the concentric map's 0 / 0 at the square's centre
+// (0 x (1 / 0) = 0: the centre maps to the centre) -- a compare and a select, or two compares, a scalar and and two selects, per call otherwise.
+#ifndef KY_MUL_LEGACY
+#define KY_MUL_LEGACY 1
+#endif
+// (the s_nop: an operand may come straight from a quarter-rate instruction -- v_rcp_f32, v_log_f32 -- whose result the next VALU instruction must not read without a wait
+// state; the compiler's hazard recogniser does not look inside an asm statement, and without the wait the product was made from a stale register: measured, 0.3 % of a film's mean)
+KY_DEV float mul_legacy(float a, float b) { float r; asm("s_nop 0\n\tv_mul_legacy_f32_e64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // x^n for x >= 0 (pow(0, n > 0) = 0, pow(x, 0) = 1)
-KY_DEV float pow_nonneg(float x, float n) { return n == 0.f ? 1.f : __builtin_amdgcn_exp2f(n * __builtin_amdgcn_logf(x)); }
+#ifndef KY_MUL_LEGACY_POW
+#define KY_MUL_LEGACY_POW KY_MUL_LEGACY
+#endif
+KY_DEV float pow_nonneg(float x, float n) {
+#if KY_MUL_LEGACY_POW
+    return __builtin_amdgcn_exp2f(mul_legacy(n, __builtin_amdgcn_logf(x)));
+#else
+    return n == 0.f ? 1.f : __builtin_amdgcn_exp2f(n * __builtin_amdgcn_logf(x));
+#endif
+}
 
 // ---------------------------------------------------------------------------------------------
 // vectors (ky.cpp:226-388)
@@ -842,11 +860,18 @@ KY_DEV void concentric_disk(float u0, float u1, float& px, float& py) {
     const float rx = 2.f * u0 - 1, ry = 2.f * u1 - 1;
     const bool xmajor = fabsf(rx) > fabsf(ry);
     const float radius = xmajor ? rx : ry;
+#if KY_MUL_LEGACY
+    const float ratio = mul_legacy(xmajor ? ry : rx, rcp(radius));    // rx = ry = 0: 0 x (1 / 0) = 0, and the radius is 0
+    const float rev = xmajor ? 0.125f * ratio : 0.25f - 0.125f * ratio;  // (pi/4) q, pi/2 - (pi/4) q
+    px = cos_rev(rev) * radius;
+    py = sin_rev(rev) * radius;
+#else
     const float ratio = (xmajor ? ry : rx) * rcp(radius);             // 0/0 = NaN only when rx = ry = 0, handled below
     const float rev = xmajor ? 0.125f * ratio : 0.25f - 0.125f * ratio;  // (pi/4) q, pi/2 - (pi/4) q
     const bool origin = (rx == 0 && ry == 0);
     px = origin ? 0.f : cos_rev(rev) * radius;
     py = origin ? 0.f : sin_rev(rev) * radius;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1012,9 +1037,14 @@ KY_DEV f3 bsdf_sample_dir_nondelta(const Vertex& v, f3 wo, float u0, float u1, b
         const float rx = 2.f * u0 - 1, ry = 2.f * u1 - 1;
         const bool xmajor = fabsf(rx) > fabsf(ry);
         rad = xmajor ? rx : ry;
+#if KY_MUL_LEGACY
+        const float ratio = mul_legacy(xmajor ? ry : rx, rcp(rad));        // rx = ry = 0: 0 x (1 / 0) = 0 (mul_legacy): the radius is 0 and the centre maps to the centre
+        ang = xmajor ? 0.125f * ratio : 0.25f - 0.125f * ratio;            // (pi/4) q, pi/2 - (pi/4) q
+#else
         const float ratio = (xmajor ? ry : rx) * rcp(rad);                 // 0/0 = NaN only when rx = ry = 0, handled below
         ang = xmajor ? 0.125f * ratio : 0.25f - 0.125f * ratio;            // (pi/4) q, pi/2 - (pi/4) q
         origin = (rx == 0 && ry == 0);
+#endif
     }
     float px = cos_rev(ang) * rad, py = sin_rev(ang) * rad;
     if (!phong) {   // cosine_hemisphere_sample 737-743, flipped into wo's hemisphere (2247-2249)

@@ -38,6 +38,9 @@
 #ifndef KY_CARRIER_IN_LIGHT
 #define KY_CARRIER_IN_LIGHT 1
 #endif
+#ifndef KY_BLACK_FLAGS
+#define KY_BLACK_FLAGS 1
+#endif
 #ifndef KY_PDF_CLASS
 #define KY_PDF_CLASS 1
 #endif
@@ -1145,16 +1148,26 @@ KY_DEV BsdfContinue bsdf_continue(const Vertex& v, f3 wo, float u0, float u1, bo
         const DeltaSample d = bsdf_sample_delta(v, wo, u0);
         c.wi = d.wi;
         c.weight = ld3(d.reflected ? v.bsdf.m->c0 : v.bsdf.m->c1);
+#if KY_BLACK_FLAGS
+        c.ok = ((v.bsdf.m->exp_flags & (d.reflected ? 4 : 8)) != 0) & (d.percent != 0.f);   // !is_black(weight): a constant of the material, decided by the host (DMat::exp_flags)
+#else
         c.ok = !is_black(c.weight) && d.percent != 0.f;
+#endif
     } else {
         bool back_dead = false;
         c.wi = bsdf_sample_dir_nondelta(v, wo, u0, u1, &back_dead, flat_phong);
         const float cos_o = dot(v.normal, wo), cos_i = dot(v.normal, c.wi);
         const bool phong = v.bsdf.lobe == LOBE_PHONG;
         const f3 col = ld3(phong ? v.bsdf.m->c1 : v.bsdf.m->c0);
+#if KY_BLACK_FLAGS
+        c.weight = col * (phong ? fabsf(cos_i) : 1.f);   // (one select, three products: col x 1 is col)
+        const bool dead_u1 = phong & !(u1 > 0.f) & (v.bsdf.m->exponent > 0.f);   // (bitwise: every operand is at hand, no short-circuit branches)
+        c.ok = (cos_o * cos_i > 0) & ((v.bsdf.m->exp_flags & (phong ? 8 : 4)) != 0) & !dead_u1 & !back_dead;
+#else
         c.weight = phong ? col * fabsf(cos_i) : col;
         const bool dead_u1 = phong & !(u1 > 0.f) & (v.bsdf.m->exponent > 0.f);   // (bitwise: every operand is at hand, no short-circuit branches)
         c.ok = (cos_o * cos_i > 0) & !is_black(col) & !dead_u1 & !back_dead;
+#endif
     }
     return c;
 }

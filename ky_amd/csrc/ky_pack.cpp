@@ -227,6 +227,9 @@ void pack_material(const ky_material& m, DMat* d) {
     const float e = m.exponent;
     const bool integral = std::isfinite(e) && std::fabs(e) < 16777216.f && std::floor(e) == e;
     d->exp_flags = (integral ? 1 : 0) | ((integral && std::fmod(std::fabs(e), 2.f) == 1.f) ? 2 : 0);
+    // bits 2 / 3: c0 / c1 as packed above is not black (color_t::is_black, 258: every channel <= 0) -- the test of 4588 on a colour that is a constant of the material
+    if (!(d->c0[0] <= 0 && d->c0[1] <= 0 && d->c0[2] <= 0)) d->exp_flags |= 4;
+    if (!(d->c1[0] <= 0 && d->c1[1] <= 0 && d->c1[2] <= 0)) d->exp_flags |= 8;
 }
 
 // the stored normal of a disk / triangle / rectangle must be unit length (the reference's constructors normalise it:

@@ -106,4 +106,6 @@ int get_ctx(int device, DeviceCtx** out);       // looks the context of `device`
 DeviceCtx* find_ctx(int device);
 int get_stream_state(DeviceCtx* c, hipStream_t stream, StreamState** out);
 int upload_scene(DeviceCtx* c, const ky_scene* scene, hipStream_t stream, SceneSlot** out);
+// whether kyhip_render_tiles_device runs these parameters on a table kernel with the box traversal (KY_FEAT_BOXES): the per-sample replay entries (ky_kat.hip) take the same traversal
+bool render_uses_boxes(const ky_scene* scene, const ky_render_params* p, const kyd::DScene* packed);
 }  // namespace kyh

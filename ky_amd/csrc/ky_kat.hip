@@ -100,8 +100,11 @@ __global__ void kat_occluded_kernel(const DScene* __restrict__ S, const float* _
     out1[i] = occ ? 1.f : 0.f;
 }
 
-template <bool DEBUG_SAMPLER>
-__global__ void kat_li_kernel(const DScene* __restrict__ S, RenderConst rc, int x, int y, int s0, int n, float* __restrict__ out3) {
+// BOXES: the launch these samples replay runs a kernel with the box traversal (render_uses_boxes): the replay takes the same one, so that "per sample what render() did" holds
+// to the last decision (a ray along a box's edge may take the other face in the other traversal)
+template <bool DEBUG_SAMPLER, bool BOXES>
+__global__ void kat_li_kernel(const DScene* __restrict__ S_, RenderConst rc, int x, int y, int s0, int n, float* __restrict__ out3) {
+    const SceneRef S{S_, true, BOXES ? KY_FEAT_BOXES : 0, true};
     const LdsScene Lds = stage_scene<true>(S);   // KAT kernels: always the scene-sized dynamic block
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     PathState ps;
@@ -149,8 +152,9 @@ __global__ void kat_nee_kernel(const DScene* __restrict__ S, int strategy, int l
 }
 
 // one camera sample, traced vertex by vertex (lane 0 walks the path; the other lanes only keep the wave-uniform calls company)
-template <bool DEBUG_SAMPLER>
-__global__ void kat_li_trace_kernel(const DScene* __restrict__ S, RenderConst rc, int x, int y, int s, int max_rows, float* __restrict__ out) {
+template <bool DEBUG_SAMPLER, bool BOXES>
+__global__ void kat_li_trace_kernel(const DScene* __restrict__ S_, RenderConst rc, int x, int y, int s, int max_rows, float* __restrict__ out) {
+    const SceneRef S{S_, true, BOXES ? KY_FEAT_BOXES : 0, true};
     const LdsScene Lds = stage_scene<true>(S);   // KAT kernels: always the scene-sized dynamic block
     PathState ps;
     bool alive = threadIdx.x == 0;
@@ -277,8 +281,13 @@ int kyhip_kat_li(int device, const ky_scene* scene, const ky_render_params* p, i
     return kat_run(device, &dummy, 4, out3, (size_t)n * 3 * 4, [&](DeviceCtx* c, const float*, float* d_out) {
         SceneSlot* sc; int r = upload_scene(c, scene, 0, &sc);
         if (r != KY_OK) return r;
-        if (dbg) hipLaunchKernelGGL(kat_li_kernel<true>, dim3((n + 255) / 256), dim3(256), lds_scene_bytes(scene->surface_count, scene->material_count, scene->light_count), 0, (const DScene*)sc->d, rc, x, y, s0, n, d_out);
-        else hipLaunchKernelGGL(kat_li_kernel<false>, dim3((n + 255) / 256), dim3(256), lds_scene_bytes(scene->surface_count, scene->material_count, scene->light_count), 0, (const DScene*)sc->d, rc, x, y, s0, n, d_out);
+        const size_t lds = lds_scene_bytes(scene->surface_count, scene->material_count, scene->light_count);
+        const dim3 grid((n + 255) / 256), block(256);
+        const bool boxes = render_uses_boxes(scene, p, sc->h);
+        if (dbg && boxes) hipLaunchKernelGGL((kat_li_kernel<true, true>), grid, block, lds, 0, (const DScene*)sc->d, rc, x, y, s0, n, d_out);
+        else if (dbg) hipLaunchKernelGGL((kat_li_kernel<true, false>), grid, block, lds, 0, (const DScene*)sc->d, rc, x, y, s0, n, d_out);
+        else if (boxes) hipLaunchKernelGGL((kat_li_kernel<false, true>), grid, block, lds, 0, (const DScene*)sc->d, rc, x, y, s0, n, d_out);
+        else hipLaunchKernelGGL((kat_li_kernel<false, false>), grid, block, lds, 0, (const DScene*)sc->d, rc, x, y, s0, n, d_out);
         return (int)KY_OK;
     });
 }
@@ -311,8 +320,12 @@ int kyhip_kat_li_trace(int device, const ky_scene* scene, const ky_render_params
     const int rcode = kat_run(device, &dummy, 4, host.data(), host.size() * 4, [&](DeviceCtx* c, const float*, float* d_out) {
         SceneSlot* sc; int r = upload_scene(c, scene, 0, &sc);
         if (r != KY_OK) return r;
-        if (dbg) hipLaunchKernelGGL(kat_li_trace_kernel<true>, dim3(1), dim3(64), lds_scene_bytes(scene->surface_count, scene->material_count, scene->light_count), 0, (const DScene*)sc->d, rc, x, y, s, max_rows, d_out);
-        else hipLaunchKernelGGL(kat_li_trace_kernel<false>, dim3(1), dim3(64), lds_scene_bytes(scene->surface_count, scene->material_count, scene->light_count), 0, (const DScene*)sc->d, rc, x, y, s, max_rows, d_out);
+        const size_t lds = lds_scene_bytes(scene->surface_count, scene->material_count, scene->light_count);
+        const bool boxes = render_uses_boxes(scene, p, sc->h);
+        if (dbg && boxes) hipLaunchKernelGGL((kat_li_trace_kernel<true, true>), dim3(1), dim3(64), lds, 0, (const DScene*)sc->d, rc, x, y, s, max_rows, d_out);
+        else if (dbg) hipLaunchKernelGGL((kat_li_trace_kernel<true, false>), dim3(1), dim3(64), lds, 0, (const DScene*)sc->d, rc, x, y, s, max_rows, d_out);
+        else if (boxes) hipLaunchKernelGGL((kat_li_trace_kernel<false, true>), dim3(1), dim3(64), lds, 0, (const DScene*)sc->d, rc, x, y, s, max_rows, d_out);
+        else hipLaunchKernelGGL((kat_li_trace_kernel<false, false>), dim3(1), dim3(64), lds, 0, (const DScene*)sc->d, rc, x, y, s, max_rows, d_out);
         return (int)KY_OK;
     });
     if (rcode != KY_OK) return rcode;

@@ -355,6 +355,13 @@ static const Variant* pick_variant(const ky_render_params* p, const DScene* pack
     return nullptr;   // not reached: the last entries accept everything
 }
 
+}  // extern "C"
+bool kyh::render_uses_boxes(const ky_scene* scene, const ky_render_params* p, const DScene* packed) {   // (ky_ctx.hpp)
+    const Variant* v = pick_variant(p, packed, shadow_queue_wanted(scene), p->width * p->height);
+    return v != nullptr && (v->feat & KY_FEAT_BOXES) != 0;
+}
+extern "C" {
+
 int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render_params* p, float* d_tiles, void* d_workspace,
                               size_t workspace_bytes, void* stream_) {
     if (!valid_params(p)) return fail(KY_ERR_INVALID_VALUE, "invalid render params (integrator %d, direct_sample %d)", p ? p->integrator : -1, p ? p->direct_sample : -1);

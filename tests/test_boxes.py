@@ -291,5 +291,13 @@ def test_boxy_rooms_nobody_tuned_for(A, api, O, seed):
     fin = np.isfinite(ref).all(axis=2)
     assert np.isfinite(film).all() and fin.mean() > 0.995 and ref.mean() > 0.002, (seed, float(ref.mean()))
     e = rmse(film[fin], ref[fin])
-    print("boxy room %d: %d boxes, facts %d, kernel %s, film RMSE %.2e" % (seed, n_box, facts, kernel.split(" =")[0], e))
-    assert e < 1.5e-3, (seed, e, kernel)
+    note = ""
+    if e >= 1e-3:
+        # one sample of 128 that takes another discrete decision than the oracle's and carries the lamp's radiance is 2e-3 of RMSE on this frame (soak room 14): the pixels that
+        # are off are set aside only if every differing sample of theirs is explained (helpers.explain_pixel asserts it)
+        from helpers import rmse_with_explained_flips
+        e_without, e_with, n_exempt = rmse_with_explained_flips(api, O, scene, p, film, ref, max_exempt=8, threshold=5e-3)
+        note = " (%.2e with %d explained pixel(s))" % (e_with, n_exempt)
+        e = e_without
+    print("boxy room %d: %d boxes, facts %d, kernel %s, film RMSE %.2e%s" % (seed, n_box, facts, kernel.split(" =")[0], e, note))
+    assert e < 1e-3, (seed, e, kernel)

@@ -31,29 +31,6 @@
 
 #define KY_DEV __device__ __forceinline__
 
-// A/B switches of round 5's second half (each a measured default: docs/rounds/round5.md)
-#ifndef KY_IPDF
-#define KY_IPDF 1
-#endif
-#ifndef KY_CARRIER_IN_LIGHT
-#define KY_CARRIER_IN_LIGHT 1
-#endif
-#ifndef KY_BLACK_FLAGS
-#define KY_BLACK_FLAGS 1
-#endif
-#ifndef KY_PDF_CLASS
-#define KY_PDF_CLASS 1
-#endif
-#ifndef KY_SPH_ANY_BOUND
-#define KY_SPH_ANY_BOUND 1
-#endif
-#ifndef KY_AAR_OFFLOOP
-#define KY_AAR_OFFLOOP 1
-#endif
-#ifndef KY_SPH_INVR
-#define KY_SPH_INVR 1
-#endif
-
 // KY_PROBE(k) / KY_CLK(k): lane-utilisation probes and phase clocks of measurement builds (ky_measure.hpp); nothing in product builds
 #if defined(KY_PROFILE_LANES) || defined(KY_PROFILE_CLOCKS) || defined(KY_MARKS)
 #include "ky_measure.hpp"
@@ -85,22 +62,12 @@ KY_DEV unsigned any_reg_u() { unsigned x; asm volatile("" : "=v"(x)); return x; 
 // v_mul_legacy_f32: the product with 0 x anything = 0 (inf and NaN included), otherwise the IEEE product bit for bit.  It turns two special cases into no case at all:
 // pow(x, 0) = 1 for every x (0 x log2(x) = 0 also for log2(0) = -inf and for NaN, as std::pow has it), and the concentric map's 0 / 0 at the square's centre
 // (0 x (1 / 0) = 0: the centre maps to the centre) -- a compare and a select, or two compares, a scalar and and two selects, per call otherwise.
-#ifndef KY_MUL_LEGACY
-#define KY_MUL_LEGACY 1
-#endif
 // (the s_nop: an operand may come straight from a quarter-rate instruction -- v_rcp_f32, v_log_f32 -- whose result the next VALU instruction must not read without a wait
 // state; the compiler's hazard recogniser does not look inside an asm statement, and without the wait the product was made from a stale register: measured, 0.3 % of a film's mean)
 KY_DEV float mul_legacy(float a, float b) { float r; asm("s_nop 0\n\tv_mul_legacy_f32_e64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // x^n for x >= 0 (pow(0, n > 0) = 0, pow(x, 0) = 1)
-#ifndef KY_MUL_LEGACY_POW
-#define KY_MUL_LEGACY_POW KY_MUL_LEGACY
-#endif
 KY_DEV float pow_nonneg(float x, float n) {
-#if KY_MUL_LEGACY_POW
     return __builtin_amdgcn_exp2f(mul_legacy(n, __builtin_amdgcn_logf(x)));
-#else
-    return n == 0.f ? 1.f : __builtin_amdgcn_exp2f(n * __builtin_amdgcn_logf(x));
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -195,7 +162,7 @@ struct SceneRef {
     __device__ __forceinline__ bool flat_phong() const { return (feat & KY_FEAT_FLAT_PHONG) != 0; }   // every plastic surface is a rectangle (bsdf_sample_dir_nondelta)
     __device__ __forceinline__ bool no_par() const { return (feat & KY_FEAT_AXIS_ALIGNED) != 0; }   // every planar surface is a rectangle in an axis plane: no parallelogram loops   // nearest-hit traversals scan DScene::boxtrav
     // the light-sampling estimators work with the RECIPROCAL of the light's density (shape_sample_direction): where every light is a sphere lamp
-    __device__ __forceinline__ bool ipdf() const { return KY_IPDF && (feat & KY_FEAT_SPHERE_LIGHTS) != 0; }   // (measured on the one-rectangle-lamp kernel too: configs[1] -0.3 %, not taken)
+    __device__ __forceinline__ bool ipdf() const { return (feat & KY_FEAT_SPHERE_LIGHTS) != 0; }   // (measured on the one-rectangle-lamp kernel too: configs[1] -0.3 %, not taken)
 };
 
 struct LdsScene {
@@ -363,20 +330,9 @@ KY_DEV void par_coords(const float4 q0, const float4 q1, const float4 q2, f3 o, 
     v = (h.x * q2.x + h.y * q2.y + h.z * q2.z) - q2.w;
 }
 
-// rectangle_t::intersect (1261-1297) for a rectangle in an axis plane: the plane hit is one subtraction and one multiply
-// by the ray's reciprocal direction, the inside test needs only the two in-plane coordinates (12 VALU instead of 26).
+// rectangle_t::intersect (1261-1297) for a rectangle in an axis plane (aar_scan below, and the lamp's test in estimate_by_bsdf): the plane hit is one
+// subtraction and one multiply by the ray's reciprocal direction, the inside test needs only the two in-plane coordinates (12 VALU instead of 26).
 // A zero direction component gives inf / NaN, which compare false.
-template <int AXIS>
-KY_DEV bool aar_hit(const float4 q0, const float ov, f3 o, f3 d, f3 inv_d, float tmax, float& t_out) {
-    const float oa = AXIS == 0 ? o.x : (AXIS == 1 ? o.y : o.z), ia = AXIS == 0 ? inv_d.x : (AXIS == 1 ? inv_d.y : inv_d.z);
-    const float ou_ = AXIS == 0 ? o.y : (AXIS == 1 ? o.z : o.x), du_ = AXIS == 0 ? d.y : (AXIS == 1 ? d.z : d.x);
-    const float ov_ = AXIS == 0 ? o.z : (AXIS == 1 ? o.x : o.y), dv_ = AXIS == 0 ? d.z : (AXIS == 1 ? d.x : d.y);
-    const float t = (q0.x - oa) * ia;
-    const float u = (ou_ + t * du_) - q0.y;
-    const float v = (ov_ + t * dv_) - q0.w;
-    t_out = t;
-    return (fabsf(u) <= q0.z) & (fabsf(v) <= ov) & (t > K_SHAPE_EPS) & (t < tmax);
-}
 
 // Scene tables are addressed as S + (32-bit byte offset): the scalar loads then take the scene pointer as their base and the offset from
 // one SGPR (s_load_dwordx4 s[..], s[S:S+1], s_off offset:16), so no table needs a 64-bit pointer of its own.  As `T.aar + i` the compiler
@@ -398,9 +354,6 @@ KY_DEV const DSurf& scene_surf(SceneRef S, int i) { return scene_at<DSurf>(S, op
 // v_cndmask: one VALU and three SALU instructions more per surface, in loops that run at 0.85 SALU per VALU instruction (the scalar unit retires
 // an instruction per 1.84 ns against 1.1 for the vector unit: ky_amd DESIGN 3, "what bounds the kernel").  `ex` is the mask on entry (wave-uniform control
 // flow inside the scan loops: the same for every surface of a scan).
-#ifndef KY_CMPX
-#define KY_CMPX 1
-#endif
 
 KY_DEV void hit_update_nearest(unsigned long long ex, float u, float ru, float v, float rv, float t, float& tmax, int& best, int i) {
     unsigned long long tmp;
@@ -431,14 +384,13 @@ KY_DEV void hit_update_any(unsigned long long ex, float u, float ru, float v, fl
 // Which form the rectangle loops take (a compile-time choice per instantiation, made by measurement: docs/rounds/round5.md): on the record's byte offset alone
 // (one scalar add per record less) in the sphere-light instantiations -- configs[2] +0.75 % -- and on a counter + offset elsewhere, where the shorter form measured
 // 0.3-0.7 % SLOWER on configs[1] (its register allocation spills one more SGPR in the bookkeeping block).
-KY_DEV bool aar_by_offset(SceneRef S) { return KY_AAR_OFFLOOP && KY_CMPX && S.sphere_lights(); }
+KY_DEV bool aar_by_offset(SceneRef S) { return S.sphere_lights(); }
 
 // the axis-aligned rectangles of one axis: records [first, first + n) of the table at byte offset `aar_off`, whose sorted surface indices are the same
 template <int AXIS, bool NEAREST>
 KY_DEV void aar_scan(SceneRef S, unsigned aar_off, int first, int n, f3 o, f3 d, f3 inv_d, float& tmax, int& best, unsigned& occ_v) {
     if (n <= 0) return;
     unsigned off = aar_off + (unsigned)first * (unsigned)sizeof(DAar);
-#if KY_CMPX
     const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);   // the exec mask here
     const float oa = AXIS == 0 ? o.x : (AXIS == 1 ? o.y : o.z), ia = AXIS == 0 ? inv_d.x : (AXIS == 1 ? inv_d.y : inv_d.z);
     const float ou_ = AXIS == 0 ? o.y : (AXIS == 1 ? o.z : o.x), du_ = AXIS == 0 ? d.y : (AXIS == 1 ? d.z : d.x);
@@ -473,23 +425,6 @@ KY_DEV void aar_scan(SceneRef S, unsigned aar_off, int first, int n, f3 o, f3 d,
         else hit_update_any(ex, u, q0.z, v, rv, t, tmax, occ_v);
         off += (unsigned)sizeof(DAar);
     }
-#else
-    for (int i = first; i < first + n; ++i) {
-        asm volatile("" : "+s"(off));
-        const DAar& r = scene_at<DAar>(S, off);
-        const float4 q0 = r.q0;
-        const float ov = r.q1.x;
-        float t;
-        const bool ok = aar_hit<AXIS>(q0, ov, o, d, inv_d, tmax, t);
-        if (NEAREST) {
-            tmax = ok ? t : tmax;
-            best = ok ? __float_as_int(r.q1.y) : best;
-        } else {
-            occ_v |= ok ? 1u : 0u;
-        }
-        off += (unsigned)sizeof(DAar);
-    }
-#endif
 }
 
 // sphere_t::intersect, 1336-1393.  sqrt of a negative discriminant is NaN, which fails both range tests.
@@ -514,7 +449,7 @@ KY_DEV bool sph_hit(const float4 c, f3 o, f3 d, float tmax, float& t_out, bool s
     return hit;
 }
 
-// The second half of sph_hit with its update, for the scan loops (KY_CMPX): the candidate root is t0 if it lies beyond the epsilon and t1 otherwise (t0 <= t1:
+// The second half of sph_hit with its update, for the scan loops: the candidate root is t0 if it lies beyond the epsilon and t1 otherwise (t0 <= t1:
 // if t0 > eps is too far, so is t1; if t0 <= eps only t1 can count) -- one compare and one select; then the v_cmpx chain of the planar tests.
 // 6 VALU + 1 SALU for the nearest-hit update where four compares, three selects and the index move were 8 + 3; 5 + 1 for the any-hit flag where the lane masks'
 // bookkeeping was 4 + 7.  (A NaN root -- the line misses the sphere -- fails both range tests as before.  The two wait states between a VALU write of VCC and
@@ -643,28 +578,18 @@ KY_DEV int trace_nearest(SceneRef S, f3 o, f3 d, float& tmax) {
     }
     if (n_par > 0) {
         unsigned off = t_off + (unsigned)__builtin_offsetof(DTrav, par);
-#if KY_CMPX
         const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
-#endif
         for (int i = 0; i < n_par; ++i) {
             asm volatile("" : "+s"(off));
             const DPar& r = scene_at<DPar>(S, off);
-#if KY_CMPX
             float t, u, v;
             par_coords(r.q0, r.q1, r.q2, o, d, t, u, v);
             hit_update_nearest(ex, u, 0.5f, v, 0.5f, t, tmax, best, n_aar + i);
-#else
-            float t;
-            const bool ok = par_hit(r.q0, r.q1, r.q2, o, d, tmax, t);
-            tmax = ok ? t : tmax;
-            best = ok ? n_aar + i : best;
-#endif
             off += (unsigned)sizeof(DPar);
         }
     }
     if (n_sph > 0) {
         unsigned off = scene_off(S, &S->sph[0]);
-#if KY_CMPX
         const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
         for (int i = 0; i < n_sph; ++i) {
             asm volatile("" : "+s"(off));
@@ -675,16 +600,6 @@ KY_DEV int trace_nearest(SceneRef S, f3 o, f3 d, float& tmax) {
             if (!S.sphere_lights() || __any(discr >= 0.f)) sph_update_nearest(ex, neg_b, discr, tmax, best, n_aar + n_par + i);   // (sph_hit's `sparse` rule)
             off += (unsigned)sizeof(DSph);
         }
-#else
-        for (int i = 0; i < n_sph; ++i) {
-            asm volatile("" : "+s"(off));
-            float t;
-            const bool ok = sph_hit(scene_at<DSph>(S, off).c, o, d, tmax, t, S.sphere_lights());
-            tmax = ok ? t : tmax;
-            best = ok ? n_aar + n_par + i : best;
-            off += (unsigned)sizeof(DSph);
-        }
-#endif
     }
     for (int i = 0; S.general && i < n_gen; ++i) {
         float t;
@@ -714,20 +629,13 @@ KY_DEV bool trace_any_planar(SceneRef S, const DTrav& T, f3 o, f3 d, float tmax)
     }
     if (n_par > 0) {
         unsigned off = t_off + (unsigned)__builtin_offsetof(DTrav, par);
-#if KY_CMPX
         const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
-#endif
         for (int i = 0; i < n_par; ++i) {
             asm volatile("" : "+s"(off));
             const DPar& r = scene_at<DPar>(S, off);
-#if KY_CMPX
             float t, u, v;
             par_coords(r.q0, r.q1, r.q2, o, d, t, u, v);
             hit_update_any(ex, u, 0.5f, v, 0.5f, t, tmax, occ);
-#else
-            float t;
-            occ |= par_hit(r.q0, r.q1, r.q2, o, d, tmax, t) ? 1u : 0u;
-#endif
             off += (unsigned)sizeof(DPar);
         }
     }
@@ -739,7 +647,6 @@ KY_DEV bool trace_any(SceneRef S, const DTrav& T, f3 o, f3 d, float tmax) {
     float t;
     if (n_sph > 0) {
         unsigned off = scene_off(S, &S->sph[0]);
-#if KY_CMPX
         const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
         unsigned occ_v = 0;
         for (int i = 0; i < n_sph; ++i) {
@@ -748,25 +655,14 @@ KY_DEV bool trace_any(SceneRef S, const DTrav& T, f3 o, f3 d, float tmax) {
             const f3 oc = mk3(c.x, c.y, c.z) - o;
             const float neg_b = dot(oc, d);
             const float discr = neg_b * neg_b - dot(oc, oc) + c.w;
-#if KY_SPH_ANY_BOUND
             // sphere-light scenes: a shadow ray is AIMED at a lamp, so its line always meets that lamp -- 2e-3 beyond tmax (3187-3201) -- and with five lamps every sphere is
             // some lane's target.  The root is needed only if some lane's nearer crossing can lie before tmax: neg_b - sqrt(discr) < tmax <=> e < 0 or e^2 < discr, e = neg_b - tmax
             // (no square root; conservative: the far crossing and eps are left to the full test).
             const float e = neg_b - tmax;
             if (!S.sphere_lights() || __any((discr >= 0.f) & ((e < 0.f) | (e * e < discr)))) sph_update_any(ex, neg_b, discr, tmax, occ_v);
-#else
-            if (!S.sphere_lights() || __any(discr >= 0.f)) sph_update_any(ex, neg_b, discr, tmax, occ_v);
-#endif
             off += (unsigned)sizeof(DSph);
         }
         occ = occ | (occ_v != 0);
-#else
-        for (int i = 0; i < n_sph; ++i) {
-            asm volatile("" : "+s"(off));
-            occ = occ | sph_hit(scene_at<DSph>(S, off).c, o, d, tmax, t, S.sphere_lights());
-            off += (unsigned)sizeof(DSph);
-        }
-#endif
     }
     for (int i = 0; S.general && i < n_gen; ++i) occ = occ || full_shape_hit(S->full[S->gen[i].full], o, d, tmax, t);
     return occ;
@@ -863,18 +759,10 @@ KY_DEV void concentric_disk(float u0, float u1, float& px, float& py) {
     const float rx = 2.f * u0 - 1, ry = 2.f * u1 - 1;
     const bool xmajor = fabsf(rx) > fabsf(ry);
     const float radius = xmajor ? rx : ry;
-#if KY_MUL_LEGACY
     const float ratio = mul_legacy(xmajor ? ry : rx, rcp(radius));    // rx = ry = 0: 0 x (1 / 0) = 0, and the radius is 0
     const float rev = xmajor ? 0.125f * ratio : 0.25f - 0.125f * ratio;  // (pi/4) q, pi/2 - (pi/4) q
     px = cos_rev(rev) * radius;
     py = sin_rev(rev) * radius;
-#else
-    const float ratio = (xmajor ? ry : rx) * rcp(radius);             // 0/0 = NaN only when rx = ry = 0, handled below
-    const float rev = xmajor ? 0.125f * ratio : 0.25f - 0.125f * ratio;  // (pi/4) q, pi/2 - (pi/4) q
-    const bool origin = (rx == 0 && ry == 0);
-    px = origin ? 0.f : cos_rev(rev) * radius;
-    py = origin ? 0.f : sin_rev(rev) * radius;
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1031,7 +919,6 @@ KY_DEV f3 bsdf_sample_dir_nondelta(const Vertex& v, f3 wo, float u0, float u1, b
     const bool phong = v.bsdf.lobe == LOBE_PHONG;
     const float cos_o = dot(v.normal, wo);
     float ang, rad, z = any_f();
-    bool origin = false;
     if (phong) {
         z = pow_nonneg(u1, v.bsdf.m->eta);                                 // 1 / (exponent + 1)
         rad = fsqrt(1.f - z * z);
@@ -1040,18 +927,11 @@ KY_DEV f3 bsdf_sample_dir_nondelta(const Vertex& v, f3 wo, float u0, float u1, b
         const float rx = 2.f * u0 - 1, ry = 2.f * u1 - 1;
         const bool xmajor = fabsf(rx) > fabsf(ry);
         rad = xmajor ? rx : ry;
-#if KY_MUL_LEGACY
         const float ratio = mul_legacy(xmajor ? ry : rx, rcp(rad));        // rx = ry = 0: 0 x (1 / 0) = 0 (mul_legacy): the radius is 0 and the centre maps to the centre
         ang = xmajor ? 0.125f * ratio : 0.25f - 0.125f * ratio;            // (pi/4) q, pi/2 - (pi/4) q
-#else
-        const float ratio = (xmajor ? ry : rx) * rcp(rad);                 // 0/0 = NaN only when rx = ry = 0, handled below
-        ang = xmajor ? 0.125f * ratio : 0.25f - 0.125f * ratio;            // (pi/4) q, pi/2 - (pi/4) q
-        origin = (rx == 0 && ry == 0);
-#endif
     }
     float px = cos_rev(ang) * rad, py = sin_rev(ang) * rad;
     if (!phong) {   // cosine_hemisphere_sample 737-743, flipped into wo's hemisphere (2247-2249)
-        if (origin) { px = 0.f; py = 0.f; }
         z = __builtin_copysignf(fsqrt(fmaxf(0.f, 1 - px * px - py * py)), cos_o);   // `if (wo.z < 0) z = -z` as one v_bfi_b32 (no divergent region around a single negation)
     }
     const LobeBasis L = vertex_basis(v);
@@ -1148,26 +1028,16 @@ KY_DEV BsdfContinue bsdf_continue(const Vertex& v, f3 wo, float u0, float u1, bo
         const DeltaSample d = bsdf_sample_delta(v, wo, u0);
         c.wi = d.wi;
         c.weight = ld3(d.reflected ? v.bsdf.m->c0 : v.bsdf.m->c1);
-#if KY_BLACK_FLAGS
         c.ok = ((v.bsdf.m->exp_flags & (d.reflected ? 4 : 8)) != 0) & (d.percent != 0.f);   // !is_black(weight): a constant of the material, decided by the host (DMat::exp_flags)
-#else
-        c.ok = !is_black(c.weight) && d.percent != 0.f;
-#endif
     } else {
         bool back_dead = false;
         c.wi = bsdf_sample_dir_nondelta(v, wo, u0, u1, &back_dead, flat_phong);
         const float cos_o = dot(v.normal, wo), cos_i = dot(v.normal, c.wi);
         const bool phong = v.bsdf.lobe == LOBE_PHONG;
         const f3 col = ld3(phong ? v.bsdf.m->c1 : v.bsdf.m->c0);
-#if KY_BLACK_FLAGS
         c.weight = col * (phong ? fabsf(cos_i) : 1.f);   // (one select, three products: col x 1 is col)
         const bool dead_u1 = phong & !(u1 > 0.f) & (v.bsdf.m->exponent > 0.f);   // (bitwise: every operand is at hand, no short-circuit branches)
         c.ok = (cos_o * cos_i > 0) & ((v.bsdf.m->exp_flags & (phong ? 8 : 4)) != 0) & !dead_u1 & !back_dead;
-#else
-        c.weight = phong ? col * fabsf(cos_i) : col;
-        const bool dead_u1 = phong & !(u1 > 0.f) & (v.bsdf.m->exponent > 0.f);   // (bitwise: every operand is at hand, no short-circuit branches)
-        c.ok = (cos_o * cos_i > 0) & !is_black(col) & !dead_u1 & !back_dead;
-#endif
     }
     return c;
 }
@@ -1220,7 +1090,7 @@ KY_DEV void shape_sample_position(const DLight& L, float u0, float u1, f3& posit
 }
 
 // shape_t::sample_direction (1028-1051) and sphere_t::sample_direction (1419-1501)
-// `ipdf` (a compile-time constant at every call; the callers that pass true: KY_IPDF): `pdf` receives the RECIPROCAL of the density -- for the cone that is
+// `ipdf` (a compile-time constant at every call; the callers that pass true: SceneRef::ipdf): `pdf` receives the RECIPROCAL of the density -- for the cone that is
 // 2 pi (1 - cos theta_max) itself, and the estimators' weights 2 / (p_l + p_b) become 2 x / (1 + p_b x): one quarter-rate reciprocal per light sample instead of two.
 // A density of zero is an infinite reciprocal.
 KY_DEV void shape_sample_direction(const DLight& L, f3 p, f3 p_normal, float u0, float u1, f3& lposition, f3& lnormal, float& pdf, int feat = 0, bool ipdf = false) {
@@ -1232,11 +1102,7 @@ KY_DEV void shape_sample_direction(const DLight& L, f3 p, f3 p_normal, float u0,
         const float inv_dist = rsq(dc2);
         const float sin_theta_max = L.radius * inv_dist;
         const float sin_theta_max_sq = sin_theta_max * sin_theta_max;
-#if KY_SPH_INVR
         const float inv_sin_theta_max = (dc2 * inv_dist) * L.e0[0];   // distance x 1 / radius (the host's, DLight::e0[0] of a sphere light): two multiplies for a quarter-rate reciprocal
-#else
-        const float inv_sin_theta_max = rcp(sin_theta_max);
-#endif
         const float cos_theta_max = fsqrt(fmaxf(0.f, 1 - sin_theta_max_sq));
         float cos_theta = (cos_theta_max - 1) * u0 + 1;
         float sin_theta_sq = 1 - cos_theta * cos_theta;
@@ -1271,13 +1137,9 @@ KY_DEV void shape_sample_direction(const DLight& L, f3 p, f3 p_normal, float u0,
         return;
     }
     const float q = L.inv_area * d2 * rcp(fabsf(dot(nn, wi)));
-#if KY_PDF_CLASS
     // q is a product of non-negative factors: "d2 == 0 (q is NaN then: 0 x rcp(|NaN|)), infinite or NaN -> 0" is "keep it iff it is a positive finite number": one
     // v_cmp_class_f32 (+normal | +denormal) instead of three compares and two scalar ors
     pdf = __builtin_amdgcn_classf(q, 0x180) ? q : 0.f;
-#else
-    pdf = (d2 == 0 || __builtin_isinf(q) || q != q) ? 0.f : q;
-#endif
 }
 
 // shape_t::pdf_direction (1055-1090) and sphere_t::pdf_direction (1503-1513)
@@ -1326,7 +1188,7 @@ KY_DEV LightSample light_sample_Li(const DLight& L, f3 p, f3 p_normal, float u0,
         const f3 dv = lposition - p;
         const float d2 = length_sq(dv);
         // (a coincident sample of a planar shape has a NaN direction and therefore density 0 already: only the cone sampler's needs the second test)
-        const bool ok = !((ipdf ? __builtin_isinf(s.pdf) : s.pdf == 0) || ((KY_PDF_CLASS && (feat & KY_FEAT_RECT_LIGHTS)) ? false : d2 == 0));
+        const bool ok = !((ipdf ? __builtin_isinf(s.pdf) : s.pdf == 0) || ((feat & KY_FEAT_RECT_LIGHTS) ? false : d2 == 0));
         const float inv_d = rsq(d2);
         const f3 wi = dv * inv_d;
         s.dir = wi;
@@ -1476,7 +1338,7 @@ KY_DEV void estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f
         for (int k = 0; k < L.n_carriers; ++k) {
             float t;
             bool hit;
-            if (KY_CARRIER_IN_LIGHT && S.sphere_lights() && k == 0)   // the first carrier's sphere from the light's own record (DLight::aar): one load, not index -> table
+            if (S.sphere_lights() && k == 0)   // the first carrier's sphere from the light's own record (DLight::aar): one load, not index -> table
                 hit = sph_hit(make_float4(L.aar[0], L.aar[1], L.aar[2], L.aar[3]), o, bs.wi, t_l, t, true);
             else
                 hit = surf_hit(scene_surf(S, L.carrier[k]), S->full, o, bs.wi, t_l, t, S.general, S.sphere_lights());
@@ -1621,12 +1483,9 @@ KY_DEV void estimate_by_bsdf(SceneRef S, const LdsScene& Lds, const Vertex& v, f
 #ifndef KY_SQ_FLUSH_AT
 #define KY_SQ_FLUSH_AT 64   // rays at hand (waiting + new) that trigger a traversal: 64 fills every lane; less keeps the stack shallower and the lanes emptier (measurements)
 #endif
-#ifndef KY_SQ_FLUSH_ALL_NEW
-#define KY_SQ_FLUSH_ALL_NEW 1
-#endif
 constexpr int KY_SQ_ENTRY = 3;                                // float4 per ray: (origin, tmax) (direction, tag) (contribution, -)
 #ifndef KY_SQ_CAP_ENTRIES
-#define KY_SQ_CAP_ENTRIES (KY_SQ_FLUSH_ALL_NEW ? 64 : 128)
+#define KY_SQ_CAP_ENTRIES 64
 #endif
 constexpr int KY_SQ_CAP = KY_SQ_CAP_ENTRIES;                  // entries per wavefront's block: < 64 waiting (round 5: a flush stores nothing; rounds 3-4: + < 64 of a push that did not fit the wave being traced)
 struct ShadowQueue {
@@ -1681,7 +1540,6 @@ KY_DEV void sq_push(SceneRef S, ShadowQueue& q, bool push, SqRay r) {
         q.n += k;
         return;
     }
-#if KY_SQ_FLUSH_ALL_NEW
     // 64 or more rays at hand: EVERY new ray is traced from the registers it is in, and the 64 - k lanes without one pop the top of the stack (q.n >= 64 - k).
     // Round 5: rounds 3-4 kept only the first 64 - q.n new rays in registers and stored the others on top of the stack -- from where they were popped again a
     // moment later by the very lanes that had stored them: k - (64 - q.n) entries written and read for nothing per flush, and a stack that grew to 2 q.n + k - 65
@@ -1694,22 +1552,6 @@ KY_DEV void sq_push(SceneRef S, ShadowQueue& q, bool push, SqRay r) {
     if (pop) r = sq_load(KY_SQ_SLOT(q, q.n - 1 - idx));
     q.n -= min(q.n, 64 - k);
     if (KY_SQ_FLUSH_AT == 64 || push || pop) sq_trace(S, q, r);
-    return;
-#endif
-    // 64 or more: the first `take` new rays are traced from the registers they are in, the rest wait; the q.n lanes without a ray to
-    // trace pop the top of the stack (which may hold rays stored a moment ago: same wavefront, same address -> in order)
-    const int take = 64 - q.n;
-    const bool keep = push && rank < take;
-    if (push && !keep) sq_store(KY_SQ_SLOT(q, q.n + rank - take), r);
-    const int n1 = q.n + k - take;
-    asm volatile("" ::: "memory");   // the compiler must keep the order; the hardware keeps a wavefront's accesses to one address in order by itself
-    const unsigned long long others = __ballot(!keep);
-    if (!keep) {
-        const int j = n1 - 1 - (int)__builtin_amdgcn_mbcnt_hi((unsigned)(others >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)others, 0u));
-        r = sq_load(KY_SQ_SLOT(q, j));
-    }
-    q.n = k - take;
-    sq_trace(S, q, r);
 }
 KY_DEV void sq_push_bsdf_query(SceneRef S, ShadowQueue& q, bool push, f3 o, f3 d, float tmax, f3 c, unsigned tag) {
     sq_push(S, q, push, SqRay{o, d, c, tmax, tag});
@@ -1801,7 +1643,7 @@ KY_DEV void estimate_by_emitter(SceneRef S, const LdsScene& Lds, const Vertex& v
     const bool ip = S.ipdf();   // (compile-time) ls.pdf is the density's reciprocal: shape_sample_direction
     const LightSample ls = light_sample_Li(L, v.position, v.normal, u0, u1, S.feat, ip);
     const bool area = S.is_area(L.kind);   // (wave-uniform)
-    const bool dead = (area ? !ls.lit : is_black(ls.Li)) || (!(ip || (KY_PDF_CLASS && area)) && (MIS ? (ls.pdf <= 0) : (ls.pdf == 0)));   // (an area light's `lit` says that the density is not zero -- and it is never negative)
+    const bool dead = (area ? !ls.lit : is_black(ls.Li)) || (!(ip || area) && (MIS ? (ls.pdf <= 0) : (ls.pdf == 0)));   // (an area light's `lit` says that the density is not zero -- and it is never negative)
     KY_CLK(5);
     if (!dead) {
         // scene_t::occluded(isect, ls.position), 3187-3201 (an area light's direction and distance: LightSample::dir)

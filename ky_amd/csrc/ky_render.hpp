@@ -20,9 +20,6 @@ using namespace kyd;
 #ifndef KY_REFILL_WAIT
 #define KY_REFILL_WAIT 4      // ... or turns the first of them waits at most
 #endif
-#ifndef KY_FLUSH_FAST
-#define KY_FLUSH_FAST 1       // the chunk flush's plain form for wavefronts whose flushing lanes all hold finite non-negative sums (render_kernel_body)
-#endif
 #ifndef KY_RETRACE_THRESHOLD
 #define KY_RETRACE_THRESHOLD 80
 #endif
@@ -141,7 +138,6 @@ KY_DEV void render_kernel_body(const DScene* __restrict__ S_, RenderConst rc, Sh
                 ps.Lo = mk3(0, 0, 0);
                 const int pix = c_pix[tid];
                 c_pix[tid] = -1;   // rays of this chunk that are still on the stack go to the global accumulator directly
-#if KY_FLUSH_FAST
                 // Nearly every chunk sum is three finite, non-negative numbers far below the accumulator's range: when that holds for every flushing lane of the wavefront
                 // (one min3, two adds, two compares; a NaN fails the sum's test) the conversion needs no classification, no sign and no flag word -- 30 instead of 75
                 // VALU instructions for every lane of the wavefront, flushing or not.  Any other wavefront takes the complete form below.
@@ -156,7 +152,6 @@ KY_DEV void render_kernel_body(const DScene* __restrict__ S_, RenderConst rc, Sh
                         atomicAdd(&accum[(size_t)pix * 3 + ch], fx);
                     }
                 } else
-#endif
                 {
                     unsigned fl = 0;
 #pragma unroll

@@ -9,6 +9,9 @@
                                 a first-hit AOV pass, each 1024x1024 at 2048 spp -- six frames per step
             --workload stress   configs[4]: Cornell 4096x4096, 16384 spp, max depth 16 (2.7e11 samples per step: pass --steps 1
                                 --warmup 0, or scale with --spp)
+            --workload single   ky's own default driver, render_single_scene (ky.cpp:4675-4712): the Cornell box lit by the ENVIRONMENT light,
+                                1024x1024, path_tracing_iteration depth 5 both_mis -- at 2048 spp instead of the driver's 16 (the rate does not
+                                depend on spp from 256 up)
             One "step" renders the workload's frame(s) once.
   N > 1     every frame's tiles are interleaved over the N ranks (one process per GPU), each rank renders its tiles with no
             communication, then ONE gather of film tiles to rank 0 (RCCL over xGMI) and one add kernel there.  Total work is
@@ -177,7 +180,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cornell", choices=["cornell", "veach", "batch", "stress"])
+    ap.add_argument("--workload", default="cornell", choices=["cornell", "veach", "batch", "stress", "single"])
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
@@ -218,6 +221,12 @@ def workload(args):
         W, H, spp, depth = args.width or 4096, args.height or 4096, args.spp or 16384, args.depth or 16
         frames = [Frame("cornell_d16", api.cornell_box_scene(A.CB_DEFAULT_SCENE, W, H), api.make_params(W, H, spp, max_path_depth=depth, direct_sample=args.direct_sample, integrator=args.integrator), ITER["cornell_d16"])]
         name = "BASELINE configs[4]: stress, ky Cornell box %dx%d, %d spp, path_tracing_iteration d%d both_mis" % (W, H, spp, depth)
+        return frames, (H, W), name
+    if args.workload == "single":
+        W, H, spp, depth = args.width or 1024, args.height or 1024, args.spp or 2048, args.depth or 5
+        frames = [Frame("cornell_environment", api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | A.CB_LIGHT_ENVIRONMENT, W, H),
+                        api.make_params(W, H, spp, max_path_depth=depth, direct_sample=args.direct_sample, integrator=args.integrator), ITER["cornell_other_lights"])]
+        name = "ky render_single_scene (ky.cpp:4675-4712): Cornell box (both_small_spheres|light_environment) %dx%d, %d spp, path_tracing_iteration d%d both_mis" % (W, H, spp, depth)
         return frames, (H, W), name
     # batch: render_multiple_scene (ky.cpp:4819-4876) at production size, one film_grid_t(2, 3, res, res)
     res, spp, depth = args.width or 1024, args.spp or 2048, args.depth or 5
@@ -274,6 +283,53 @@ def rmse_of(pairs):
     return (se / max(cnt, 1)) ** 0.5, bad
 
 
+def sample_params(fr, spp, pixels=131072):
+    """fr's parameters cut down to an interleaved subset of its tiles (about `pixels` pixels spread over the whole picture) at `spp` samples per pixel."""
+    p = A.RenderParams.from_buffer_copy(fr.params)
+    p.tile_first = 0
+    p.tile_step = max(1, kydist.tiles_total(fr.params) * fr.params.tile_w * fr.params.tile_h // pixels)
+    p.samples_per_pixel = max(1, min(fr.params.samples_per_pixel, spp))
+    return p
+
+
+def parity_full_spp(frames, gpu_render, O, threads, budget_samples=None, min_pixels=0, scene_device=0):
+    """RMSE of the GPU's film against the CPU oracle's at the workload's FULL spp on an interleaved tile sample of every path frame -- the figure the north
+    star's 1e-3 is about.  The sample is `min_pixels` pixels over the frames, or what `budget_samples` camera samples buy if that is more.  Pixels that are
+    off by more than 5e-3 are replayed sample by sample on both sides (kyhip_kat_li / the oracle's li) and classified with the tests' own rules
+    (tests/helpers.py, explain_sample): "explained" = every differing sample differs first in a recorded decision or at / after a vertex that amplifies rounding."""
+    pairs, full_px, t_full, flips = [], 0, 0.0, {"pixels_off_by_5e-3": 0, "explained": 0, "unexplained": 0, "not_examined": 0}
+    path_frames = [fr for fr in frames if fr.params.samples_per_pixel > 1]
+    per_frame_px = max(1, int(np.ceil(min_pixels / max(len(path_frames), 1))))
+    for fr in path_frames:
+        px = max(fr.params.tile_w * fr.params.tile_h, per_frame_px, int((budget_samples or 0) / len(path_frames) / fr.params.samples_per_pixel))
+        p = sample_params(fr, fr.params.samples_per_pixel, pixels=px)
+        t0 = time.perf_counter()
+        cpu_film = O.render(fr.scene, p, threads=threads)
+        t_full += time.perf_counter() - t0
+        gpu_film = gpu_render(fr.scene, p)
+        pairs.append((gpu_film, cpu_film))
+        full_px += film_pixels_of(p)
+        fin = np.isfinite(cpu_film).all(axis=2) & np.isfinite(gpu_film).all(axis=2)
+        off = np.where(fin, np.abs(gpu_film.astype(np.float64) - cpu_film.astype(np.float64)).max(axis=2), 0.0)
+        ys, xs = np.nonzero(off > 5e-3)
+        flips["pixels_off_by_5e-3"] += int(len(ys))
+        order = np.argsort(-off[ys, xs])
+        for i in order[:4]:   # the four worst of a frame are replayed (a replay is spp samples on both sides)
+            try:
+                from tests import helpers as TH
+                kinds = TH.explain_pixel(api, O, fr.scene, p, int(xs[i]), int(ys[i]), value_tol=2e-3 if fr.label.startswith("veach") else 2e-4,
+                                         geom_tol=1e-3 if fr.label.startswith("veach") else 1e-4)
+                flips["explained" if sum(kinds.values()) > 0 else "unexplained"] += 1
+            except AssertionError:
+                flips["unexplained"] += 1
+            except Exception:
+                flips["not_examined"] += 1
+        flips["not_examined"] += max(0, int(len(ys)) - 4)
+    rmse_full, bad_full = rmse_of(pairs)
+    return {"value": rmse_full, "spp": max(fr.params.samples_per_pixel for fr in frames), "pixels": full_px, "excluded_nonfinite_pixels": bad_full,
+            "cpu_seconds": t_full, "target": 1e-3, **flips}
+
+
 def cpu_baseline(frames, gpu_render, target_seconds, workload_name):
     """Time the CPU oracle (a port of the reference's algorithm; one OpenMP thread per granted CPU, pinned: OMP_PROC_BIND / OMP_PLACES
     are set at the top of this file) on a BOUNDED sample of the same workload: of every frame an interleaved subset of its tiles
@@ -283,13 +339,6 @@ def cpu_baseline(frames, gpu_render, target_seconds, workload_name):
     from oracle import kyoracle as O
     granted = cpus_granted()
     threads = max(1, min(O.max_threads(), granted))
-
-    def sample_params(fr, spp, pixels=131072):
-        p = A.RenderParams.from_buffer_copy(fr.params)
-        p.tile_first = 0
-        p.tile_step = max(1, kydist.tiles_total(fr.params) * fr.params.tile_w * fr.params.tile_h // pixels)
-        p.samples_per_pixel = max(1, min(fr.params.samples_per_pixel, spp))
-        return p
 
     def run(spp_scale):
         films, n, t = [], 0, 0.0
@@ -316,17 +365,7 @@ def cpu_baseline(frames, gpu_render, target_seconds, workload_name):
     spps = sorted({p.samples_per_pixel for p, _ in films})
     # the same comparison at the workload's full spp: a few tiles per path frame, sized to about a third of the throughput sample's CPU time
     budget = max(2e5, 0.35 * target_seconds * rate * 1e6)
-    pairs, full_px, t_full = [], 0, 0.0
-    path_frames = [fr for fr in frames if fr.params.samples_per_pixel > 1]
-    for fr in path_frames:
-        px = max(fr.params.tile_w * fr.params.tile_h, int(budget / len(path_frames) / fr.params.samples_per_pixel))
-        p = sample_params(fr, fr.params.samples_per_pixel, pixels=px)
-        t0 = time.perf_counter()
-        cpu_film = O.render(fr.scene, p, threads=threads)
-        t_full += time.perf_counter() - t0
-        pairs.append((gpu_render(fr.scene, p), cpu_film))
-        full_px += film_pixels_of(p)
-    rmse_full, bad_full = rmse_of(pairs)
+    full = parity_full_spp(frames, gpu_render, O, threads, budget_samples=budget)
     ref = REFERENCE_CPU.get(workload_name)
     cb = {
         "value": rate, "unit": "Msamples/s", "cores": threads, "kind": "port", "omp_threads": threads, "cpus_granted": granted,
@@ -335,9 +374,7 @@ def cpu_baseline(frames, gpu_render, target_seconds, workload_name):
                   % (len(frames), films[0][0].tile_step, "/".join(map(str, spps)), n, dt, threads, granted),
         "reference_itself": ref,   # the reference's own rate where it could be built (other hardware): shows the port is not a sandbagged baseline
     }
-    extra = {"rmse_gpu_vs_cpu": rmse, "rmse_spp": spps[-1], "rmse_excluded_nonfinite_pixels": bad,
-             "rmse_full_spp": {"value": rmse_full, "spp": full_spp, "pixels": full_px, "excluded_nonfinite_pixels": bad_full, "cpu_seconds": t_full,
-                               "target": 1e-3}}
+    extra = {"rmse_gpu_vs_cpu": rmse, "rmse_spp": spps[-1], "rmse_excluded_nonfinite_pixels": bad, "rmse_full_spp": full}
     return cb, extra
 
 
@@ -553,6 +590,7 @@ def main():
         if exceeds:
             frac, model_achieved = lane_slot_frac, lane_slot_frac * peak_tlaneops
         line = {
+            "schema": 6,   # round of the line's layout: since 5 `value` is the pipelined rate (`single_frame.value` continues rounds 1-4's series) and `roofline.frac` the floor model's
             "metric": "Msamples/s (paths*spp)", "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -579,6 +617,9 @@ def main():
                          "lane_slot_frac": lane_slot_frac, "executed_lane_instr_per_sample": executed_per_sample,
                          "useful_lane_instr_per_sample": (model_ops / (samples_per_step / world)) if model_ops is not None else None,
                          "valu_model_exceeds_executed": exceeds,
+                         #  why the check above is None when it is: the counter set of profiles/valu.json describes other kernel sources or another workload
+                         "valu_counters_status": ("current" if exceeds is not None else
+                                                  ("none for this workload" if not valu else (valu.get("stale_reason") or ("stale: kernel time moved" if valu.get("stale") else "no executed figure")))),
                          "traffic": traffic, "traffic_source": (valu or {}).get("source") if traffic is not None else None,
                          "kernel": "render_kernel", "kernel_ms": kernel_total_ms, "kernel_ms_per_frame": frame_kernel_ms,
                          "samples_per_launch_set": samples_per_step // world,
@@ -592,7 +633,7 @@ def main():
         }
         default_line = world == 1 and args.workload == "cornell" and both_mis and not (args.width or args.height or args.spp or args.depth)
         if default_line and not args.no_extra:
-            line["extra_workloads"] = extra_workloads(args, run_workload, peak_tlaneops, lib, local_rank, kernel_total_ms)
+            line["extra_workloads"] = extra_workloads(args, run_workload, peak_tlaneops, lib, local_rank, kernel_total_ms, parity=not args.no_cpu_baseline)
             line["projected_scaling"] = projected_scaling(frames[0], dev, local_rank, lib, frame_kernel_ms[0], ms_per_step)
         if default_line and not args.no_extra:
             line["boundary"] = boundary_rates(frames[0], dev, local_rank)
@@ -604,17 +645,31 @@ def main():
             line.update(extra)
             if cb["omp_threads"] <= cb["cpus_granted"]:
                 line["speedup_vs_cpu_baseline"] = value / cb["value"]
+        # parity gate of the line: every RMSE at full spp the line carries must be under the north star's 1e-3, and no pixel may be
+        # off by more than 5e-3 without its samples explaining it; otherwise the line is printed and the process exits non-zero
+        gates = [("headline", line.get("rmse_full_spp"))] + [(k, v.get("rmse_full_spp")) for k, v in (line.get("extra_workloads") or {}).items() if isinstance(v, dict)]
+        failed = [k for k, g in gates if g and (not (g["value"] < g["target"]) or g.get("unexplained", 0) > 0)]
+        line["parity_gate"] = {"checked": [k for k, g in gates if g], "failed": failed}
         print(json.dumps(line), flush=True)
+        if failed:
+            sys.stderr.write("bench.py: parity gate failed for %s\n" % ", ".join(failed))
+            if world > 1:
+                tdist.destroy_process_group()
+            sys.exit(3)
     if world > 1:
         tdist.destroy_process_group()
 
 
-def extra_workloads(args, run_workload, peak_tlaneops, lib, local_rank, kernel_ms_specialised):
+def extra_workloads(args, run_workload, peak_tlaneops, lib, local_rank, kernel_ms_specialised, parity=True):
     """configs[2], [3] and [4], one timed step each (outside the headline's timed region; veach and batch after a warm-up step, the
     25-second stress frame without one), so that the driver's record of the default run carries them: value, ms per step, the live kernel
     duration of every frame, the contract fraction."""
     out = {}
-    for wl in ("veach", "batch", "stress"):
+    O = threads = None
+    if parity:
+        from oracle import kyoracle as O   # the checker of rmse_full_spp below; never inside a timed region
+        threads = max(1, min(O.max_threads(), cpus_granted()))
+    for wl in ("veach", "batch", "stress", "single"):
         wargs = argparse.Namespace(**vars(args))
         wargs.workload = wl
         wargs.width = wargs.height = wargs.spp = wargs.depth = 0
@@ -637,6 +692,14 @@ def extra_workloads(args, run_workload, peak_tlaneops, lib, local_rank, kernel_m
                    "frames": [fr.label for fr in r["frames"]], "kernel_ms_per_frame": r["kernel_ms"], "kernel_ms": sum(r["kernel_ms"]),
                    "roofline_frac": lane_slot if exceeds else model_frac, "lane_slot_frac": lane_slot, "valu_model_exceeds_executed": exceeds,
                    "contract_frac": achieved / HBM_PEAK_GBS, "film_mean": r["film_mean"]}
+        if parity:
+            # parity in the driver-run line: GPU against the CPU oracle at the config's FULL spp on an interleaved tile sample of at least
+            # 4096 pixels -- fewer (never under 1024) where the oracle would need more than about 40 s of this host's CPUs for them (the 16 384-spp frame on 2 CPUs)
+            spp_sum = sum(fr.params.samples_per_pixel for fr in r["frames"] if fr.params.samples_per_pixel > 1)
+            n_path = max(1, sum(1 for fr in r["frames"] if fr.params.samples_per_pixel > 1))
+            cpu_rate = (0.45e6 if wl == "veach" else 0.9e6) * threads          # the oracle's samples per second per thread, roughly (this box measures its own below)
+            px = int(min(4096, max(1024, 40.0 * cpu_rate / (spp_sum / n_path))))
+            out[wl]["rmse_full_spp"] = parity_full_spp(r["frames"], lambda scene, sp: api.render(scene, sp, device=local_rank), O, threads, min_pixels=px)
     # configs[1] without the scene-fact instantiations (kyhip_set_specialisation(0): what a scene outside the table of facts gets -- the
     # both_mis kernel that assumes nothing about lights or materials), next to its specialised twin of the headline
     prev = lib.kyhip_set_specialisation(0)

@@ -93,8 +93,8 @@ struct DeviceCtx {
     unsigned long long clock = 0;
     StreamState* last_launch = nullptr;    // kyhip_kernel_ms reads its event pair
     hipStream_t stream = nullptr;   // the library's own stream on this device (kyhip_render_multi)
-    int variant_blocks[48] = {};           // resident workgroups per CU of g_variants[i] (0: not asked yet) ...
-    size_t variant_lds[48] = {};           // ... for a scene block of this many bytes
+    int variant_blocks[64] = {};           // resident workgroups per CU of g_variants[i] (0: not asked yet) ...
+    size_t variant_lds[64] = {};           // ... for a scene block of this many bytes
     int last_variant = -1;
     int q_blocks_per_cu[3] = {0, 0, 0};
     struct JitKernel { hipModule_t module = nullptr; hipFunction_t fn = nullptr; int per_cu = 0; size_t lds = ~(size_t)0; bool failed = false; };
@@ -106,6 +106,9 @@ int get_ctx(int device, DeviceCtx** out);       // looks the context of `device`
 DeviceCtx* find_ctx(int device);
 int get_stream_state(DeviceCtx* c, hipStream_t stream, StreamState** out);
 int upload_scene(DeviceCtx* c, const ky_scene* scene, hipStream_t stream, SceneSlot** out);
-// whether kyhip_render_tiles_device runs these parameters on a table kernel with the box traversal (KY_FEAT_BOXES): the per-sample replay entries (ky_kat.hip) take the same traversal
+// The facts of the table kernel kyhip_render_tiles_device runs these parameters on that decide WHICH tests a ray goes through (KY_FEAT_BOXES: the box traversal;
+// KY_FEAT_SINGLE_ENV: the environment estimate's any-hit pair scan): the per-sample replay entries (ky_kat.hip) take the same ones, so that a replayed sample takes
+// every decision the rendered one took
+int render_replay_feat(const ky_scene* scene, const ky_render_params* p, const kyd::DScene* packed);
 bool render_uses_boxes(const ky_scene* scene, const ky_render_params* p, const kyd::DScene* packed);
 }  // namespace kyh

@@ -157,6 +157,7 @@ struct SceneRef {
         return (feat & KY_FEAT_SINGLE_ENV) ? true : ((feat & (KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_DELTA | KY_FEAT_SPHERE_LIGHTS)) ? false : kind == KY_LIGHT_ENVIRONMENT);
     }
     __device__ __forceinline__ bool may_have_env() const { return (feat & (KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_DELTA | KY_FEAT_SPHERE_LIGHTS)) == 0; }
+    __device__ __forceinline__ bool no_carried_light() const { return (feat & (KY_FEAT_SINGLE_DELTA | KY_FEAT_SINGLE_ENV)) != 0; }
     __device__ __forceinline__ bool sphere_lights() const { return (feat & KY_FEAT_SPHERE_LIGHTS) != 0; }
     __device__ __forceinline__ bool boxes() const { return (feat & KY_FEAT_BOXES) != 0; }
     __device__ __forceinline__ bool flat_phong() const { return (feat & KY_FEAT_FLAT_PHONG) != 0; }   // every plastic surface is a rectangle (bsdf_sample_dir_nondelta)
@@ -380,6 +381,19 @@ KY_DEV void hit_update_any(unsigned long long ex, float u, float ru, float v, fl
         : [occ] "+v"(occ), [tmp] "=&s"(tmp)
         : [u] "v"(u), [ru] "s"(ru), [v] "v"(v), [rv] "s"(rv), [t] "v"(t), [tmax] "v"(tmax), [eps] "s"(K_SHAPE_EPS), [ex] "s"(ex));
 }
+// ... for a ray without an end (tmax = inf: "does the ray leave the scene"): every finite distance lies before it, and a distance that is not finite has failed the chain
+// already (its in-plane coordinates are NaN or out of range), so the fourth compare is gone
+KY_DEV void hit_update_any_unbounded(unsigned long long ex, float u, float ru, float v, float rv, float t, unsigned& occ) {
+    unsigned long long tmp;
+    asm volatile(
+        "v_cmpx_le_f32_e64 %[tmp], |%[u]|, %[ru]\n\t"
+        "v_cmpx_le_f32_e64 %[tmp], |%[v]|, %[rv]\n\t"
+        "v_cmpx_lt_f32_e64 %[tmp], %[eps], %[t]\n\t"
+        "v_mov_b32_e32 %[occ], 1\n\t"
+        "s_mov_b64 exec, %[ex]"
+        : [occ] "+v"(occ), [tmp] "=&s"(tmp)
+        : [u] "v"(u), [ru] "s"(ru), [v] "v"(v), [rv] "s"(rv), [t] "v"(t), [eps] "s"(K_SHAPE_EPS), [ex] "s"(ex));
+}
 
 // Which form the rectangle loops take (a compile-time choice per instantiation, made by measurement: docs/rounds/round5.md): on the record's byte offset alone
 // (one scalar add per record less) in the sphere-light instantiations -- configs[2] +0.75 % -- and on a counter + offset elsewhere, where the shorter form measured
@@ -489,6 +503,17 @@ KY_DEV void sph_update_any(unsigned long long ex, float neg_b, float discr, floa
         : [t0] "v"(t0), [t1] "v"(t1), [tmax] "v"(tmax), [eps] "s"(K_SHAPE_EPS), [ex] "s"(ex)
         : "vcc");
 }
+// ... without an end: some crossing lies beyond the epsilon iff the farther one does (a NaN root -- the line misses the sphere -- fails the compare)
+KY_DEV void sph_update_any_unbounded(unsigned long long ex, float neg_b, float discr, unsigned& occ) {
+    const float t1 = neg_b + fsqrt(discr);
+    unsigned long long tmp;
+    asm volatile(
+        "v_cmpx_lt_f32_e64 %[tmp], %[eps], %[t1]\n\t"
+        "v_mov_b32_e32 %[occ], 1\n\t"
+        "s_mov_b64 exec, %[ex]"
+        : [occ] "+v"(occ), [tmp] "=&s"(tmp)
+        : [t1] "v"(t1), [eps] "s"(K_SHAPE_EPS), [ex] "s"(ex));
+}
 
 // A box's faces in one slab test (DBox, ky_scene.hpp; host: find_boxes).  A ray meets the boundary of a convex box at the two ends of the segment it has inside
 // it: where it enters -- the LARGEST of the three near-plane distances -- and where it leaves -- the smallest of the three far-plane distances --, and it meets
@@ -527,6 +552,53 @@ KY_DEV void box_update_nearest(unsigned long long ex, const float4 q0, const flo
     const float t_leave = vmin3(vmax(xl, xh), vmax(yl, yh), vmax(zl, zh));
     box_candidate(ex, t_enter, t_leave, t_enter, tmax, best);
     box_candidate(ex, t_enter, t_leave, t_leave, tmax, best);   // (after a hit at the entry point tmax <= t_leave: the chain's third compare keeps the entry)
+}
+
+// The same for an any-hit query (scene_t::occluded's scan, 3193-3195; an environment light's "does the ray leave the scene"): some face that is a surface is met inside
+// (eps, tmax) iff the entry point or the exit point is such a face's -- two chains that set a flag instead of noting distance and surface.
+KY_DEV void box_candidate_any(unsigned long long ex, float t_enter, float t_leave, float t, float tmax, unsigned& occ) {
+    unsigned long long tmp;
+    const unsigned surface = __float_as_uint(t) & 15u;
+    asm volatile(
+        "v_cmpx_le_f32_e64 %[tmp], %[te], %[tl]\n\t"
+        "v_cmpx_lt_f32_e64 %[tmp], %[eps], %[t]\n\t"
+        "v_cmpx_lt_f32_e64 %[tmp], %[t], %[tmax]\n\t"
+        "v_cmpx_ne_u32_e64 %[tmp], %[none], %[s]\n\t"
+        "v_mov_b32_e32 %[occ], 1\n\t"
+        "s_mov_b64 exec, %[ex]"
+        : [occ] "+v"(occ), [tmp] "=&s"(tmp)
+        : [te] "v"(t_enter), [tl] "v"(t_leave), [t] "v"(t), [tmax] "v"(tmax), [s] "v"(surface), [eps] "s"(K_SHAPE_EPS), [none] "n"(KY_BOX_NO_FACE), [ex] "s"(ex));
+}
+KY_DEV void box_update_any(unsigned long long ex, const float4 q0, const float4 q1, const float4 q2, f3 o, f3 inv_c, float tmax, unsigned& occ) {
+    const float xl = face_tag((q0.x - o.x) * inv_c.x, q0.w), xh = face_tag((q1.x - o.x) * inv_c.x, q1.w);
+    const float yl = face_tag((q0.y - o.y) * inv_c.y, q2.x), yh = face_tag((q1.y - o.y) * inv_c.y, q2.y);
+    const float zl = face_tag((q0.z - o.z) * inv_c.z, q2.z), zh = face_tag((q1.z - o.z) * inv_c.z, q2.w);
+    const float t_enter = vmax3(vmin(xl, xh), vmin(yl, yh), vmin(zl, zh));
+    const float t_leave = vmin3(vmax(xl, xh), vmax(yl, yh), vmax(zl, zh));
+    box_candidate_any(ex, t_enter, t_leave, t_enter, tmax, occ);
+    box_candidate_any(ex, t_enter, t_leave, t_leave, tmax, occ);
+}
+KY_DEV void box_candidate_any_unbounded(unsigned long long ex, float t_enter, float t_leave, float t, unsigned& occ) {
+    unsigned long long tmp;
+    const unsigned surface = __float_as_uint(t) & 15u;
+    asm volatile(
+        "v_cmpx_le_f32_e64 %[tmp], %[te], %[tl]\n\t"
+        "v_cmpx_lt_f32_e64 %[tmp], %[eps], %[t]\n\t"
+        "v_cmpx_ne_u32_e64 %[tmp], %[none], %[s]\n\t"
+        "v_mov_b32_e32 %[occ], 1\n\t"
+        "s_mov_b64 exec, %[ex]"
+        : [occ] "+v"(occ), [tmp] "=&s"(tmp)
+        : [te] "v"(t_enter), [tl] "v"(t_leave), [t] "v"(t), [s] "v"(surface), [eps] "s"(K_SHAPE_EPS), [none] "n"(KY_BOX_NO_FACE), [ex] "s"(ex));
+}
+// (the distances are at most 1e30 x a coordinate difference: finite, so "before the end" always holds)
+KY_DEV void box_update_any_unbounded(unsigned long long ex, const float4 q0, const float4 q1, const float4 q2, f3 o, f3 inv_c, unsigned& occ) {
+    const float xl = face_tag((q0.x - o.x) * inv_c.x, q0.w), xh = face_tag((q1.x - o.x) * inv_c.x, q1.w);
+    const float yl = face_tag((q0.y - o.y) * inv_c.y, q2.x), yh = face_tag((q1.y - o.y) * inv_c.y, q2.y);
+    const float zl = face_tag((q0.z - o.z) * inv_c.z, q2.z), zh = face_tag((q1.z - o.z) * inv_c.z, q2.w);
+    const float t_enter = vmax3(vmin(xl, xh), vmin(yl, yh), vmin(zl, zh));
+    const float t_leave = vmin3(vmax(xl, xh), vmax(yl, yh), vmax(zl, zh));
+    box_candidate_any_unbounded(ex, t_enter, t_leave, t_enter, occ);
+    box_candidate_any_unbounded(ex, t_enter, t_leave, t_leave, occ);
 }
 
 // one shape given as a generic record (KAT entry point, light shapes re-intersected by pdf_direction)
@@ -641,8 +713,8 @@ KY_DEV bool trace_any_planar(SceneRef S, const DTrav& T, f3 o, f3 d, float tmax)
     }
     return occ != 0;
 }
-KY_DEV bool trace_any(SceneRef S, const DTrav& T, f3 o, f3 d, float tmax) {
-    bool occ = trace_any_planar(S, T, o, d, tmax);
+// the part of an any-hit scan no table prunes: spheres and general shapes
+KY_DEV bool trace_any_round(SceneRef S, bool occ, f3 o, f3 d, float tmax) {
     const int n_sph = S->n_sph, n_gen = S->n_gen;
     float t;
     if (n_sph > 0) {
@@ -666,6 +738,109 @@ KY_DEV bool trace_any(SceneRef S, const DTrav& T, f3 o, f3 d, float tmax) {
     }
     for (int i = 0; S.general && i < n_gen; ++i) occ = occ || full_shape_hit(S->full[S->gen[i].full], o, d, tmax, t);
     return occ;
+}
+KY_DEV bool trace_any(SceneRef S, const DTrav& T, f3 o, f3 d, float tmax) {
+    return trace_any_round(S, trace_any_planar(S, T, o, d, tmax), o, d, tmax);
+}
+// Two any-hit queries of the same lanes over EVERY surface in one scan (an environment light's both_mis estimate: the BSDF-sampled ray and the light-sampled
+// ray both ask "does it leave the scene"): every record is loaded once and the loops' scalar bookkeeping runs once for the two rays -- in loops that run at one
+// scalar instruction per two vector ones that is a quarter of their issue slots.  The tests are trace_any_all's, instruction for instruction (the reciprocal
+// direction clamped to +-1e30 for the rectangles too: it differs from the unclamped one only for |d| < 1e-30, where both give "no hit").
+struct AnyRay {
+    f3 o, d;
+    float tmax;
+};
+template <int AXIS>
+KY_DEV void aar_scan_any_pair(SceneRef S, unsigned long long ex, unsigned aar_off, int first, int n, const AnyRay& A, f3 iA, unsigned& occA, const AnyRay& B, f3 iB, unsigned& occB) {
+    if (n <= 0) return;
+    unsigned off = aar_off + (unsigned)first * (unsigned)sizeof(DAar);
+    const float oaA = AXIS == 0 ? A.o.x : (AXIS == 1 ? A.o.y : A.o.z), iaA = AXIS == 0 ? iA.x : (AXIS == 1 ? iA.y : iA.z);
+    const float ouA = AXIS == 0 ? A.o.y : (AXIS == 1 ? A.o.z : A.o.x), duA = AXIS == 0 ? A.d.y : (AXIS == 1 ? A.d.z : A.d.x);
+    const float ovA = AXIS == 0 ? A.o.z : (AXIS == 1 ? A.o.x : A.o.y), dvA = AXIS == 0 ? A.d.z : (AXIS == 1 ? A.d.x : A.d.y);
+    const float oaB = AXIS == 0 ? B.o.x : (AXIS == 1 ? B.o.y : B.o.z), iaB = AXIS == 0 ? iB.x : (AXIS == 1 ? iB.y : iB.z);
+    const float ouB = AXIS == 0 ? B.o.y : (AXIS == 1 ? B.o.z : B.o.x), duB = AXIS == 0 ? B.d.y : (AXIS == 1 ? B.d.z : B.d.x);
+    const float ovB = AXIS == 0 ? B.o.z : (AXIS == 1 ? B.o.x : B.o.y), dvB = AXIS == 0 ? B.d.z : (AXIS == 1 ? B.d.x : B.d.y);
+    for (int i = 0; i < n; ++i) {
+        asm volatile("" : "+s"(off));
+        const DAar& r = scene_at<DAar>(S, off);
+        const float4 q0 = r.q0;
+        const float rv = r.q1.x;
+        const float tA = (q0.x - oaA) * iaA, tB = (q0.x - oaB) * iaB;
+        const float uA = (ouA + tA * duA) - q0.y, uB = (ouB + tB * duB) - q0.y;
+        const float vA = (ovA + tA * dvA) - q0.w, vB = (ovB + tB * dvB) - q0.w;
+        hit_update_any_unbounded(ex, uA, q0.z, vA, rv, tA, occA);
+        hit_update_any(ex, uB, q0.z, vB, rv, tB, B.tmax, occB);
+        off += (unsigned)sizeof(DAar);
+    }
+}
+// A: a ray without an end (its tmax is not read: the chains without the fourth compare); B: a ray that ends at B.tmax
+KY_DEV void trace_any_pair(SceneRef S, const AnyRay& A, const AnyRay& B, bool& occ_a, bool& occ_b) {
+    unsigned occA = 0, occB = 0;
+    const f3 iA = mk3(__builtin_amdgcn_fmed3f(rcp(A.d.x), -1e30f, 1e30f), __builtin_amdgcn_fmed3f(rcp(A.d.y), -1e30f, 1e30f), __builtin_amdgcn_fmed3f(rcp(A.d.z), -1e30f, 1e30f));
+    const f3 iB = mk3(__builtin_amdgcn_fmed3f(rcp(B.d.x), -1e30f, 1e30f), __builtin_amdgcn_fmed3f(rcp(B.d.y), -1e30f, 1e30f), __builtin_amdgcn_fmed3f(rcp(B.d.z), -1e30f, 1e30f));
+    const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
+    const unsigned t_off = opaque_off((unsigned)__builtin_offsetof(DScene, trav));
+    if (S.boxes()) {
+        const unsigned b_off = opaque_off((unsigned)__builtin_offsetof(DScene, boxtrav));
+        const int4 bhead = scene_at<int4>(S, b_off), baxis = scene_at<int4>(S, b_off + 16u);   // n_box, n_aar; n_aar_axis[3]
+        unsigned off = b_off + (unsigned)__builtin_offsetof(DBoxTrav, box);
+        for (int k = 0; k < bhead.x; ++k) {
+            asm volatile("" : "+s"(off));
+            const DBox& Bx = scene_at<DBox>(S, off);
+            const float4 q0 = Bx.q0, q1 = Bx.q1, q2 = Bx.q2;
+            box_update_any_unbounded(ex, q0, q1, q2, A.o, iA, occA);
+            box_update_any(ex, q0, q1, q2, B.o, iB, B.tmax, occB);
+            off += (unsigned)sizeof(DBox);
+        }
+        if (bhead.y > 0) {
+            const unsigned aar_off = b_off + (unsigned)__builtin_offsetof(DBoxTrav, aar);
+            aar_scan_any_pair<0>(S, ex, aar_off, 0, baxis.x, A, iA, occA, B, iB, occB);
+            aar_scan_any_pair<1>(S, ex, aar_off, baxis.x, baxis.y, A, iA, occA, B, iB, occB);
+            aar_scan_any_pair<2>(S, ex, aar_off, baxis.x + baxis.y, baxis.z, A, iA, occA, B, iB, occB);
+        }
+    } else {
+        const int4 head = scene_at<int4>(S, t_off), axis = scene_at<int4>(S, t_off + 16u);   // n_aar, n_par; n_aar_axis[3]
+        if (head.x > 0) {
+            const unsigned aar_off = t_off + (unsigned)__builtin_offsetof(DTrav, aar);
+            aar_scan_any_pair<0>(S, ex, aar_off, 0, axis.x, A, iA, occA, B, iB, occB);
+            aar_scan_any_pair<1>(S, ex, aar_off, axis.x, axis.y, A, iA, occA, B, iB, occB);
+            aar_scan_any_pair<2>(S, ex, aar_off, axis.x + axis.y, axis.z, A, iA, occA, B, iB, occB);
+        }
+    }
+    const int n_par = S.no_par() ? 0 : S->trav.n_par;
+    if (n_par > 0) {
+        unsigned off = t_off + (unsigned)__builtin_offsetof(DTrav, par);
+        for (int i = 0; i < n_par; ++i) {
+            asm volatile("" : "+s"(off));
+            const DPar& r = scene_at<DPar>(S, off);
+            float t, u, v;
+            par_coords(r.q0, r.q1, r.q2, A.o, A.d, t, u, v);
+            hit_update_any_unbounded(ex, u, 0.5f, v, 0.5f, t, occA);
+            par_coords(r.q0, r.q1, r.q2, B.o, B.d, t, u, v);
+            hit_update_any(ex, u, 0.5f, v, 0.5f, t, B.tmax, occB);
+            off += (unsigned)sizeof(DPar);
+        }
+    }
+    const int n_sph = S->n_sph, n_gen = S->n_gen;
+    if (n_sph > 0) {
+        unsigned off = scene_off(S, &S->sph[0]);
+        for (int i = 0; i < n_sph; ++i) {
+            asm volatile("" : "+s"(off));
+            const float4 c = scene_at<DSph>(S, off).c;
+            const f3 ocA = mk3(c.x, c.y, c.z) - A.o, ocB = mk3(c.x, c.y, c.z) - B.o;
+            const float nbA = dot(ocA, A.d), nbB = dot(ocB, B.d);
+            sph_update_any_unbounded(ex, nbA, nbA * nbA - dot(ocA, ocA) + c.w, occA);
+            sph_update_any(ex, nbB, nbB * nbB - dot(ocB, ocB) + c.w, B.tmax, occB);
+            off += (unsigned)sizeof(DSph);
+        }
+    }
+    occ_a = occA != 0;
+    occ_b = occB != 0;
+    float t;
+    for (int i = 0; S.general && i < n_gen; ++i) {
+        occ_a = occ_a || full_shape_hit(S->full[S->gen[i].full], A.o, A.d, A.tmax, t);
+        occ_b = occ_b || full_shape_hit(S->full[S->gen[i].full], B.o, B.d, B.tmax, t);
+    }
 }
 
 // normal the shape reports for a hit (1125, 1208, 1289, 1389)
@@ -1734,6 +1909,48 @@ KY_DEV void estimate_by_emitter_ride(SceneRef S, const LdsScene& Lds, const Vert
     }
 }
 
+// estimate_direct_lighting_both_mis (4076-4088) for a scene whose ONLY light is its environment (KY_FEAT_SINGLE_ENV): the two halves above in one pass.  Both halves' rays ask
+// the same question of the same surfaces -- the BSDF-sampled ray counts iff it leaves the scene (no surface carries a light: 3994 never holds, 4000 decides), the
+// light-sampled ray is unoccluded iff it does (its sample lies a scene diameter away, 3039) -- so both go through ONE any-hit scan (trace_any_pair).
+// Called by the lanes that hold a non-delta vertex; `acc_b` / `acc_l` receive w x the halves (the same sum unless a trace keeps them apart).
+KY_DEV void estimate_env_both(SceneRef S, const Vertex& v, f3 wo, float ub0, float ub1, float ul0, float ul1, f3& acc_b, f3& acc_l, f3 w) {
+    const DLight& L = scene_light(S, 0);
+    const bool dark = is_black_bits(L.color);   // (wave-uniform)
+    // BSDF-sampling half up to its ray (3979-3990): only the direction now -- the sample's value and pdf (a pow for the Phong lobe) are evaluated for the rays that
+    // leave the scene (a sample whose value is black traces its ray for nothing, and adds nothing)
+    AnyRay A;
+    A.d = bsdf_sample_dir_nondelta(v, wo, ub0, ub1, nullptr, S.flat_phong());
+    A.o = offset_ray_origin(v.position, v.normal, A.d);
+    A.tmax = K_INF;
+    const bool live_b = !dark;
+    // light-sampling half up to its ray (4041-4050): a uniform direction with quirk 4's density (3026-3041); the ray towards p + wi 2R
+    // (uniform_sphere_sample's radius IS the sine of the density: sqrt(1 - z^2) of the same z, which lies in [-1, 1] without the clamp)
+    const float z = 1 - 2 * ul0;
+    const float sin_theta = fsqrt(fmaxf(0.f, 1.f - z * z));
+    const f3 wl = mk3(sin_theta * cos_rev(ul1), sin_theta * sin_rev(ul1), z);
+    const float pl = sin_theta == 0 ? 0.f : rcp(2 * K_PI * K_PI * sin_theta);
+    const bool live_l = !dark && !(pl <= 0);
+    AnyRay B{offset_ray_origin(v.position, v.normal, wl), wl, 2 * L.world_radius - 2e-3f};
+    bool occ_b = true, occ_l = true;
+    if (live_b | live_l) trace_any_pair(S, A, B, occ_b, occ_l);
+    const f3 Li = ld3(L.color);
+    if (live_b && !occ_b) {
+        f3 f;
+        float pdf, abs_cos_i;
+        bsdf_eval_pdf(v, wo, A.d, f, pdf, abs_cos_i);   // the sample's own value and pdf (2253-2254, 2526-2527)
+        const f3 f_cos = f * abs_cos_i;
+        const float light_pdf = env_pdf(A.d.z);
+        if (!(is_black(f_cos) || pdf <= 0) && light_pdf > 0) acc_b = acc_b + w * ((f_cos * Li) * (2.f * rcp(pdf + light_pdf)));   // 3987, 4014, 4028
+    }
+    if (live_l && !occ_l) {
+        f3 col;
+        float scale, bsdf_pdf, abs_cos_i;
+        bsdf_eval_parts(v, wo, wl, col, scale, bsdf_pdf, abs_cos_i);
+        const float fc = scale * abs_cos_i;
+        if (!(fc <= 0.f) && !is_black(col)) acc_l = acc_l + ((col * Li) * w) * (fc * (2.f * rcp(pl + bsdf_pdf)));   // 4052, 4070
+    }
+}
+
 // sample_all_light, 3834-3872.  Wave-uniform call; `active` lanes draw 4 numbers per light (+2 for the plain bsdf
 // strategy, 3900) and ADD beta x (the estimators' sum) to Lo -- each estimator adds its own term in place (estimate_by_bsdf), so the 0.5 of
 // both_mis (4083) is part of the weight the terms are multiplied by, not a pass over their sum.
@@ -1754,7 +1971,12 @@ KY_DEV void sample_all_light(SceneRef S, const LdsScene& Lds, const Vertex& v, f
         f3& ab = decisions ? Lb : Lo;
         f3& al = decisions ? Ll : Lo;
         const f3 wt = decisions ? mk3(1, 1, 1) : w;
-        if (strategy == KY_DIRECT_BOTH_MIS) {  // 4076-4088
+        if (strategy == KY_DIRECT_BOTH_MIS && (S.feat & KY_FEAT_SINGLE_ENV) && !sq && !ra) {   // (compile-time) one environment light: both halves in one pass
+            if (active) {
+                ul0 = sampler_next<DEBUG_SAMPLER>(smp); ul1 = sampler_next<DEBUG_SAMPLER>(smp);
+                estimate_env_both(S, v, wo, ub0, ub1, ul0, ul1, ab, al, wt);
+            }
+        } else if (strategy == KY_DIRECT_BOTH_MIS) {  // 4076-4088
             KY_CLK(3);
             estimate_by_bsdf<true>(S, Lds, v, wo, li, ub0, ub1, active, ab, wt, sq, beta, weight * 0.5f, tag, ra);   // draws nothing itself
             KY_CLK(4);
@@ -1854,9 +2076,11 @@ KY_DEV bool path_intersect(PathState& ps, Vertex& v, SceneRef S, const LdsScene&
         see = rc.integrator == KY_INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION;   // every way out of 4201-4237 returns it; the debug integrators: never
     if (see) {
         if (hit) {
+            if (!S.no_carried_light()) {   // (a scene lit by one delta or environment light: no surface carries a light)
             const int al = Lds.hit[hs].area_light;
             if (al >= 0 && dot(v.normal, ps.d) < 0)            // areal_radiance: the side the (ray-facing) normal looks at, wo = -d
                 ps.Lo = ps.Lo + ps.beta * mk3(Lds.light_color[al][0], Lds.light_color[al][1], Lds.light_color[al][2]);
+            }
         } else if (S.may_have_env() && S->env_light >= 0) {
             ps.Lo = ps.Lo + ps.beta * ld3(S->light[S->env_light].color);
         }

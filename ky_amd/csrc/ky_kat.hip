@@ -102,9 +102,10 @@ __global__ void kat_occluded_kernel(const DScene* __restrict__ S, const float* _
 
 // BOXES: the launch these samples replay runs a kernel with the box traversal (render_uses_boxes): the replay takes the same one, so that "per sample what render() did" holds
 // to the last decision (a ray along a box's edge may take the other face in the other traversal)
+// single_env (a run-time flag: these kernels are not timed): ... whose both_mis estimate is estimate_env_both (KY_FEAT_SINGLE_ENV): the replay takes that too
 template <bool DEBUG_SAMPLER, bool BOXES>
-__global__ void kat_li_kernel(const DScene* __restrict__ S_, RenderConst rc, int x, int y, int s0, int n, float* __restrict__ out3) {
-    const SceneRef S{S_, true, BOXES ? KY_FEAT_BOXES : 0, true};
+__global__ void kat_li_kernel(const DScene* __restrict__ S_, RenderConst rc, int x, int y, int s0, int n, float* __restrict__ out3, int single_env) {
+    const SceneRef S{S_, true, (BOXES ? KY_FEAT_BOXES : 0) | (single_env ? KY_FEAT_SINGLE_ENV : 0), true};
     const LdsScene Lds = stage_scene<true>(S);   // KAT kernels: always the scene-sized dynamic block
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     PathState ps;
@@ -153,8 +154,8 @@ __global__ void kat_nee_kernel(const DScene* __restrict__ S, int strategy, int l
 
 // one camera sample, traced vertex by vertex (lane 0 walks the path; the other lanes only keep the wave-uniform calls company)
 template <bool DEBUG_SAMPLER, bool BOXES>
-__global__ void kat_li_trace_kernel(const DScene* __restrict__ S_, RenderConst rc, int x, int y, int s, int max_rows, float* __restrict__ out) {
-    const SceneRef S{S_, true, BOXES ? KY_FEAT_BOXES : 0, true};
+__global__ void kat_li_trace_kernel(const DScene* __restrict__ S_, RenderConst rc, int x, int y, int s, int max_rows, float* __restrict__ out, int single_env) {
+    const SceneRef S{S_, true, (BOXES ? KY_FEAT_BOXES : 0) | (single_env ? KY_FEAT_SINGLE_ENV : 0), true};
     const LdsScene Lds = stage_scene<true>(S);   // KAT kernels: always the scene-sized dynamic block
     PathState ps;
     bool alive = threadIdx.x == 0;
@@ -283,11 +284,13 @@ int kyhip_kat_li(int device, const ky_scene* scene, const ky_render_params* p, i
         if (r != KY_OK) return r;
         const size_t lds = lds_scene_bytes(scene->surface_count, scene->material_count, scene->light_count);
         const dim3 grid((n + 255) / 256), block(256);
-        const bool boxes = render_uses_boxes(scene, p, sc->h);
-        if (dbg && boxes) hipLaunchKernelGGL((kat_li_kernel<true, true>), grid, block, lds, 0, (const DScene*)sc->d, rc, x, y, s0, n, d_out);
-        else if (dbg) hipLaunchKernelGGL((kat_li_kernel<true, false>), grid, block, lds, 0, (const DScene*)sc->d, rc, x, y, s0, n, d_out);
-        else if (boxes) hipLaunchKernelGGL((kat_li_kernel<false, true>), grid, block, lds, 0, (const DScene*)sc->d, rc, x, y, s0, n, d_out);
-        else hipLaunchKernelGGL((kat_li_kernel<false, false>), grid, block, lds, 0, (const DScene*)sc->d, rc, x, y, s0, n, d_out);
+        const int rf = render_replay_feat(scene, p, sc->h);
+        const bool boxes = (rf & KY_FEAT_BOXES) != 0;
+        const int env = (rf & KY_FEAT_SINGLE_ENV) ? 1 : 0;
+        if (dbg && boxes) hipLaunchKernelGGL((kat_li_kernel<true, true>), grid, block, lds, 0, (const DScene*)sc->d, rc, x, y, s0, n, d_out, env);
+        else if (dbg) hipLaunchKernelGGL((kat_li_kernel<true, false>), grid, block, lds, 0, (const DScene*)sc->d, rc, x, y, s0, n, d_out, env);
+        else if (boxes) hipLaunchKernelGGL((kat_li_kernel<false, true>), grid, block, lds, 0, (const DScene*)sc->d, rc, x, y, s0, n, d_out, env);
+        else hipLaunchKernelGGL((kat_li_kernel<false, false>), grid, block, lds, 0, (const DScene*)sc->d, rc, x, y, s0, n, d_out, env);
         return (int)KY_OK;
     });
 }
@@ -321,11 +324,13 @@ int kyhip_kat_li_trace(int device, const ky_scene* scene, const ky_render_params
         SceneSlot* sc; int r = upload_scene(c, scene, 0, &sc);
         if (r != KY_OK) return r;
         const size_t lds = lds_scene_bytes(scene->surface_count, scene->material_count, scene->light_count);
-        const bool boxes = render_uses_boxes(scene, p, sc->h);
-        if (dbg && boxes) hipLaunchKernelGGL((kat_li_trace_kernel<true, true>), dim3(1), dim3(64), lds, 0, (const DScene*)sc->d, rc, x, y, s, max_rows, d_out);
-        else if (dbg) hipLaunchKernelGGL((kat_li_trace_kernel<true, false>), dim3(1), dim3(64), lds, 0, (const DScene*)sc->d, rc, x, y, s, max_rows, d_out);
-        else if (boxes) hipLaunchKernelGGL((kat_li_trace_kernel<false, true>), dim3(1), dim3(64), lds, 0, (const DScene*)sc->d, rc, x, y, s, max_rows, d_out);
-        else hipLaunchKernelGGL((kat_li_trace_kernel<false, false>), dim3(1), dim3(64), lds, 0, (const DScene*)sc->d, rc, x, y, s, max_rows, d_out);
+        const int rf = render_replay_feat(scene, p, sc->h);
+        const bool boxes = (rf & KY_FEAT_BOXES) != 0;
+        const int env = (rf & KY_FEAT_SINGLE_ENV) ? 1 : 0;
+        if (dbg && boxes) hipLaunchKernelGGL((kat_li_trace_kernel<true, true>), dim3(1), dim3(64), lds, 0, (const DScene*)sc->d, rc, x, y, s, max_rows, d_out, env);
+        else if (dbg) hipLaunchKernelGGL((kat_li_trace_kernel<true, false>), dim3(1), dim3(64), lds, 0, (const DScene*)sc->d, rc, x, y, s, max_rows, d_out, env);
+        else if (boxes) hipLaunchKernelGGL((kat_li_trace_kernel<false, true>), dim3(1), dim3(64), lds, 0, (const DScene*)sc->d, rc, x, y, s, max_rows, d_out, env);
+        else hipLaunchKernelGGL((kat_li_trace_kernel<false, false>), dim3(1), dim3(64), lds, 0, (const DScene*)sc->d, rc, x, y, s, max_rows, d_out, env);
         return (int)KY_OK;
     });
     if (rcode != KY_OK) return rcode;

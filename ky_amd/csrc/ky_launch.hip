@@ -272,6 +272,9 @@ static const Variant g_variants[] = {
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES | KY_FEAT_BOXES, IT),
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES, IT),
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, KY_FEAT_VEACH | KY_FEAT_FLAT_PHONG, IT),
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_ENV | KY_FEAT_SMALL_TABLES | KY_FEAT_BOXES | KY_FEAT_AXIS_ALIGNED | KY_FEAT_FLAT_PHONG, IT),
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_ENV | KY_FEAT_SMALL_TABLES | KY_FEAT_AXIS_ALIGNED | KY_FEAT_FLAT_PHONG, IT),
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_ENV, IT),
     KY_VARIANT(false, -1, false, false, 0, IT),
 #else
     // the iterative integrator, both_mis: by scene facts
@@ -282,9 +285,11 @@ static const Variant g_variants[] = {
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES, IT),   // one rectangle area light, at most 16 surfaces and 8 materials
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL, IT),                  // one rectangle area light
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_DELTA | KY_FEAT_BOXES | KY_FEAT_AXIS_ALIGNED | KY_FEAT_FLAT_PHONG, IT),   // one point / directional light in a room that is a box (configs[3]'s frames)
-    // (measured and not taken: KY_FEAT_SINGLE_ENV | KY_FEAT_BOXES -- the environment-light frame of configs[3] 153.9 -> 164.1 ms: its BSDF-sampled rays are nearest-hit
-    // traversals too and the instantiation's allocation does not take the second copy of the box code well)
+    // (round 5 measured KY_FEAT_SINGLE_ENV | KY_FEAT_BOXES slower -- its BSDF-sampled rays were a second inlined nearest-hit traversal; since round 6 both of the
+    // estimate's rays are any-hit queries that share one scan, estimate_env_both, and the box rows below pay: ky's default frame 38.3 -> 32.6 ms at 512 spp)
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_DELTA, IT),             // one point / directional light
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_ENV | KY_FEAT_SMALL_TABLES | KY_FEAT_BOXES | KY_FEAT_AXIS_ALIGNED | KY_FEAT_FLAT_PHONG, IT),
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_ENV | KY_FEAT_SMALL_TABLES | KY_FEAT_AXIS_ALIGNED | KY_FEAT_FLAT_PHONG, IT),
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_ENV, IT),               // one environment light
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, KY_FEAT_VEACH | KY_FEAT_FLAT_PHONG, IT),   // several sphere lights, no mirror / glass, plastic on rectangles only: configs[2]
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, KY_FEAT_VEACH, IT),                     // several sphere lights, no mirror / glass
@@ -334,7 +339,7 @@ static const Variant g_variants[] = {
 #endif
 };
 constexpr int KY_N_VARIANTS = (int)(sizeof g_variants / sizeof g_variants[0]);
-static_assert(KY_N_VARIANTS <= 48, "DeviceCtx::variant_blocks");
+static_assert(KY_N_VARIANTS <= 64, "DeviceCtx::variant_blocks");
 
 static const Variant* pick_variant(const ky_render_params* p, const DScene* packed, bool deferred_rays, int n_pix) {
     const bool dbg = p->sampler == KY_SAMPLER_DEBUG;
@@ -356,10 +361,11 @@ static const Variant* pick_variant(const ky_render_params* p, const DScene* pack
 }
 
 }  // extern "C"
-bool kyh::render_uses_boxes(const ky_scene* scene, const ky_render_params* p, const DScene* packed) {   // (ky_ctx.hpp)
+int kyh::render_replay_feat(const ky_scene* scene, const ky_render_params* p, const DScene* packed) {   // (ky_ctx.hpp)
     const Variant* v = pick_variant(p, packed, shadow_queue_wanted(scene), p->width * p->height);
-    return v != nullptr && (v->feat & KY_FEAT_BOXES) != 0;
+    return v != nullptr ? (v->feat & (KY_FEAT_BOXES | KY_FEAT_SINGLE_ENV)) : 0;
 }
+bool kyh::render_uses_boxes(const ky_scene* scene, const ky_render_params* p, const DScene* packed) { return (render_replay_feat(scene, p, packed) & KY_FEAT_BOXES) != 0; }
 extern "C" {
 
 int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render_params* p, float* d_tiles, void* d_workspace,
@@ -427,9 +433,11 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
         if (jit_mode != 0 && specialisation_enabled() && p->integrator >= KY_INTEGRATOR_DIRECT_LIGHTING) {   // (kyhip_set_specialisation(0) asks for the fact-free kernels: nothing to instantiate)
             const bool dbg = p->sampler == KY_SAMPLER_DEBUG, general = sc->h->general != 0;
             int feat = (dbg || general) ? 0 : sc->h->feat;
-            // the box traversal pays where it was measured to (one lamp, one point / directional light: +3-4 %); in instantiations that inline the nearest-hit
-            // traversal more than once (an environment light's BSDF-sampled rays, several lights) it measured 7-10 % SLOWER: those keep the rectangle scan
-            if (!(feat & (KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_DELTA))) feat &= ~KY_FEAT_BOXES;
+            // the box traversal pays where it was measured to (one lamp, one point / directional light: +3-4 %; one environment light under both_mis, whose estimate's two
+            // rays share one any-hit scan: estimate_env_both); in instantiations that inline the nearest-hit traversal more than once (an environment light's BSDF-sampled
+            // rays under the other strategies, several lights) it measured 7-10 % SLOWER: those keep the rectangle scan
+            const bool env_pair = (feat & KY_FEAT_SINGLE_ENV) && p->direct_sample == KY_DIRECT_BOTH_MIS && p->integrator != KY_INTEGRATOR_PATH_TRACING_RECURSION;
+            if (!((feat & (KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_DELTA)) || env_pair)) feat &= ~KY_FEAT_BOXES;
             const bool want_queue = (p->direct_sample == KY_DIRECT_BOTH_MIS || p->direct_sample == KY_DIRECT_LIGHT_MIS || p->direct_sample == KY_DIRECT_LIGHT) &&
                                     p->integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION && sh.n_pix < (1 << 26) && !general && shadow_queue_wanted(scene);
             const bool same = v->dbg == dbg && v->strategy == p->direct_sample && v->queue == want_queue && v->general == general && v->feat == feat &&

@@ -36,6 +36,9 @@ using namespace kyd;
 #ifndef KY_WAVES_PER_EU_HOT
 #define KY_WAVES_PER_EU_HOT 8          // the iterative integrator's both_mis with a single-light fact (every Cornell configuration): 64 VGPRs with 0-4 spilled, +1 % over
 #endif                                 // seven (+1.0 ... +2.9 % per Cornell light variant); the other strategies lose up to 15 % at eight
+#ifndef KY_WAVES_PER_EU_ENV
+#define KY_WAVES_PER_EU_ENV 7          // ... with one environment light (round 6): 72 VGPRs and 15 spilled SGPRs against 64 / 31 at eight, +1.8 % (its both_mis estimate scans every surface with two rays at once: trace_any_pair)
+#endif
 #ifndef KY_WAVES_PER_EU_NO_FACTS
 #define KY_WAVES_PER_EU_NO_FACTS 7     // both_mis without scene facts (any lights, inline shadow rays; every integrator).  Round 3: six (19-39 spilled VGPRs at seven); round 4, with
 #endif                                 // the path state the loop no longer carries: seven is +1 ... +2.4 % with two or more lights (the Cornell box with lamp and point light 17.41 -> 17.00 ms), -2 % with one
@@ -70,7 +73,7 @@ template <bool DEBUG_SAMPLER, int STRATEGY, bool QUEUE, bool GENERAL, int FEAT, 
 constexpr int ky_waves_per_eu() {
     return STRATEGY >= 0 ? (QUEUE ? (FEAT ? KY_WAVES_PER_EU_QUEUE_FEAT : KY_WAVES_PER_EU_QUEUE)
                                   : ((FEAT == 0 && STRATEGY == KY_DIRECT_BOTH_MIS) ? ((GENERAL || INTEGRATOR == KY_INTEGRATOR_PATH_TRACING_RECURSION) ? KY_WAVES_PER_EU_NO_FACTS_GENERAL : KY_WAVES_PER_EU_NO_FACTS)
-                                     : ((FEAT != 0 && STRATEGY == KY_DIRECT_BOTH_MIS && INTEGRATOR == KY_INTEGRATOR_PATH_TRACING_ITERATION) ? KY_WAVES_PER_EU_HOT : KY_WAVES_PER_EU)))
+                                     : ((FEAT != 0 && STRATEGY == KY_DIRECT_BOTH_MIS && INTEGRATOR == KY_INTEGRATOR_PATH_TRACING_ITERATION) ? ((FEAT & KY_FEAT_SINGLE_ENV) ? KY_WAVES_PER_EU_ENV : KY_WAVES_PER_EU_HOT) : KY_WAVES_PER_EU)))
                          : KY_WAVES_PER_EU_GENERIC;
 }
 
@@ -185,6 +188,9 @@ KY_DEV void render_kernel_body(const DScene* __restrict__ S_, RenderConst rc, Sh
                     it.y0 = trow * sh.tile_h + by * 8;
                     it.pix0 = (k * sh.tile_h + by * 8) * sh.tile_w + bx * 8;
                     chunk_range(chunk_plan(rc.spp), c, it.s_begin, it.s_end);
+#ifdef KY_EXP_TRANSPOSE   // experiment (1024 spp, 64 chunks of 16): item c of a block = its pixel c, the item's 64 units = that pixel's 64 chunks
+                    it.x0 += c & 7; it.y0 += c >> 3; it.pix0 += (c >> 3) * sh.tile_w + (c & 7);
+#endif
                     my_ring[fetched % KY_RING] = it;
                 }
                 ++fetched;
@@ -195,14 +201,23 @@ KY_DEV void render_kernel_body(const DScene* __restrict__ S_, RenderConst rc, Sh
                 const int mine = cursor + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(need_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need_mask, 0u));
                 if (mine < fetched * 64) {
                     const ItemSlot it = my_ring[(mine >> 6) % KY_RING];
+#ifdef KY_EXP_TRANSPOSE
+                    const int px = 0, py = 0;
+#else
                     const int px = mine & 7, py = (mine >> 3) & 7;
+#endif
                     const int x = it.x0 + px, y = it.y0 + py;
                     const bool in_range = x < rc.width && y < rc.height;
                     c_xy[tid] = x | (y << 16);
                     c_pix[tid] = it.pix0 + py * sh.tile_w + px;
                     if (!QUEUE) c_key[tid] = sampler_pixel_key(rc.seed, (uint32_t)(y * rc.width + x));
+#ifdef KY_EXP_TRANSPOSE
+                    c_se[tid] = ((unsigned)((mine & 63) * 16) << 7) | 16u;
+                    open = in_range;
+#else
                     c_se[tid] = ((unsigned)it.s_begin << 7) | (unsigned)(it.s_end - it.s_begin);
                     open = in_range && it.s_begin < it.s_end;
+#endif
                     has_item = in_range;
                 } else {
                     done = true;  // only reachable once the queue is exhausted

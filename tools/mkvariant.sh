@@ -12,5 +12,10 @@ wait
 python3 tools/resources.py /tmp/bv/$NAME.log > build_variants/$NAME.txt
 grep -E "error" /tmp/bv/$NAME.log /tmp/bv/$NAME.kat.log | head -5
 if grep -q "error:" /tmp/bv/$NAME.log /tmp/bv/$NAME.kat.log; then echo "BUILD FAILED: $NAME"; exit 1; fi
-hipcc --offload-arch=gfx950 -fPIC -no-hip-rt -shared -o build_variants/$NAME.so /tmp/bv/$NAME.launch.o /tmp/bv/$NAME.kat.o build/obj/ky_pack.o build/obj/ky_jit.o build/obj/ky_seam.o || exit 1
+HOSTOBJ="build/obj/ky_pack.o build/obj/ky_jit.o build/obj/ky_seam.o"
+if [ -n "$KY_HOSTFLAGS" ]; then   # flags that change what host and device share (ky_shard.hpp's chunk schedule): the host objects are rebuilt with them too
+  HOSTOBJ=""
+  for f in ky_pack ky_jit ky_seam; do hipcc $BASE "$@" -c -o /tmp/bv/$NAME.$f.o ky_amd/csrc/$f.cpp || exit 1; HOSTOBJ="$HOSTOBJ /tmp/bv/$NAME.$f.o"; done
+fi
+hipcc --offload-arch=gfx950 -fPIC -no-hip-rt -shared -o build_variants/$NAME.so /tmp/bv/$NAME.launch.o /tmp/bv/$NAME.kat.o $HOSTOBJ || exit 1
 echo "== $NAME: $*"; cat build_variants/$NAME.txt

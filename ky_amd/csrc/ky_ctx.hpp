@@ -46,6 +46,7 @@ struct StreamState {
     unsigned* d_counter = nullptr;
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    bool ws_clean = false;                 // `ws` and the work counter hold zeros: the last frame's resolve_kernel put them back (no fills before the next frame's launch)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing_valid = false;
     float4* d_shadow_queue = nullptr;      // QUEUE instantiations: the wavefronts' stacks, allocated on first use ...

@@ -42,18 +42,25 @@ static_assert(kyh::KY_SP_MAX_SPHERES == kysp::SP_MAX_SPHERES, "smallpt_check (ky
 // ------------------------------------------------------------------------------------------------
 #include "ky_queue.hpp"   // the queue engine: render_kernel_q
 
-// fixed-point accumulator -> clamp01(L) (3726) -> fp32 tile buffer
-__global__ void resolve_kernel(const unsigned long long* __restrict__ accum, const unsigned* __restrict__ flags, float* __restrict__ tiles, int n_floats) {
+// fixed-point accumulator -> clamp01(L) (3726) -> fp32 tile buffer, one thread per pixel.  The kernel leaves the accumulators, the flag words and the work counter
+// ZERO behind it: the next frame on this stream starts from them without the two fills (round 6: 2 x ~5 us of a launch's fixed cost, a twentieth of what a 1/8
+// shard of configs[1] spends outside its render kernel).
+__global__ void resolve_kernel(unsigned long long* __restrict__ accum, unsigned* __restrict__ flags, float* __restrict__ tiles, int n_pix, unsigned* __restrict__ counter) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_floats) return;
-    const int ch = i % 3;
-    const unsigned fl = flags[i / 3];
-    float v = (float)((double)(long long)accum[i] * (1.0 / KY_FIX_SCALE));
-    const bool nan = (fl >> ch) & 1u, pinf = (fl >> (3 + ch)) & 1u, ninf = (fl >> (6 + ch)) & 1u;
-    if (pinf) v = 1.f;
-    if (ninf) v = 0.f;
-    if (nan || (pinf && ninf)) v = 0.f;  // a NaN pixel: clamp01 keeps NaN in the reference and its 8-bit image shows 0
-    tiles[i] = fminf(fmaxf(v, 0.f), 1.f);
+    if (i == 0) *counter = 0u;
+    if (i >= n_pix) return;
+    const unsigned fl = flags[i];
+    flags[i] = 0u;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float v = (float)((double)(long long)accum[3 * (size_t)i + ch] * (1.0 / KY_FIX_SCALE));
+        accum[3 * (size_t)i + ch] = 0ull;
+        const bool nan = (fl >> ch) & 1u, pinf = (fl >> (3 + ch)) & 1u, ninf = (fl >> (6 + ch)) & 1u;
+        if (pinf) v = 1.f;
+        if (ninf) v = 0.f;
+        if (nan || (pinf && ninf)) v = 0.f;  // a NaN pixel: clamp01 keeps NaN in the reference and its 8-bit image shows 0
+        tiles[3 * (size_t)i + ch] = fminf(fmaxf(v, 0.f), 1.f);
+    }
 }
 
 __global__ void film_add_kernel(const float* __restrict__ tiles, float* __restrict__ film, size_t stride_px, ShardConst sh, int width, int height) {
@@ -398,6 +405,7 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
             st->ws = nullptr; st->ws_bytes = 0;
             HIP_TRY(hipMalloc(&st->ws, need));
             st->ws_bytes = need;
+            st->ws_clean = false;
         }
         ws = st->ws;
     }
@@ -405,8 +413,14 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
     unsigned* flags = (unsigned*)(accum + (size_t)sh.n_pix * 3);
     const bool large_scene = scene->surface_count > KY_LDS_SURFACES || scene->material_count > KY_LDS_MATERIALS;
     const size_t lds_bytes = large_scene ? (size_t)lds_scene_bytes(scene->surface_count, scene->material_count, scene->light_count) : 0;   // LARGE kernels' LdsScene
-    HIP_TRY(hipMemsetAsync(ws, 0, need, stream));
-    HIP_TRY(hipMemsetAsync(st->d_counter, 0, sizeof(unsigned), stream));
+    // accumulators, flags and the work counter start at zero: resolve_kernel leaves the library's own block that way (a caller's workspace, a new block and the frame
+    // after a failed launch are filled here)
+    const bool own_ws = ws == st->ws;
+    if (!(own_ws && st->ws_clean)) {
+        HIP_TRY(hipMemsetAsync(ws, 0, own_ws ? st->ws_bytes : need, stream));
+        HIP_TRY(hipMemsetAsync(st->d_counter, 0, sizeof(unsigned), stream));
+    }
+    st->ws_clean = false;   // until this frame's resolve_kernel is enqueued
 
     // the queue engine implements path_tracing_iteration_t; every other integrator runs on the lane engine
     if (current_engine() == KY_ENGINE_QUEUE && p->integrator == KY_INTEGRATOR_PATH_TRACING_ITERATION && !large_scene) {
@@ -521,9 +535,9 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
     HIP_TRY(hipEventRecord(st->ev1, stream));
     st->timing_valid = true;
     c->last_launch = st;
-    const int nf = sh.n_pix * 3;
-    hipLaunchKernelGGL(resolve_kernel, dim3((nf + 255) / 256), dim3(256), 0, stream, accum, flags, d_tiles, nf);
+    hipLaunchKernelGGL(resolve_kernel, dim3((sh.n_pix + 255) / 256), dim3(256), 0, stream, accum, flags, d_tiles, sh.n_pix, st->d_counter);
     HIP_TRY(hipGetLastError());
+    st->ws_clean = own_ws;
     HIP_TRY(hipEventRecord(st->done, stream));
     sc->readers |= 1u << (unsigned)(st - c->ss);
     return KY_OK;

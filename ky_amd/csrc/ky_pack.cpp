@@ -230,6 +230,15 @@ void pack_material(const ky_material& m, DMat* d) {
     // bits 2 / 3: c0 / c1 as packed above is not black (color_t::is_black, 258: every channel <= 0) -- the test of 4588 on a colour that is a constant of the material
     if (!(d->c0[0] <= 0 && d->c0[1] <= 0 && d->c0[2] <= 0)) d->exp_flags |= 4;
     if (!(d->c1[0] <= 0 && d->c1[1] <= 0 && d->c1[2] <= 0)) d->exp_flags |= 8;
+    // bits 16-31: the upper half of a float F with pow(|x|, exponent) == 0 in the device's arithmetic for every |x| <= F (phong_pow_lobe): exp2(exponent x log2|x|)
+    // underflows to zero once the product is below -150; F = 2^(-151 / exponent) leaves the hardware logarithm's last bits a margin, and cutting a positive
+    // float's lower half off only lowers it.  0 (nothing is skipped) for exponents that are not positive and finite.
+    if (m.kind == KY_MATERIAL_PLASTIC && std::isfinite(e) && e > 0.f) {
+        const float F = std::exp2(-151.f / e);
+        uint32_t bits;
+        std::memcpy(&bits, &F, 4);
+        if (F > 0.f && F < 1.f) d->exp_flags |= (int32_t)(bits & 0xffff0000u);
+    }
 }
 
 // the stored normal of a disk / triangle / rectangle must be unit length (the reference's constructors normalise it:

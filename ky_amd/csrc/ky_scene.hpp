@@ -69,7 +69,8 @@ struct DMat {  // ky_material, gathered per lane from LDS
     float c1[3];        // glass T; plastic: cs (n + 2) / (n + 1), the Phong lobe's value / pdf per unit |cos| (bsdf_continue)
     float eta;          // glass: eta; plastic: 1 / (exponent + 1), the power of the Phong lobe's cos(theta) = u^(1/(n+1)) (2515)
     float exponent, phong_pdf_norm, p_specular;   // phong_pdf_norm = (exponent + 1) / 2 pi (2549)
-    int32_t exp_flags;  // bit 0: exponent is integral, bit 1: it is odd (sign of pow(negative, n)); bit 2 / 3: c0 / c1 is not black (some channel positive, or NaN)
+    int32_t exp_flags;  // bit 0: exponent is integral, bit 1: it is odd (sign of pow(negative, n)); bit 2 / 3: c0 / c1 is not black (some channel positive, or NaN);
+                        // bits 16-31: plastic: the upper half of a float F such that pow(|x|, exponent) underflows to 0 for |x| <= F (phong_pow_lobe), else 0
     float cs[3];        // plastic: Ks / P_spec, the Phong lobe's colour (2665)
     float inv_eta;      // glass: 1 / eta (`eta_i / eta_t` entering, 1977 / 2388: the same float division, done once on the host);
                         // plastic: (exponent + 2) / 2 pi, the Phong lobe's normalisation (2505)

@@ -365,7 +365,11 @@ def test_specialised_instantiations_change_nothing(A, api, O, table_kernels, no_
                 assert "integrator %d" % integrator in kernel_on and "strategy 48" in kernel_on, kernel_on
                 if integrator != A.INTEGRATOR_SIMPLE_PATH_TRACING_RECURSION:    # (it samples no lights: one kernel for every scene)
                     # (the iterative integrator's lamp kernel also knows the scene's tables for small: 7 + 128)
-                    assert not table_kernels or (fact if not (flag == A.CB_LIGHT_AREA and integrator == A.INTEGRATOR_PATH_TRACING_ITERATION) else "feat 1415") in kernel_on, (kernel_on, fact)
+                    # (... and the environment light's -- 16 + 128, axis planes 1024, plastic on rectangles 2048 --, whose both_mis estimate is estimate_env_both)
+                    want = fact
+                    if integrator == A.INTEGRATOR_PATH_TRACING_ITERATION:
+                        want = {A.CB_LIGHT_AREA: "feat 1415", A.CB_LIGHT_ENVIRONMENT: "feat 3216"}.get(flag, fact)
+                    assert not table_kernels or want in kernel_on, (kernel_on, want)
                 if integrator != A.INTEGRATOR_PATH_TRACING_ITERATION:
                     assert "strategy -1" in kernel_off, kernel_off
                 fin = np.isfinite(on) & np.isfinite(off)

@@ -354,6 +354,10 @@ void find_boxes(const ky_scene* in, Boxes& B) {
                     if (box.face[f] >= 0 && box.face[f] != k && r[k].lo[ka] == (side ? box.hi[ka] : box.lo[ka])) ok = false;
                 }
             }
+            //  the slab test multiplies coordinate differences by reciprocal directions clamped to +-1e30: beyond 3.4e8 the product overflows to inf,
+            // whose face tag makes a signalling-NaN pattern.  A scene that large (camera included: ray origins) keeps its rectangles.
+            for (int k3 = 0; k3 < 3; ++k3)
+                if (!(std::fabs(box.lo[k3]) < 1e7f && std::fabs(box.hi[k3]) < 1e7f && std::fabs(in->camera.position[k3]) < 1e7f)) ok = false;
             if (!ok || n_faces < KY_BOX_MIN_FACES) continue;
             for (int f = 0; f < 6; ++f) if (box.face[f] >= 0) B.box_of[box.face[f]] = (int)B.box.size();
             B.box.push_back(box);
@@ -659,6 +663,10 @@ int pack_scene(const ky_scene* in, DScene* out) {
         if (l.kind < KY_LIGHT_POINT || l.kind > KY_LIGHT_ENVIRONMENT) return fail(KY_ERR_INVALID_VALUE, "light %d has an unknown kind", i);
         DLight& d = out->light[i];
         cp3(d.color, l.color); cp3(d.position, l.position); cp3(d.direction, l.direction);
+        //  the device decides "this light's colour is black" on the scalar unit from the floats' bits as signed integers (is_black_bits): a NaN with
+        // the sign bit set would read as "<= 0", where color_t::is_black (258) says "not black" for every NaN.  A NaN channel is stored as the positive quiet NaN.
+        for (int j = 0; j < 3; ++j)
+            if (d.color[j] != d.color[j]) d.color[j] = std::numeric_limits<float>::quiet_NaN();
         d.kind = l.kind; d.world_radius = l.world_radius; d.shape_kind = -1;
         d.occ_ok = non.light_ok[i];
         d.shadow_table = (i == non.ts_light) ? ((int32_t)__builtin_offsetof(DScene, occ_front) | 1)

@@ -67,11 +67,19 @@ int kyhip_render_multi(const int* devices, int n_devices, const ky_scene* scene,
     {
         const size_t span = ((size_t)(p->height - 1) * stride_px + (size_t)p->width) * 3 * sizeof(float);
         hipPointerAttribute_t first{}, last{};
-        void* dptr = nullptr;
+        void *dptr = nullptr, *dlast = nullptr;
+        //  both ends pinned is not enough: two adjacent registrations, or one whose device mapping is not one piece, would pass.  The film's
+        // whole span must lie in ONE mapping: the device alias of its last byte is span - 1 bytes beyond the alias of its first, and where the runtime knows
+        // the allocation behind the alias (hipMemGetAddressRange) the span lies inside it.
         if (hipPointerGetAttributes(&first, film_rgb) == hipSuccess && first.type == hipMemoryTypeHost &&
             hipPointerGetAttributes(&last, (const char*)film_rgb + span - 1) == hipSuccess && last.type == hipMemoryTypeHost &&
-            hipHostGetDevicePointer(&dptr, film_rgb, 0) == hipSuccess && dptr)
-            film_in_place = (float*)dptr;
+            hipHostGetDevicePointer(&dptr, film_rgb, 0) == hipSuccess && dptr &&
+            hipHostGetDevicePointer(&dlast, (char*)film_rgb + span - 1, 0) == hipSuccess && dlast == (char*)dptr + span - 1) {
+            hipDeviceptr_t base = nullptr;
+            size_t size = 0;
+            const bool known = hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)dptr) == hipSuccess && base && size;
+            if (!known || ((char*)dptr >= (char*)base && (char*)dptr + span <= (char*)base + size)) film_in_place = (float*)dptr;
+        }
         (void)hipGetLastError();   // "not a registered pointer" is the ordinary answer for a pageable film
     }
     int rcode = seam_reserve(&sb.d_gather, &sb.gather_bytes, rank_stride * n_devices * sizeof(float), false);

@@ -91,6 +91,10 @@ def _check_scene(api, O, scene, params, pixels, n, value_tol, max_bad_fraction, 
                 kind = "continuous, within the Phong lobe's pow amplification" if phong else "continuous, a dim sample after a specular bounce (amplified rounding, within value_tol absolutely)"
             kinds[kind] = kinds.get(kind, 0) + 1
     assert bad <= max_bad_fraction * tot, (bad, tot)
+    #  the "dim sample after a specular bounce" way out is capped: it was measured once in 25 600 samples; four in one scene's 5 120 would be a
+    # regression of that size hiding in it
+    dim = sum(v for k, v in kinds.items() if k.startswith("continuous, a dim sample"))
+    assert dim <= max(2, tot // 2560), (dim, tot, kinds)
     return bad, tot, kinds
 
 

@@ -101,6 +101,7 @@ struct DeviceCtx {
     struct JitKernel { hipModule_t module = nullptr; hipFunction_t fn = nullptr; int per_cu = 0; size_t lds = ~(size_t)0; bool failed = false; };
     std::map<std::string, JitKernel> jit;   // run-time instantiations loaded on this device, by template arguments
     std::string last_jit;                   // ... and the one the last launch used (last_variant == -3)
+    std::string last_note;                  // what kyhip_last_kernel adds about the last launch's own instantiation: being compiled / unavailable / not asked for
 };
 
 int get_ctx(int device, DeviceCtx** out);       // looks the context of `device` up (creating it on first use) and makes the device current for the calling thread

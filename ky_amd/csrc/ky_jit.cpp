@@ -23,8 +23,9 @@
  *   - the /tmp fallback directory (no KYHIP_CACHE_DIR, no HOME) must be a real directory owned by this user with mode 0700, or the cache is not used;
  *   - mode 2: a missing object is compiled by a background thread while the table's kernel renders; the launch code switches when the object is
  *     there (ky_launch.hip).  A frame of kyhip_render_multi uses one kernel for all its shards (frame_begin / frame_end below).
- * Off by default: table and own kernel differ in the last bit of a pixel, so WHEN a process switches is visible -- across the ranks of a
- * multi-process frame it would differ per rank; mode 1 (blocking) is deterministic, mode 2 trades that for not waiting ("run-time instantiations").
+ * Table and own kernel differ in the last bit of a pixel, so WHEN a process switches is visible -- across the ranks of a multi-process frame it would
+ * differ per rank; mode 1 (blocking) is deterministic, mode 2 trades that for not waiting ("run-time instantiations").  Round 6: mode 2 is the default
+ * of a single-process job with a compiler at hand and no profiler attached (default_mode below); KYHIP_JIT=0 keeps the table's kernels.
  * Plain C++ with no HIP call: part of `make sanitize`.
  */
 #include <cctype>
@@ -273,14 +274,36 @@ void finish(State& s, Entry& e, bool ok, std::vector<char>& object, const std::s
 }
 }  // namespace
 
+// The mode a process starts in without KYHIP_JIT (round 6; rounds 4-5: off): ASYNCHRONOUS instantiations (2) where they can run and cannot surprise --
+// a compiler at a known path, no profiler attached to this process (its preload would start inside the compiler's processes), a single-process job (the ranks of
+// a multi-process frame would switch kernels at different times: WORLD_SIZE > 1 keeps the table's kernels; ky_amd/dist.py says the same for callers that build
+// their own groups).  A scene outside the table of facts then renders on the table's kernel for the seconds the compiler needs and on its own from the next
+// frame boundary on (frame_begin / frame_end): 22-25 % faster, last bits of a pixel different.  KYHIP_JIT=0 / kyhip_set_jit(0) keeps a sequence of frames on one kernel.
+int default_mode(std::string* why) {
+    std::string prof;
+    if (under_profiler(&prof)) { *why = "off by default under a profiler (" + prof + " is set)"; return 0; }
+    const char* ws = std::getenv("WORLD_SIZE");
+    if (ws && std::atoi(ws) > 1) { *why = "off by default in a multi-process job (WORLD_SIZE > 1: the ranks of a frame must render on one kernel)"; return 0; }
+    const std::string cc = compiler();
+    if (cc.find('/') == std::string::npos || access(cc.c_str(), X_OK) != 0) { *why = "off by default: no ROCm compiler at a known path (KYHIP_HIPCC names one)"; return 0; }
+    *why = "on by default (asynchronous, mode 2; KYHIP_JIT=0 turns it off): nothing compiled yet";
+    return 2;
+}
+
 int mode() {
     State& s = st();
     std::lock_guard<std::mutex> lock(s.m);
     if (s.mode < 0) {
         const char* e = std::getenv("KYHIP_JIT");
-        const int v = e ? std::atoi(e) : 0;
-        s.mode = (v == 1 || v == 2) ? v : 0;
-        if (s.mode) s.status = "on (nothing compiled yet)";
+        if (e && *e) {
+            const int v = std::atoi(e);
+            s.mode = (v == 1 || v == 2) ? v : 0;
+            s.status = s.mode ? "on (nothing compiled yet)" : "off (KYHIP_JIT=0)";
+        } else {
+            std::string why;
+            s.mode = default_mode(&why);
+            s.status = why;
+        }
     }
     return s.mode;
 }

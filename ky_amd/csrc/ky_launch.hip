@@ -444,6 +444,8 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
         DeviceCtx::JitKernel* jk = nullptr;
         bool queue = v->queue;
         const int jit_mode = kyjit::mode();
+        c->last_note.clear();
+        if (v->strategy < 0 && jit_mode == 0) c->last_note = " [the run-time-dispatched kernel: no row of the table holds this launch's strategy / integrator / shapes; kyhip_set_jit(1 / 2) instantiates its own]";
         if (jit_mode != 0 && specialisation_enabled() && p->integrator >= KY_INTEGRATOR_DIRECT_LIGHTING) {   // (kyhip_set_specialisation(0) asks for the fact-free kernels: nothing to instantiate)
             const bool dbg = p->sampler == KY_SAMPLER_DEBUG, general = sc->h->general != 0;
             int feat = (dbg || general) ? 0 : sc->h->feat;
@@ -475,7 +477,9 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
                     } else if (!pending) {
                         k.failed = true;   // the table's kernel serves this launch and every later one of its kind (kyhip_jit_status() says why)
                     }
+                    if (pending) c->last_note = " [its own instantiation render_kernel<" + std::string(expr) + "> is being compiled (kyhip_set_jit mode 2): this frame ran on the table's kernel]";
                 }
+                if (k.failed) c->last_note = " [its own instantiation is unavailable: " + kyjit::status() + "]";
                 if (k.fn) {
                     if (k.lds != lds_bytes) {
                         int per_cu = 0;
@@ -569,6 +573,7 @@ const char* kyhip_last_kernel(int device) {
                  v.general ? ", general shapes" : "", v.large ? ", scene-sized LDS block" : "", v.feat, v.integrator);
         name = buf;
     }
+    name += c->last_note;
     return name.c_str();
 }
 

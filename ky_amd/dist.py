@@ -86,7 +86,13 @@ def render_shard(scene, params, rank, world, device_index=0, out=None):
         # own background compile finishes -- a matter of timing, so it is refused here.
         mode = lib.kyhip_set_jit(-1)
         if mode == 2:
-            raise RuntimeError("kyhip_set_jit(2) (asynchronous run-time instantiations) would let the ranks of one frame render on different kernels; use mode 1 with world > 1")
+            import os
+            if os.environ.get("KYHIP_JIT") == "2":
+                raise RuntimeError("kyhip_set_jit(2) (asynchronous run-time instantiations) would let the ranks of one frame render on different kernels; use mode 1 with world > 1")
+            # the library's own default (round 6: mode 2 in a single-process job; torchrun's WORLD_SIZE already turns it off): a caller that builds its own
+            # group gets the table's kernels on every rank
+            lib.kyhip_set_jit(0)
+            mode = 0
         if mode == 1 and lib.kyhip_jit_failures() > 0:
             raise RuntimeError("a run-time instantiation failed on this rank (%s): its shards would come from another kernel than the other ranks'" % lib.kyhip_jit_status().decode())
     p = shard_params(params, rank, world)

@@ -15,6 +15,10 @@ def _cpus_granted():
 
 
 os.environ.setdefault("OMP_NUM_THREADS", str(_cpus_granted()))
+# Run-time instantiations are ON by default in a single-process job (asynchronous: a scene outside the table switches kernels a few seconds in); the suite pins
+# the table's kernels so that two renders of one scene are the same image, and tests/test_jit.py sets the modes it tests itself (KYHIP_JIT=1 runs the whole
+# suite on instantiated kernels: the `table_kernels` fixture).
+os.environ.setdefault("KYHIP_JIT", "0")
 
 import numpy as np  # noqa: E402
 import pytest  # noqa: E402

@@ -116,7 +116,8 @@ def test_asynchronous_mode_renders_on_the_table_until_the_object_is_there(A, api
         t0 = time.time()
         first = api.render(scene, p)
         dt_first = time.time() - t0
-        assert lib.kyhip_last_kernel(0) == table_kernel and np.array_equal(first, table)     # nothing compiled yet: the table's kernel, the table's image
+        name = lib.kyhip_last_kernel(0)
+        assert name.split(b" [")[0] == table_kernel and b"is being compiled" in name and np.array_equal(first, table)     # nothing compiled yet: the table's kernel (which says so), the table's image
         assert dt_first < 1.0, dt_first                                                          # (a compile takes 2-3 s)
         own = None
         deadline = time.time() + 60
@@ -132,3 +133,31 @@ def test_asynchronous_mode_renders_on_the_table_until_the_object_is_there(A, api
         assert np.array_equal(api.render(scene, p), own)                                       # from here on: always the own kernel, deterministically
     finally:
         lib.kyhip_set_jit(prev)
+
+
+def test_default_mode_policy(A):
+    """Round 6: without KYHIP_JIT a single-process job with a compiler at hand and no profiler attached starts in mode 2 (asynchronous); KYHIP_JIT=0, a
+    multi-process job (WORLD_SIZE > 1), a profiler's preload or a missing compiler start it in mode 0 -- and say why."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); from ky_amd import _abi as A; lib = A.load_kyhip(); "
+            "print(lib.kyhip_set_jit(-1), '|', lib.kyhip_jit_status().decode())" % root)
+
+    def run(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("KYHIP_JIT", "WORLD_SIZE", "LD_PRELOAD", "KYHIP_HIPCC")}
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        mode, why = out.stdout.strip().splitlines()[-1].split(" | ", 1)
+        return int(mode), why
+
+    mode, why = run()
+    assert (mode, "on by default" in why) == ((2, True) if HIPCC and "/" in HIPCC else (0, False)), (mode, why)
+    assert run(KYHIP_JIT="0")[0] == 0 and run(KYHIP_JIT="1")[0] == 1
+    mode, why = run(WORLD_SIZE="8")
+    assert mode == 0 and "multi-process" in why
+    mode, why = run(ROCPROFSYS_MODE="trace")   # (a variable of a profiler that does nothing by itself: the policy looks at names)
+    assert mode == 0 and "profiler" in why
+    mode, why = run(KYHIP_HIPCC="no-such-compiler")
+    assert mode == 0 and "compiler" in why

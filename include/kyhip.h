@@ -370,7 +370,7 @@ int kyhip_scene_boxes(const ky_scene* scene, int* box_face, int n);
 /* Host only: the facts the library finds for a scene when it packs it -- a mask of the KY_FEAT_* values of ky_amd/csrc/ky_scene.hpp (1 exactly one area light, 2 every
    area light samples a rectangle, 4 few carrier surfaces per light, 8 exactly one point / directional light, 16 exactly one environment light, 32 sphere lamps only,
    64 no mirror or glass, 128 at most 16 surfaces and 8 materials, 256 every lamp is its own one carrier, 512 boxes, 1024 every planar surface is a rectangle in an axis
-   plane, 2048 every plastic surface is a rectangle) -- which decide the render-kernel instantiation a launch takes (kyhip_last_kernel names it).  0 with kyhip_set_specialisation(0); negative: a ky_status. */
+   plane, 2048 every plastic surface is a rectangle, 4096 every tilted rectangle is a plank about the x axis) -- which decide the render-kernel instantiation a launch takes (kyhip_last_kernel names it).  0 with kyhip_set_specialisation(0); negative: a ky_status. */
 int kyhip_scene_facts(const ky_scene* scene);
 
 /* integrator_t::Li per camera sample (3714-3717): for pixel (x, y) and samples [s0, s0+n) writes the

@@ -161,6 +161,7 @@ struct SceneRef {
     }
     __device__ __forceinline__ bool may_have_env() const { return (feat & (KY_FEAT_SINGLE_AREA | KY_FEAT_SINGLE_DELTA | KY_FEAT_SPHERE_LIGHTS)) == 0; }
     __device__ __forceinline__ bool no_carried_light() const { return (feat & (KY_FEAT_SINGLE_DELTA | KY_FEAT_SINGLE_ENV)) != 0; }
+    __device__ __forceinline__ bool x_planks() const { return (feat & KY_FEAT_X_PLANKS) != 0; }
     __device__ __forceinline__ bool sphere_lights() const { return (feat & KY_FEAT_SPHERE_LIGHTS) != 0; }
     __device__ __forceinline__ bool boxes() const { return (feat & KY_FEAT_BOXES) != 0; }
     __device__ __forceinline__ bool flat_phong() const { return (feat & KY_FEAT_FLAT_PHONG) != 0; }   // every plastic surface is a rectangle (bsdf_sample_dir_nondelta)
@@ -325,7 +326,17 @@ KY_DEV bool par_hit(const float4 q0, const float4 q1, const float4 q2, f3 o, f3 
 }
 
 // the same up to the range tests: distance and the hit point's dual-basis coordinates minus one half (hit_update_nearest / hit_update_any test them)
-KY_DEV void par_coords(const float4 q0, const float4 q1, const float4 q2, f3 o, f3 d, float& t, float& u, float& v) {
+// `x_plank` (a compile-time constant at every call: KY_FEAT_X_PLANKS): q0.x = q1.x = q2.y = q2.z = 0 -- the terms they multiply are left out, the sums keep their order
+KY_DEV void par_coords(const float4 q0, const float4 q1, const float4 q2, f3 o, f3 d, float& t, float& u, float& v, bool x_plank = false) {
+    if (x_plank) {
+        const float den = q0.y * d.y + q0.z * d.z;
+        const float num = q0.w - (q0.y * o.y + q0.z * o.z);
+        t = num * rcp(den);
+        const f3 h = o + t * d;
+        u = (h.y * q1.y + h.z * q1.z) - q1.w;
+        v = h.x * q2.x - q2.w;
+        return;
+    }
     const float den = q0.x * d.x + q0.y * d.y + q0.z * d.z;
     const float num = q0.w - (q0.x * o.x + q0.y * o.y + q0.z * o.z);   // n.(p0 - o)
     t = num * rcp(den);
@@ -658,7 +669,7 @@ KY_DEV int trace_nearest(SceneRef S, f3 o, f3 d, float& tmax) {
             asm volatile("" : "+s"(off));
             const DPar& r = scene_at<DPar>(S, off);
             float t, u, v;
-            par_coords(r.q0, r.q1, r.q2, o, d, t, u, v);
+            par_coords(r.q0, r.q1, r.q2, o, d, t, u, v, S.x_planks());
             hit_update_nearest(ex, u, 0.5f, v, 0.5f, t, tmax, best, n_aar + i);
             off += (unsigned)sizeof(DPar);
         }
@@ -709,7 +720,7 @@ KY_DEV bool trace_any_planar(SceneRef S, const DTrav& T, f3 o, f3 d, float tmax)
             asm volatile("" : "+s"(off));
             const DPar& r = scene_at<DPar>(S, off);
             float t, u, v;
-            par_coords(r.q0, r.q1, r.q2, o, d, t, u, v);
+            par_coords(r.q0, r.q1, r.q2, o, d, t, u, v, S.x_planks());
             hit_update_any(ex, u, 0.5f, v, 0.5f, t, tmax, occ);
             off += (unsigned)sizeof(DPar);
         }
@@ -817,9 +828,9 @@ KY_DEV void trace_any_pair(SceneRef S, const AnyRay& A, const AnyRay& B, bool& o
             asm volatile("" : "+s"(off));
             const DPar& r = scene_at<DPar>(S, off);
             float t, u, v;
-            par_coords(r.q0, r.q1, r.q2, A.o, A.d, t, u, v);
+            par_coords(r.q0, r.q1, r.q2, A.o, A.d, t, u, v, S.x_planks());
             hit_update_any_unbounded(ex, u, 0.5f, v, 0.5f, t, occA);
-            par_coords(r.q0, r.q1, r.q2, B.o, B.d, t, u, v);
+            par_coords(r.q0, r.q1, r.q2, B.o, B.d, t, u, v, S.x_planks());
             hit_update_any(ex, u, 0.5f, v, 0.5f, t, B.tmax, occB);
             off += (unsigned)sizeof(DPar);
         }

@@ -278,6 +278,7 @@ static const Variant g_variants[] = {
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES | KY_FEAT_BOXES | KY_FEAT_AXIS_ALIGNED | KY_FEAT_FLAT_PHONG, IT),
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES | KY_FEAT_BOXES, IT),
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES, IT),
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, KY_FEAT_VEACH | KY_FEAT_FLAT_PHONG | KY_FEAT_X_PLANKS, IT),
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, KY_FEAT_VEACH | KY_FEAT_FLAT_PHONG, IT),
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_ENV | KY_FEAT_SMALL_TABLES | KY_FEAT_BOXES | KY_FEAT_AXIS_ALIGNED | KY_FEAT_FLAT_PHONG, IT),
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_ENV | KY_FEAT_SMALL_TABLES | KY_FEAT_AXIS_ALIGNED | KY_FEAT_FLAT_PHONG, IT),
@@ -298,7 +299,8 @@ static const Variant g_variants[] = {
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_ENV | KY_FEAT_SMALL_TABLES | KY_FEAT_BOXES | KY_FEAT_AXIS_ALIGNED | KY_FEAT_FLAT_PHONG, IT),
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_ENV | KY_FEAT_SMALL_TABLES | KY_FEAT_AXIS_ALIGNED | KY_FEAT_FLAT_PHONG, IT),
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_ENV, IT),               // one environment light
-    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, KY_FEAT_VEACH | KY_FEAT_FLAT_PHONG, IT),   // several sphere lights, no mirror / glass, plastic on rectangles only: configs[2]
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, KY_FEAT_VEACH | KY_FEAT_FLAT_PHONG | KY_FEAT_X_PLANKS, IT),   // ... whose tilted rectangles are planks about the x axis: configs[2]
+    KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, KY_FEAT_VEACH | KY_FEAT_FLAT_PHONG, IT),   // several sphere lights, no mirror / glass, plastic on rectangles only: create_mis_scene's materials
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, KY_FEAT_VEACH, IT),                     // several sphere lights, no mirror / glass
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, 0, IT),                                 // many sphere lamps (shadow_queue_wanted): deferred shadow rays
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, 0, IT),

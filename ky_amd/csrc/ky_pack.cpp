@@ -640,6 +640,12 @@ int pack_scene(const ky_scene* in, DScene* out) {
             if (in->materials[in->surfaces[i].material].kind == KY_MATERIAL_PLASTIC && in->shapes[in->surfaces[i].shape].kind != KY_SHAPE_RECTANGLE) flat_phong = false;
         if (flat_phong) out->feat |= KY_FEAT_FLAT_PHONG;
         if (out->trav.n_aar > 0 && out->trav.n_par == 0 && out->n_gen == 0) out->feat |= KY_FEAT_AXIS_ALIGNED;   // (n_gen: the surfaces are laid out above)
+        bool x_planks = out->trav.n_par > 0;   // KY_FEAT_X_PLANKS: the four zeros of every parallelogram record, exactly (a NaN is not a zero)
+        for (int i = 0; i < out->trav.n_par; ++i) {
+            const DPar& r = out->trav.par[i];
+            if (!(r.q0.x == 0.f && r.q1.x == 0.f && r.q2.y == 0.f && r.q2.z == 0.f)) x_planks = false;
+        }
+        if (x_planks) out->feat |= KY_FEAT_X_PLANKS;
     }
     if (non.ts_light >= 0) {
         build_trav(out->occ_front, [&](int i) { return non.wall[i] != 0 || non.ts_behind[i] != 0; });

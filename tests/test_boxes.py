@@ -66,7 +66,7 @@ def test_scene_facts(A, api):
     # the one plastic surface (the floor) a rectangle (2048)
     assert api.scene_facts(area) == 1 + 2 + 4 + 128 + 256 + 512 + 1024 + 2048
     assert api.scene_facts(api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | A.CB_LIGHT_POINT, 64, 64)) == 2 + 4 + 8 + 128 + 512 + 1024 + 2048   # (no area light: 2 and 4 hold vacuously)
-    assert api.scene_facts(api.mis_scene(96, 54)) == 4 + 32 + 64 + 128 + 2048                  # sphere lamps, no delta lobes; its planks are tilted: no 1024
+    assert api.scene_facts(api.mis_scene(96, 54)) == 4 + 32 + 64 + 128 + 2048 + 4096           # sphere lamps, no delta lobes; its planks are tilted (no 1024) about the x axis (4096)
     prev = lib.kyhip_set_boxes(0)
     try:
         assert api.scene_facts(area) == 1 + 2 + 4 + 128 + 256 + 1024 + 2048

@@ -120,7 +120,7 @@ def test_shadow_ray_stacks_grow_with_the_launch(A, api, O, table_kernels):
 def _stacks_grow(A, api, O, lib, sc, p, room, W, H, spp):
     veach = api.mis_scene(W, H)
     full = api.render(veach, p)
-    assert b"deferred shadow rays" in lib.kyhip_last_kernel(0) and b"feat 2276" in lib.kyhip_last_kernel(0), lib.kyhip_last_kernel(0)
+    assert b"deferred shadow rays" in lib.kyhip_last_kernel(0) and b"feat 6372" in lib.kyhip_last_kernel(0), lib.kyhip_last_kernel(0)
     halves = np.zeros_like(full)
     for r in range(2):
         api.render(veach, api.make_params(W, H, spp, tile_first=r, tile_step=2), film=halves)

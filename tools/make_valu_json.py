@@ -27,7 +27,7 @@ SAMPLES = {"cornell": 1024 * 768 * 1024, "veach": 1280 * 720 * 1024, "light_mis"
            "stress": 4096 * 4096 * 256,                       # configs[4]'s geometry (4096 x 4096, depth 16) at 256 of its 16 384 spp: the kernel's rate does not depend on spp
            "batch": 1024 * 1024 * (5 * 256 + 1)}              # configs[3]'s six frames at 256 of their 2048 spp (five path frames + the 1-spp AOV pass)
 LABEL = {"cornell": "render_kernel<strategy 48, feat 3975 (one rectangle area light that is its own carrier, small tables, walls and lamp housing as boxes, every planar surface in an axis plane, plastic on rectangles only), integrator 11> on BASELINE configs[1] (Cornell 1024x768x1024)",
-         "veach": "render_kernel<strategy 48, deferred shadow rays, feat 2276 (sphere lights, no delta lobes, small tables, plastic on rectangles only)> on configs[2]'s scene at 1024 spp (Veach 1280x720)",
+         "veach": "render_kernel<strategy 48, deferred shadow rays, feat 6372 (sphere lights, no delta lobes, small tables, plastic on rectangles only, tilted rectangles are planks about the x axis)> on configs[2]'s scene at 1024 spp (Veach 1280x720)",
          "light_mis": "render_kernel<strategy 32> (the light_mis instantiation) on configs[1]'s scene",
          "recursion": "render_kernel<strategy 48, feat 263, integrator 9> (path_tracing_recursion_t) on configs[1]'s scene",
          "generic": "render_kernel<false,-1> (strategy read at run time; KYHIP_SPECIALISE=0) on configs[1]'s scene with direct_sample light_mis",

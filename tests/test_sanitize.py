@@ -67,7 +67,7 @@ CHILD = textwrap.dedent('''
     assert f == pack(cornell) and f[0] == 1 + 2 + 4 + 128 + 256 + 512 + 1024 + 2048 and f[3] == 5 and f[4] == 0, f      # one rectangle lamp that is its own carrier, walls and lamp housing are boxes, every planar surface in an axis plane; five walls proved away; two-stage scan
     veach = api.mis_scene(1280, 720)
     fv = pack(veach)
-    assert fv[0] == 32 + 4 + 64 + 128 + 2048 and fv[4] == -1, fv
+    assert fv[0] == 32 + 4 + 64 + 128 + 2048 + 4096 and fv[4] == -1, fv      # (4096: its tilted rectangles are planks about the x axis)
     for flag in (A.CB_LIGHT_POINT, A.CB_LIGHT_DIRECTION, A.CB_LIGHT_ENVIRONMENT):
         pack(api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | flag, 256, 256))
     for seed in range(24):                       # rooms nobody tuned for: tilted walls, triangles, disks, every light kind (tests/test_random_scenes_gpu.py)

@@ -30,6 +30,7 @@ unset KYHIP_SPECIALISE
 run recursion --workload cornell --integrator 9   # one of the recursive integrators on its own instantiation (render_multiple_integrator's cells)
 run stress --workload stress --spp 256 --steps 2   # configs[4]'s geometry at 1/64 of its spp (round 5: its own counter set)
 run batch --workload batch --spp 256 --steps 2     # configs[3]'s six frames at 1/8 of their spp (round 5: its own counter set, summed over the step's kernels)
+run single --workload single --spp 512 --steps 2   # ky's own default driver (render_single_scene: the Cornell box under the environment light) at 1/4 of the bench's spp (round 6)
 ./build_variants/valu_peak > gpurun_out/final/${P}_valu_peak_ubench.txt 2>&1
 ./build_variants/valu_pk > gpurun_out/final/${P}_valu_pk_ubench.txt 2>&1
 ./build_variants/salu_mix > gpurun_out/final/${P}_salu_mix_ubench.txt 2>&1
@@ -39,6 +40,7 @@ python3 bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/final/
 python3 bench.py --workload veach --no-extra 2>/dev/null | tail -1 > gpurun_out/final/${P}_bench_line_veach.json
 python3 bench.py --workload batch --no-extra 2>/dev/null | tail -1 > gpurun_out/final/${P}_bench_line_batch.json
 python3 bench.py --workload stress --steps 1 --warmup 0 2>/dev/null | tail -1 > gpurun_out/final/${P}_bench_line_stress.json
+python3 bench.py --workload single --no-extra 2>/dev/null | tail -1 > gpurun_out/final/${P}_bench_line_single.json
 python3 bench.py --workload cornell --direct-sample 32 2>/dev/null | tail -1 > gpurun_out/final/${P}_bench_line_cornell_light_mis.json
 rm -rf gpurun_out/prof_${P}_*   # the raw databases: 3 MB per pass, and gpurun brings home at most 64 MiB
 ls -la gpurun_out/final | tail -40

@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
 SAMPLES = {"cornell": 1024 * 768 * 1024, "veach": 1280 * 720 * 1024, "light_mis": 1024 * 768 * 1024, "generic": 1024 * 768 * 1024, "recursion": 1024 * 768 * 1024,
            "stress": 4096 * 4096 * 256,                       # configs[4]'s geometry (4096 x 4096, depth 16) at 256 of its 16 384 spp: the kernel's rate does not depend on spp
+           "single": 1024 * 1024 * 512,                       # ky's default driver (Cornell box under the environment light, 1024 x 1024) at 512 spp
            "batch": 1024 * 1024 * (5 * 256 + 1)}              # configs[3]'s six frames at 256 of their 2048 spp (five path frames + the 1-spp AOV pass)
 LABEL = {"cornell": "render_kernel<strategy 48, feat 3975 (one rectangle area light that is its own carrier, small tables, walls and lamp housing as boxes, every planar surface in an axis plane, plastic on rectangles only), integrator 11> on BASELINE configs[1] (Cornell 1024x768x1024)",
          "veach": "render_kernel<strategy 48, deferred shadow rays, feat 6372 (sphere lights, no delta lobes, small tables, plastic on rectangles only, tilted rectangles are planks about the x axis)> on configs[2]'s scene at 1024 spp (Veach 1280x720)",
@@ -32,6 +33,7 @@ LABEL = {"cornell": "render_kernel<strategy 48, feat 3975 (one rectangle area li
          "recursion": "render_kernel<strategy 48, feat 263, integrator 9> (path_tracing_recursion_t) on configs[1]'s scene",
          "generic": "render_kernel<false,-1> (strategy read at run time; KYHIP_SPECIALISE=0) on configs[1]'s scene with direct_sample light_mis",
          "stress": "render_kernel<strategy 48, feat 3975> on configs[4]'s geometry (Cornell 4096x4096, depth 16) at 256 spp",
+         "single": "render_kernel<strategy 48, feat 3728 (one environment light, small tables, walls as a box, axis planes only, plastic on rectangles only), integrator 11> on ky's render_single_scene frame at 512 spp",
          "batch": "the six launches of configs[3]'s step (four Cornell light variants, Veach square, AOV pass; 1024x1024) at 256 spp: counters summed over its kernels"}
 
 
@@ -103,7 +105,7 @@ def main():
         lib_sha = open(os.path.join(PROF, prefix + "_kernel_source_hash.txt")).read().split()[0]
     except Exception:
         lib_sha = None
-    for wl in ("cornell", "veach", "light_mis", "generic", "recursion", "stress", "batch"):
+    for wl in ("cornell", "veach", "light_mis", "generic", "recursion", "stress", "batch", "single"):
         if not os.path.exists(os.path.join(PROF, "%s_%s_pmc_sq_issue.txt" % (prefix, wl))):
             continue
         CURRENT[0] = wl

@@ -216,8 +216,11 @@ int         kyhip_set_shadow_queue(int mode);
    launches switch to it once it is there; all shards of one kyhip_render_multi call use one kernel.  WHEN a process switches is a matter of timing,
    and table and own kernel differ in the last bit of a pixel: use mode 1 where frames must be reproducible bit for bit (the ranks of a multi-process
    job: ky_amd/dist.py refuses mode 2 there).
-   mode 0 (default; environment variable KYHIP_JIT=1 / 2 sets the initial mode): the table only.  The image does not depend on the mode beyond the last
-   bit of a pixel (like kyhip_set_specialisation).  If no compiler is found or a compile fails, the table's kernel runs and kyhip_jit_status() says why
+   mode 0: the table only.  The image does not depend on the mode beyond the last bit of a pixel (like kyhip_set_specialisation).
+   The mode a process STARTS in (round 6; rounds 4-5: 0): the environment variable KYHIP_JIT = 0 / 1 / 2 if set; otherwise 2 when this process can run instantiations
+   without surprising anyone -- a compiler at a known path, no profiler attached, a single-process job (WORLD_SIZE unset or 1) -- and 0 when not; kyhip_jit_status()
+   says which and why.  kyhip_last_kernel() names the kernel a launch ran on and adds "[its own instantiation ... is being compiled ...]" / "[... is unavailable: ...]"
+   when that was the table's kernel for the time being.  kyhip_set_jit(-1) returns the mode without changing it.  If no compiler is found or a compile fails, the table's kernel runs and kyhip_jit_status() says why
    (kyhip_jit_failures() counts such compiles: a multi-rank job checks it, because a rank that fell back renders its shards on another kernel).
    The compiler is started with posix_spawn (argv array, no shell) and an environment without LD_PRELOAD / profiler variables; in a process that
    is itself being profiled nothing is compiled ("stands down under a profiler").  Processes share the cache directory safely (flock, write-once).

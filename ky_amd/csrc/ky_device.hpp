@@ -326,17 +326,29 @@ KY_DEV bool par_hit(const float4 q0, const float4 q1, const float4 q2, f3 o, f3 
 }
 
 // the same up to the range tests: distance and the hit point's dual-basis coordinates minus one half (hit_update_nearest / hit_update_any test them)
-// `x_plank` (a compile-time constant at every call: KY_FEAT_X_PLANKS): q0.x = q1.x = q2.y = q2.z = 0 -- the terms they multiply are left out, the sums keep their order
+// ... for a plank about the x axis (KY_FEAT_X_PLANKS): q0.x = q1.x = q2.y = q2.z = 0, the terms they multiply are left out.  The roundings are written out --
+// explicit fused multiply-adds, and the products that must round on their own as instructions the compiler cannot fuse (mul_sv) -- because the sums must round where the
+// general form's do: the compiler fuses a three-term sum x a + y b + z c as fma(z, c, fma(y, b, x a)), which with x = 0 is fma(z, c, round(y b)); left to itself it fuses
+// the two-term sum the other way round, and a plank's hit point then moves by an ulp between the instantiations with and without this fact, which the planks'
+// exponent-5000 lobe turns into 1e-3 of a highlight (tests/test_parity_gpu.py, test_engines_agree).  (Not `#pragma clang fp contract(off)`: one such pragma anywhere
+// in the translation unit changes how the compiler contracts every OTHER function of it -- tests/test_random_scenes_gpu.py, room 8, caught two kernels of the table
+// drifting apart by a decision flip.)
+KY_DEV float mul_sv(float record_field, float x) {   // round(record_field * x): the field from its SGPR (records are read with wave-uniform indices)
+    float r;
+    asm("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "s"(record_field), "v"(x));
+    return r;
+}
+KY_DEV void par_coords_x_plank(const float4 q0, const float4 q1, const float4 q2, f3 o, f3 d, float& t, float& u, float& v) {
+    const float den = __builtin_fmaf(q0.z, d.z, mul_sv(q0.y, d.y));
+    const float num = q0.w - __builtin_fmaf(q0.z, o.z, mul_sv(q0.y, o.y));
+    t = num * rcp(den);
+    const f3 h = mk3(__builtin_fmaf(t, d.x, o.x), __builtin_fmaf(t, d.y, o.y), __builtin_fmaf(t, d.z, o.z));
+    u = __builtin_fmaf(q1.z, h.z, mul_sv(q1.y, h.y)) - q1.w;
+    v = mul_sv(q2.x, h.x) - q2.w;
+}
+// `x_plank` (a compile-time constant at every call: KY_FEAT_X_PLANKS)
 KY_DEV void par_coords(const float4 q0, const float4 q1, const float4 q2, f3 o, f3 d, float& t, float& u, float& v, bool x_plank = false) {
-    if (x_plank) {
-        const float den = q0.y * d.y + q0.z * d.z;
-        const float num = q0.w - (q0.y * o.y + q0.z * o.z);
-        t = num * rcp(den);
-        const f3 h = o + t * d;
-        u = (h.y * q1.y + h.z * q1.z) - q1.w;
-        v = h.x * q2.x - q2.w;
-        return;
-    }
+    if (x_plank) { par_coords_x_plank(q0, q1, q2, o, d, t, u, v); return; }
     const float den = q0.x * d.x + q0.y * d.y + q0.z * d.z;
     const float num = q0.w - (q0.x * o.x + q0.y * o.y + q0.z * o.z);   // n.(p0 - o)
     t = num * rcp(den);

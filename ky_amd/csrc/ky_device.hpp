@@ -681,7 +681,9 @@ KY_DEV int trace_nearest(SceneRef S, f3 o, f3 d, float& tmax) {
             asm volatile("" : "+s"(off));
             const DPar& r = scene_at<DPar>(S, off);
             float t, u, v;
-            par_coords(r.q0, r.q1, r.q2, o, d, t, u, v, S.x_planks());
+            // (the planks' short form, KY_FEAT_X_PLANKS, is taken by the any-hit scans only: here it is worth another 0.5 % of configs[2], but the sphere-lights kernel's
+            // allocation then spills three registers around its five-light loop -- 60 -> 106 GB of memory-side traffic per 9.4e8 samples, docs/rounds/round6.md section 3)
+            par_coords(r.q0, r.q1, r.q2, o, d, t, u, v);
             hit_update_nearest(ex, u, 0.5f, v, 0.5f, t, tmax, best, n_aar + i);
             off += (unsigned)sizeof(DPar);
         }

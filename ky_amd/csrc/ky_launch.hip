@@ -278,7 +278,9 @@ static const Variant g_variants[] = {
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES | KY_FEAT_BOXES | KY_FEAT_AXIS_ALIGNED | KY_FEAT_FLAT_PHONG, IT),
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES | KY_FEAT_BOXES, IT),
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_CORNELL | KY_FEAT_SMALL_TABLES, IT),
+#ifndef KY_NO_XPLANK_ROW   // (measurement builds: the sphere-lights kernel without the planks' fact)
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, KY_FEAT_VEACH | KY_FEAT_FLAT_PHONG | KY_FEAT_X_PLANKS, IT),
+#endif
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, true, false, KY_FEAT_VEACH | KY_FEAT_FLAT_PHONG, IT),
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_ENV | KY_FEAT_SMALL_TABLES | KY_FEAT_BOXES | KY_FEAT_AXIS_ALIGNED | KY_FEAT_FLAT_PHONG, IT),
     KY_VARIANT(false, KY_DIRECT_BOTH_MIS, false, false, KY_FEAT_SINGLE_ENV | KY_FEAT_SMALL_TABLES | KY_FEAT_AXIS_ALIGNED | KY_FEAT_FLAT_PHONG, IT),

@@ -222,7 +222,7 @@ enum : int {
                                  // entered from below its normal: the `if (wo.z < 0) wi.z *= -1` of 2539 is dead code
     KY_FEAT_X_PLANKS = 4096,     // every planar parallelogram that is not an axis rectangle is a plank tilted about the x axis -- n.x = 0, one edge along x, the other in the
                                  // y-z plane (create_mis_scene's four, 3469-3479): its record's q0.x, q1.x, q2.y, q2.z are zeros, and the products with them are not computed
-                                 // (five instructions per plank and ray; bit-identical: x + 0 x y is x)
+                                 // by the any-hit scans (five instructions per plank and ray; the sums round where the general form's do)
     KY_FEAT_SMALL_TABLES = 128   // at most KY_LDS_SURFACES_SMALL surfaces and KY_LDS_MATERIALS_SMALL materials: the per-lane tables' LDS block is 1.1 KB instead of
                                  // 3.8 (what lets the sphere-lights kernel with its deferred rays' sums fit a seventh workgroup per CU)
 };

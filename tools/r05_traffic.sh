@@ -2,7 +2,7 @@
 # tools/r05_traffic.sh <tag> name...: kernel time and memory-side traffic (FETCH_SIZE x 2 + WRITE_SIZE, two pmc passes) of configs[2]'s scene at 1024 spp per variant
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=$1; shift
-mkdir -p gpurun_out/r05
+mkdir -p gpurun_out/r06
 {
 for v in "$@"; do
   export KYHIP_LIB=$PWD/build_variants/$v.so
@@ -17,5 +17,5 @@ for l in sys.stdin:
     rm -rf gpurun_out/tr_${v}_$C gpurun_out/tr_${v}_$C.log
   done
 done
-} > gpurun_out/r05/$TAG.txt 2>&1
-cat gpurun_out/r05/$TAG.txt
+} > gpurun_out/r06/$TAG.txt 2>&1
+cat gpurun_out/r06/$TAG.txt

@@ -65,6 +65,7 @@ import torch  # noqa: E402
 from ky_amd import _abi as A  # noqa: E402
 from ky_amd import api, dist as kydist  # noqa: E402
 
+JIT_DEFAULT_MODE = None   # kyhip_set_jit's mode when this process started (main() pins 0 for the timed workloads)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 MAX_CLOCK_HZ = 2.4e9   # the same guide: max clock 2400 MHz; peak FP32 (vector) 157.3 TFLOP/s = 256 CUs x 128 lanes x 2 (FMA) x 2.4 GHz
 
@@ -423,6 +424,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: ky_amd has no CPU fallback")
     lib = A.load_kyhip()
+    # Run-time instantiations (on by default in a single-process job since round 6) are pinned OFF for everything this file times: every workload of the line runs on the
+    # library's table of kernels, whatever a background compile would have switched to and whenever; the `run_time_instantiations` section measures them on its own
+    global JIT_DEFAULT_MODE
+    JIT_DEFAULT_MODE = int(lib.kyhip_set_jit(-1))
+    lib.kyhip_set_jit(0)
     # KY_BENCH_ONE_GPU=1 (testing only): every rank uses cuda:0 and the gather runs over gloo, so that the N > 1 code
     # path can be exercised on a single-GPU box; the numbers of such a run are meaningless.
     one_gpu_test = os.environ.get("KY_BENCH_ONE_GPU") == "1"
@@ -595,6 +601,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "launch_mode": "pipelined (consecutive frames on two streams)" if pipeline else "single frame (one stream, nothing overlapped)",
+            "kernels": "the library's table (kyhip_set_jit(0) for everything timed here; this process started in mode %s)" % JIT_DEFAULT_MODE,
             "pipeline_priming_steps": R["priming"],   # untimed steps beyond `warmup` that brought the second stream's buffers into being (0 when warmup >= 2)
             "single_frame": ({"value": samples_per_step * args.steps / R1["elapsed"] / 1e6, "unit": "Msamples/s", "ms_per_step": R1["elapsed"] / args.steps * 1e3,
                               "steps": args.steps, "note": "the same steps with every frame on one stream: no overlap of a frame's start with the previous frame's tail"}
@@ -734,7 +741,7 @@ def extra_workloads(args, run_workload, peak_tlaneops, lib, local_rank, kernel_m
              "cornell_lamp_and_point_light": (two, api.make_params(W, H, 256))}
     jit = {}
     prev = lib.kyhip_set_jit(-1)
-    jit["default_mode"] = prev   # what this process started in (round 6: 2 = asynchronous, for a single-process job with a compiler at hand and no profiler attached)
+    jit["default_mode"] = JIT_DEFAULT_MODE   # what this process started in (round 6: 2 = asynchronous, for a single-process job with a compiler at hand and no profiler attached)
     try:
         for label, (scene, p) in cases.items():
             lib.kyhip_set_jit(0)

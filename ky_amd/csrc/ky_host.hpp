@@ -108,6 +108,7 @@ int mode();                                        // 0 off, 1 on (blocking: the
 const Code* get_code(const std::string& args, bool wait = true, bool* pending = nullptr);
 uint64_t source_hash();
 int set_mode(int m);                               // -> the previous mode
+bool mode_by_default();                            // nobody chose the mode: it is default_mode()'s (the launch code then instantiates for fact-free / run-time-dispatched picks only)
 std::string status();
 int failures();                                    // compiles that failed so far in this process
 // A frame that is rendered by several launches (kyhip_render_multi's shards) must not switch kernels in the middle: between frame_begin() and

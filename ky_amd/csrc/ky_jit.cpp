@@ -62,6 +62,7 @@ struct State {   // never destroyed: a background compile may outlive main()
     std::map<std::string, Entry> code;   // template arguments -> code object (node-based: addresses are stable)
     std::string status = "off";
     int mode = -1;
+    bool by_default = true;   // nobody has chosen the mode (KYHIP_JIT, kyhip_set_jit): mode_by_default()
     unsigned long long generation = 0;
     int failures = 0;
 };
@@ -298,6 +299,7 @@ int mode() {
         if (e && *e) {
             const int v = std::atoi(e);
             s.mode = (v == 1 || v == 2) ? v : 0;
+            s.by_default = false;
             s.status = s.mode ? "on (nothing compiled yet)" : "off (KYHIP_JIT=0)";
         } else {
             std::string why;
@@ -313,10 +315,14 @@ int set_mode(int m) {
     State& s = st();
     std::lock_guard<std::mutex> lock(s.m);
     s.mode = m;
+    s.by_default = false;
     if (m == 0) s.status = "off";
     else if (s.status == "off") s.status = "on (nothing compiled yet)";
     return prev;
 }
+// the mode is the one the process started in without being asked (default_mode): the launch code then instantiates only for launches the table serves with a kernel
+// that knows NOTHING of the scene (a fact-free or run-time-dispatched row: "outside the table of facts"), not for every scene that holds one fact more than its row
+bool mode_by_default() { (void)mode(); State& s = st(); std::lock_guard<std::mutex> lock(s.m); return s.by_default; }
 std::string status() { State& s = st(); std::lock_guard<std::mutex> lock(s.m); return s.status; }
 int failures() { State& s = st(); std::lock_guard<std::mutex> lock(s.m); return s.failures; }
 

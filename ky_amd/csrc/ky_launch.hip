@@ -450,7 +450,10 @@ int kyhip_render_tiles_device(int device, const ky_scene* scene, const ky_render
         const int jit_mode = kyjit::mode();
         c->last_note.clear();
         if (v->strategy < 0 && jit_mode == 0) c->last_note = " [the run-time-dispatched kernel: no row of the table holds this launch's strategy / integrator / shapes; kyhip_set_jit(1 / 2) instantiates its own]";
-        if (jit_mode != 0 && specialisation_enabled() && p->integrator >= KY_INTEGRATOR_DIRECT_LIGHTING) {   // (kyhip_set_specialisation(0) asks for the fact-free kernels: nothing to instantiate)
+        // (a mode nobody chose -- the default of round 6 -- instantiates only where the table's pick knows nothing of the scene: a launch served by a row of facts stays on it,
+        // a scene outside the table of facts gets its own kernel; kyhip_set_jit(1 / 2) / KYHIP_JIT instantiate for every launch that is not exactly a row)
+        const bool jit_wanted = jit_mode != 0 && (!kyjit::mode_by_default() || v->feat == 0 || v->strategy < 0);
+        if (jit_wanted && specialisation_enabled() && p->integrator >= KY_INTEGRATOR_DIRECT_LIGHTING) {   // (kyhip_set_specialisation(0) asks for the fact-free kernels: nothing to instantiate)
             const bool dbg = p->sampler == KY_SAMPLER_DEBUG, general = sc->h->general != 0;
             int feat = (dbg || general) ? 0 : sc->h->feat;
             // the box traversal pays where it was measured to (one lamp, one point / directional light: +3-4 %; one environment light under both_mis, whose estimate's two

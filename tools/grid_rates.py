@@ -6,6 +6,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ky_amd import api, _abi as A
 lib = A.load_kyhip()
+lib.kyhip_set_jit(0)   # the rates of the TABLE's kernels (run-time instantiations are on by default since round 6)
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 lights = (("point", A.CB_LIGHT_POINT), ("direction", A.CB_LIGHT_DIRECTION), ("area", A.CB_LIGHT_AREA), ("environment", A.CB_LIGHT_ENVIRONMENT))
 integrators = (("direct_lighting", 6), ("simple_recursion", 8), ("recursion", 9), ("recursion_defered", 10), ("iteration", 11))

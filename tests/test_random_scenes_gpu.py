@@ -146,10 +146,11 @@ def test_random_room(seed, A, api, O):
         # measured: <= 2.4e-7 on rounds 3-5's builds.  The two kernels inline the same expressions into different surroundings, and which multiply-adds the compiler fuses
         # there moves with every edit of the device headers (round 6: code that is dead in both kernels -- the planks' branch of par_coords -- moved one of them): an ulp
         # in a hit distance is a sample that takes another decision once in a few 1e5, i.e. a pixel or two of these 1920 off by (a light's radiance) / spp.  So: every
-        # pixel within 2e-6 but at most four, and those within a single sample's weight -- a defect of the deferral itself moves whole regions, not four pixels.
+        # pixel within 2e-6 but at most ten (half a percent), and those within a single sample's weight -- a defect of the deferral itself moves whole regions, not four pixels.
         d = np.abs(inline - deferred).max(axis=2)
         # (one sample's weight: these rooms' lamps carry up to 16 units of radiance, 1 / 64 of which is 0.25 of a clamped pixel; measured 4.4e-4 on room 8, 0.071 on room 10)
-        assert int((d > 2e-6).sum()) <= 4 and d.max() <= 0.25, (seed, strategy, float(d.max()), int((d > 2e-6).sum()))
+        # (the 72-room soak: 0-6 such pixels per room, i.e. a sample in 2e4 takes another decision between the two kernels -- a tenth of what separates either from the oracle)
+        assert int((d > 2e-6).sum()) <= 10 and d.max() <= 0.25, (seed, strategy, float(d.max()), int((d > 2e-6).sum()))
     print("room %d (%s%s): mismatching samples both_mis %.2f%% light_mis %.2f%% bsdf %.2f%%; film RMSE both_mis %.2e light_mis %.2e" % (
         seed, "+".join(kinds), ", general shapes" if general else "", 100 * rates[A.DIRECT_BOTH_MIS], 100 * rates[A.DIRECT_LIGHT_MIS], 100 * rates[A.DIRECT_BSDF],
         films[A.DIRECT_BOTH_MIS], films[A.DIRECT_LIGHT_MIS]))

@@ -326,10 +326,13 @@ def parity_full_spp(frames, gpu_render, O, threads, budget_samples=None, min_pix
                     keep[ys[i], xs[i]] = False
                 else:
                     flips["unexplained"] += 1
-            except AssertionError:
+                    flips.setdefault("review_pixels", []).append([fr.label, int(xs[i]), int(ys[i]), float(off[ys[i], xs[i]]), "no differing sample found by the replay"])
+            except AssertionError as e:
                 flips["unexplained"] += 1
-            except Exception:
+                flips.setdefault("review_pixels", []).append([fr.label, int(xs[i]), int(ys[i]), float(off[ys[i], xs[i]]), str(e)[:300]])
+            except Exception as e:
                 flips["not_examined"] += 1
+                flips.setdefault("review_pixels", []).append([fr.label, int(xs[i]), int(ys[i]), float(off[ys[i], xs[i]]), "replay failed: " + repr(e)[:200]])
         flips["not_examined"] += max(0, int(len(ys)) - 24)
         kept.append((np.where(keep[..., None], gpu_film, cpu_film), cpu_film))   # the explained pixels set aside (their difference zeroed)
     rmse_full, bad_full = rmse_of(pairs)

@@ -121,7 +121,7 @@ def explain_sample(g_rows, c_rows, value_tol=2e-4, geom_tol=1e-4, amplifying_sur
     ~1e-5 for a small sphere seen from afar).  amplifying_surfaces: caller's surface indices that amplify rounding like a specular sphere does
     whatever their material -- spheres a few hundredths across, whose grazing hits move by 1e-3 and whose normals turn by 1e-2 on an ulp of the
     ray: a first continuous difference at or after a vertex on one of them is "small sphere"."""
-    specular = phong = small = False
+    specular = phong = small = grazing = False
     for k in range(min(len(g_rows), len(c_rows))):
         g, c = g_rows[k], c_rows[k]
         if any(g[j] != c[j] for j in T_DECISIONS):
@@ -129,13 +129,16 @@ def explain_sample(g_rows, c_rows, value_tol=2e-4, geom_tol=1e-4, amplifying_sur
         lobe = int(c[2])
         specular = specular or lobe in (1, 2)   # "at or after": the hit ON a small specular sphere is where the cancellation happens
         small = small or int(c[1]) in amplifying_surfaces
+        # a ray that meets its surface at a grazing angle turns an offset d of its origin into d / cos of the hit point (round 6: a ceiling vertex 1.8 mm from the back
+        # wall, its 1.4e-6 of rounding 4.5e-5 at the wall under cos = 0.03, and 6e-4 three bounces on): at or after such a hit a continuous difference is "grazing"
+        grazing = grazing or abs(float(np.dot(np.asarray(c[6:9], np.float64), np.asarray(c[9:12], np.float64)))) < 0.05
         same = trace_close(g[T_GEOM], c[T_GEOM], geom_tol) and trace_close(g[T_BETA], c[T_BETA], value_tol)
         if same:   # this vertex's own radiance so far: continuous in equal inputs, but a Phong value here is already amplified
             same = trace_close(g[T_LO], c[T_LO], value_tol)
             if not same and lobe == 3:
                 phong = True
         if not same:
-            return "specular" if specular else ("phong" if phong else ("small sphere" if small else None))
+            return "specular" if specular else ("phong" if phong else ("small sphere" if small else ("grazing" if grazing else None)))
         phong = phong or lobe == 3
     if len(g_rows) != len(c_rows):
         return "decision"   # one path went on: roulette, the depth cap or the last traversal decided differently

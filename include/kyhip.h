@@ -353,6 +353,10 @@ int kyhip_kat_light(int device, const ky_scene* scene, int light, const float* i
    occluded: in n x {p[3], normal[3], target[3]}, out n x {0/1}. */
 int kyhip_kat_scene_intersect(int device, const ky_scene* scene, const float* rays7, int n, float* out9);
 int kyhip_kat_occluded(int device, const ky_scene* scene, const float* in9, int n, float* out1);
+/* The any-hit pair scan of the environment light's both_mis estimate (round 6: trace_any_pair, ky_device.hpp): per row two rays through ONE scan of every surface --
+   ray A without an end ("does it leave the scene": scene_t::intersect finds nothing, 4000), ray B ending at tmax_b (scene_t::occluded's scan, 3193-3195) -- with the box
+   traversal when the scene has boxes.  in: n x {o_a[3], d_a[3], o_b[3], d_b[3], tmax_b}.  out: n x {A meets a surface 0/1, B meets one before tmax_b 0/1}. */
+int kyhip_kat_any_pair(int device, const ky_scene* scene, const float* in13, int n, float* out2);
 /* The same query against the occluder tables the render kernels use for shadow rays ("occluder tables").
    light = -1: p and target are promised to lie on surfaces, area lights' shapes or point lights of the scene; rectangles that have the
    whole scene in one closed half-space of their plane (the walls of a room) are not tested.

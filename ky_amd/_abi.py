@@ -127,6 +127,7 @@ KYHIP_SYMBOLS = {
     "kyhip_kat_light": (C.c_int, [C.c_int, SP, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "kyhip_kat_scene_intersect": (C.c_int, [C.c_int, SP, C.c_void_p, C.c_int, C.c_void_p]),
     "kyhip_kat_occluded": (C.c_int, [C.c_int, SP, C.c_void_p, C.c_int, C.c_void_p]),
+    "kyhip_kat_any_pair": (C.c_int, [C.c_int, SP, C.c_void_p, C.c_int, C.c_void_p]),
     "kyhip_kat_occluded_between": (C.c_int, [C.c_int, SP, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "kyhip_scene_non_occluders": (C.c_int, [SP, C.c_int, C.c_void_p, C.c_int]),
     "kyhip_scene_boxes": (C.c_int, [SP, C.c_void_p, C.c_int]),

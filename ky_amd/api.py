@@ -197,6 +197,15 @@ def kat_scene_intersect(scene, rays7, device=0):
     return out
 
 
+def kat_any_pair(scene, in13, device=0):
+    """trace_any_pair (the environment estimate's scan): n x {o_a, d_a, o_b, d_b, tmax_b} -> n x {A meets a surface, B meets one before tmax_b}."""
+    lib = A.load_kyhip()
+    in13 = np.ascontiguousarray(in13, np.float32)
+    out = np.zeros((in13.shape[0], 2), np.float32)
+    _check(lib.kyhip_kat_any_pair(device, _scene_ptr(scene), _fptr(in13), in13.shape[0], _fptr(out)))
+    return out
+
+
 def kat_occluded(scene, in9, device=0, table=None):
     """scene_t::occluded for n x {p, normal, target}.  table None: every surface is tested; -1 / a light index: the occluder table the
     render kernels use for segments between scene points / for shadow rays towards samples of that light (kyhip_kat_occluded_between)."""

@@ -164,6 +164,7 @@ int kyhip_kat_bsdf(int, const ky_material*, const float*, int, float*) { return 
 int kyhip_kat_light(int, const ky_scene*, int, const float*, int, float*) { return no_gpu(); }
 int kyhip_kat_scene_intersect(int, const ky_scene*, const float*, int, float*) { return no_gpu(); }
 int kyhip_kat_occluded(int, const ky_scene*, const float*, int, float*) { return no_gpu(); }
+int kyhip_kat_any_pair(int, const ky_scene*, const float*, int, float*) { return no_gpu(); }
 int kyhip_kat_occluded_between(int, const ky_scene*, int, const float*, int, float*) { return no_gpu(); }
 int kyhip_kat_li(int, const ky_scene*, const ky_render_params*, int, int, int, int, float*) { return no_gpu(); }
 int kyhip_kat_nee(int, const ky_scene*, int, int, const float*, int, float*) { return no_gpu(); }

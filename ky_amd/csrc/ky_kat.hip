@@ -100,6 +100,20 @@ __global__ void kat_occluded_kernel(const DScene* __restrict__ S, const float* _
     out1[i] = occ ? 1.f : 0.f;
 }
 
+// the environment estimate's pair scan (trace_any_pair): ray A unbounded, ray B up to tmax
+template <bool BOXES>
+__global__ void kat_any_pair_kernel(const DScene* __restrict__ S_, const float* __restrict__ in13, int n, float* __restrict__ out2) {
+    const SceneRef S{S_, true, BOXES ? KY_FEAT_BOXES : 0, true};
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = in13 + 13 * (size_t)i;
+    const AnyRay A{ld3(r), ld3(r + 3), K_INF}, B{ld3(r + 6), ld3(r + 9), r[12]};
+    bool occ_a, occ_b;
+    trace_any_pair(S, A, B, occ_a, occ_b);
+    out2[2 * (size_t)i] = occ_a ? 1.f : 0.f;
+    out2[2 * (size_t)i + 1] = occ_b ? 1.f : 0.f;
+}
+
 // BOXES: the launch these samples replay runs a kernel with the box traversal (render_uses_boxes): the replay takes the same one, so that "per sample what render() did" holds
 // to the last decision (a ray along a box's edge may take the other face in the other traversal)
 // single_env (a run-time flag: these kernels are not timed): ... whose both_mis estimate is estimate_env_both (KY_FEAT_SINGLE_ENV): the replay takes that too
@@ -268,6 +282,16 @@ static int kat_occluded_impl(int device, const ky_scene* scene, const float* in9
     });
 }
 int kyhip_kat_occluded(int device, const ky_scene* scene, const float* in9, int n, float* out1) { return kat_occluded_impl(device, scene, in9, n, out1, -2); }
+int kyhip_kat_any_pair(int device, const ky_scene* scene, const float* in13, int n, float* out2) {
+    if (!scene || !in13 || !out2 || n <= 0) return fail(KY_ERR_INVALID_VALUE, "bad KAT arguments");
+    return kat_run(device, in13, (size_t)n * 13 * 4, out2, (size_t)n * 2 * 4, [&](DeviceCtx* c, const float* d_in, float* d_out) {
+        SceneSlot* sc; int r = upload_scene(c, scene, 0, &sc);
+        if (r != KY_OK) return r;
+        if (sc->h->feat & KY_FEAT_BOXES) hipLaunchKernelGGL(kat_any_pair_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, 0, (const DScene*)sc->d, d_in, n, d_out);
+        else hipLaunchKernelGGL(kat_any_pair_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, 0, (const DScene*)sc->d, d_in, n, d_out);
+        return (int)KY_OK;
+    });
+}
 int kyhip_kat_occluded_between(int device, const ky_scene* scene, int light, const float* in9, int n, float* out1) {
     if (light < -1) return fail(KY_ERR_INVALID_VALUE, "light %d out of range", light);
     return kat_occluded_impl(device, scene, in9, n, out1, light);

@@ -236,6 +236,55 @@ def test_kat_scene_intersect_and_occluded(which, A, api, O, rng):
     assert 0.05 < co.mean() < 0.999
 
 
+@pytest.mark.parametrize("which", ["cornell_env", "cornell_lamp", "veach", "cornell_env_no_boxes"])
+def test_kat_any_pair(which, A, api, O, rng):
+    """trace_any_pair (round 6: the environment light's both_mis estimate sends its BSDF-sampled ray -- no end: "does it leave the scene" -- and its light-sampled ray --
+    up to tmax -- through ONE any-hit scan; boxes as slab tests that set a flag, the unbounded ray's chains without their fourth compare) against the oracle's
+    scene_t::intersect: a ray meets a surface before its end iff the nearest-hit scan finds one.  Every disagreement must be a tie."""
+    lib = A.load_kyhip()
+    prev = lib.kyhip_set_boxes(0 if which.endswith("no_boxes") else 1)
+    try:
+        if which.startswith("cornell_env"):
+            scene, box = api.cornell_box_scene(A.CB_BOTH_SMALL_SPHERES | A.CB_LIGHT_ENVIRONMENT, 64, 64), 1.2
+        elif which == "cornell_lamp":
+            scene, box = api.cornell_box_scene(A.CB_DEFAULT_SCENE, 64, 64), 1.2
+        else:
+            scene, box = api.mis_scene(64, 36), 6.0
+        assert (api.scene_facts(scene) & 512 != 0) == (which in ("cornell_env", "cornell_lamp"))     # boxes: the Cornell room (and the lamp housing)
+        n = 8192
+        # origins: half of them a hair off a surface (first hits of random rays, moved 1e-2 along the normal: what spawn_ray makes), half anywhere in the scene's box
+        first = O.kat_scene_intersect(scene, random_rays(rng, 3 * n, origin_box=box, target=rng.uniform(-box, box, (3 * n, 3))))
+        first = first[first[:, 0] == 1][:n]
+        on = first[:, 2:5] + 1e-2 * first[:, 5:8]
+        free = rng.uniform(-box, box, (n, 3))
+        oa, ob = np.where(rng.uniform(size=(n, 1)) < 0.5, on, free), np.where(rng.uniform(size=(n, 1)) < 0.5, on, free)
+        da, db = unit(rng.normal(size=(n, 3))), unit(rng.normal(size=(n, 3)))
+        tb = rng.uniform(0.05, 2.5 * box, n)
+        rows = np.concatenate([oa, da, ob, db, tb[:, None]], 1).astype(np.float32)
+        g = api.kat_any_pair(scene, rows)
+        ra = np.concatenate([rows[:, 0:6], np.full((n, 1), np.inf, np.float32)], 1)
+        rb = np.concatenate([rows[:, 6:12], rows[:, 12:13]], 1)
+        ca, cb = O.kat_scene_intersect(scene, ra)[:, 0], O.kat_scene_intersect(scene, rb)[:, 0]
+        assert (g[:, 0] != ca).mean() < 2e-3 and (g[:, 1] != cb).mean() < 2e-3, ((g[:, 0] != ca).mean(), (g[:, 1] != cb).mean())
+        assert 0.02 < (ca == 0).mean() < 0.98 and 0.02 < (cb == 0).mean() < 0.98          # both answers occur
+        eps = 3e-5
+        for col, rays, c in ((0, ra, ca), (1, rb, cb)):
+            for i in np.flatnonzero(g[:, col] != c):
+                found = False
+                for _ in range(64):
+                    r = rays[i].copy()
+                    r[0:3] += (eps * box) * rng.uniform(-1, 1, 3).astype(np.float32)
+                    r[3:6] = unit(r[3:6] + eps * rng.uniform(-1, 1, 3)).astype(np.float32)
+                    if np.isfinite(r[6]):
+                        r[6] *= 1 + eps * rng.uniform(-1, 1)
+                    if O.kat_scene_intersect(scene, r[None])[0, 0] == g[i, col]:
+                        found = True
+                        break
+                assert found, ("the pair scan differs from the oracle away from any tie", which, col, rays[i], g[i], c[i])
+    finally:
+        lib.kyhip_set_boxes(prev)
+
+
 STRATEGIES = [0, 4, 8, 16, 32, 48]
 
 

@@ -301,3 +301,45 @@ def test_boxy_rooms_nobody_tuned_for(A, api, O, seed):
         e = e_without
     print("boxy room %d: %d boxes, facts %d, kernel %s, film RMSE %.2e%s" % (seed, n_box, facts, kernel.split(" =")[0], e, note))
     assert e < 1e-3, (seed, e, kernel)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KY_BOXY_ROOMS", "8"))))
+def test_boxy_rooms_any_pair(A, api, O, seed):
+    """The any-hit form of the slab test (box_update_any, round 6: the environment estimate's pair scan) on the rooms nobody tuned for -- two or three boxes with four to
+    six faces each, rays from inside, outside and from a hair off the faces themselves, with and without an end: "meets a surface" against the oracle's
+    scene_t::intersect, every disagreement a proven tie."""
+    W, H = 48, 40
+    scene = _boxy_room(A, api, seed, W, H)
+    n_box, _ = api.scene_boxes(scene)
+    assert n_box >= 2
+    rng = np.random.default_rng(700 + seed)
+    n, box = 4096, 1.8
+    first = O.kat_scene_intersect(scene, random_rays(rng, 3 * n, origin_box=box, target=rng.uniform(-box, box, (3 * n, 3))))
+    first = first[first[:, 0] == 1][:n]
+    on = first[:, 2:5] + 1e-2 * first[:, 5:8]
+    free = rng.uniform(-box, box, (len(on), 3))
+    n = len(on)
+    oa, ob = np.where(rng.uniform(size=(n, 1)) < 0.6, on, free), np.where(rng.uniform(size=(n, 1)) < 0.6, on, free)
+    da, db = unit(rng.normal(size=(n, 3))), unit(rng.normal(size=(n, 3)))
+    tb = rng.uniform(0.05, 3.0 * box, n)
+    rows = np.concatenate([oa, da, ob, db, tb[:, None]], 1).astype(np.float32)
+    g = api.kat_any_pair(scene, rows)
+    ra = np.concatenate([rows[:, 0:6], np.full((n, 1), np.inf, np.float32)], 1)
+    rb = np.concatenate([rows[:, 6:12], rows[:, 12:13]], 1)
+    ca, cb = O.kat_scene_intersect(scene, ra)[:, 0], O.kat_scene_intersect(scene, rb)[:, 0]
+    assert (g[:, 0] != ca).mean() < 4e-3 and (g[:, 1] != cb).mean() < 4e-3, (seed, (g[:, 0] != ca).mean(), (g[:, 1] != cb).mean())
+    eps = 3e-5
+    for col, rays, c in ((0, ra, ca), (1, rb, cb)):
+        for i in np.flatnonzero(g[:, col] != c):
+            found = False
+            for _ in range(64):
+                r = rays[i].copy()
+                r[0:3] += (eps * box) * rng.uniform(-1, 1, 3).astype(np.float32)
+                r[3:6] = unit(r[3:6] + eps * rng.uniform(-1, 1, 3)).astype(np.float32)
+                if np.isfinite(r[6]):
+                    r[6] *= 1 + eps * rng.uniform(-1, 1)
+                if O.kat_scene_intersect(scene, r[None])[0, 0] == g[i, col]:
+                    found = True
+                    break
+            assert found, ("the pair scan differs from the oracle away from any tie", seed, col, rays[i], g[i], c[i])

@@ -30,9 +30,6 @@
 #include "ky_scene.hpp"   // DScene and its records, KY_FEAT_*, RenderConst: plain data shared with the host's packing code
 
 #define KY_DEV __device__ __forceinline__
-#ifndef KY_POW_VOTE
-#define KY_POW_VOTE 1
-#endif
 
 // KY_PROBE(k) / KY_CLK(k): lane-utilisation probes and phase clocks of measurement builds (ky_measure.hpp); nothing in product builds
 #if defined(KY_PROFILE_LANES) || defined(KY_PROFILE_CLOCKS) || defined(KY_MARKS)
@@ -955,13 +952,13 @@ KY_DEV float phong_pow(float base, float exponent, int exp_flags) {
 // to exactly zero -- exp2(5000 x log2(0.98)) = 2^-146 -- and for a light sample that is nearly every evaluation.  The host leaves the material a bound F with
 // pow(|x|, exponent) == 0 for |x| <= F in this very arithmetic (DMat::exp_flags, upper half); when NO lane of the vote lies beyond it -- nor holds a NaN, nor a negative
 // base of a non-integral power, which is NaN -- the two quarter-rate instructions and the sign logic are skipped and every lane takes the zero it would have computed
-// (+0 where the odd power of a negative base gives -0: no caller can tell them apart).  Veach: -7 % kernel time; images unchanged.
+// (+0 where the odd power of a negative base gives -0: no caller can tell them apart).  configs[2]: +0.5 % (46.48 -> 46.23 ms at 512 spp); images unchanged.
 KY_DEV float phong_pow_lobe(float base, const DMat& M) {
     const int fl = M.exp_flags;
     const float zero_below = __uint_as_float((unsigned)fl & 0xffff0000u);
     const bool need = !(fabsf(base) <= zero_below) | ((base < 0.f) & !(fl & 1));
     float m = 0.f;
-    if (KY_POW_VOTE ? __any(need) : true) m = phong_pow(base, M.exponent, fl);
+    if (__any(need)) m = phong_pow(base, M.exponent, fl);
     return m;
 }
 

@@ -461,7 +461,7 @@ def main():
         if one_gpu_test:
             tdist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI; never executed on hardware so far
+            tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI; executed on hardware in a world of one only (tests/test_rccl_gpu.py)
         comm = {"backend": tdist.get_backend(), "world": tdist.get_world_size()}   # what the communicator itself reports
     # which physical device each rank renders on (rank 0 prints the list: two ranks on one GPU would show here, not in the rate)
     props0 = torch.cuda.get_device_properties(dev)

@@ -107,10 +107,12 @@ def render_shard(scene, params, rank, world, device_index=0, out=None):
     return tiles
 
 
-def gather_tiles(tiles, rank, world, group=None, out=None, out_list=None):
+def gather_tiles(tiles, rank, world, group=None, out=None, out_list=None, always_collective=False):
     """The one collective of a frame: gather every rank's tile buffer to rank 0.  Returns [world, ...] on rank 0.
-    With `out` ([world, ...]) / `out_list` (its slices) the collective writes straight into that tensor."""
-    if world == 1:
+    With `out` ([world, ...]) / `out_list` (its slices) the collective writes straight into that tensor.
+    always_collective: a world of one calls the communicator too instead of returning its own buffer (tests/test_rccl_gpu.py: the only way a
+    one-GPU box executes the RCCL call this function makes)."""
+    if world == 1 and not always_collective:
         return tiles.unsqueeze(0)
     import torch.distributed as dist
     if rank != 0:
